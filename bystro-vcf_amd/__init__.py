@@ -1,0 +1,267 @@
+"""bystro-vcf_amd — Python binding of libbvcf.so (the MI355X-native per-line variant pipeline).
+
+This package is plumbing for tests and benchmarks: every call goes through the C-ABI declared in
+include/bvcf.h.  There is no Python or CPU implementation of the path here; if the HIP library is
+missing the import fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+# One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).
+# Loading torch first makes libbvcf.so bind to that copy instead of pulling in a second runtime,
+# which would leave the later one without a usable device.
+try:
+    import torch  # noqa: F401
+except ImportError:  # the library then binds to /opt/rocm's runtime through its RUNPATH
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbvcf.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "bystro-vcf_amd: %s not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C bystro-vcf_amd/csrc`); there is no fallback path" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+ABI_VERSION = 1
+DEVICE_PAD = 64
+NO_CMAP = 0xFFFFFFFF
+
+OK, E_ARG, E_HIP, E_NODEV, E_BUSY, E_EMPTY, E_TOO_BIG, E_CAPACITY, E_NOMEM, E_FATAL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+LINE_OK, LINE_FIELDS, LINE_FILTER, LINE_NOALLELE = 0, 1, 2, 3
+SITE_NAMES = ["SNP", "INS", "DEL", "MNP", "MULTIALLELIC"]
+ALT_BASE, ALT_INS, ALT_DEL = 0, 1, 2
+CLS_NONE, CLS_HET, CLS_HOM, CLS_MISSING = 0, 1, 2, 3
+
+# every symbol include/bvcf.h declares
+EXPORTS = [
+    "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_alloc_pinned",
+    "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_bench_device", "bvcf_counters",
+    "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_free",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("device", C.c_int32), ("n_header_fields", C.c_uint32),
+        ("eol_chars", C.c_uint32), ("eol_byte", C.c_uint8), ("want_class_maps", C.c_uint8),
+        ("reserved0", C.c_uint8 * 2), ("allow_filter", C.c_char_p), ("exclude_filter", C.c_char_p),
+        ("max_batch_bytes", C.c_uint64), ("max_lines", C.c_uint32), ("max_alleles", C.c_uint32),
+        ("cmap_bytes", C.c_uint64), ("n_slots", C.c_uint32), ("reserved1", C.c_uint32),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("empty_field", C.c_char_p), ("field_delimiter", C.c_char_p), ("allow_filter", C.c_char_p),
+        ("exclude_filter", C.c_char_p), ("keep_id", C.c_uint8), ("keep_info", C.c_uint8),
+        ("keep_pos", C.c_uint8), ("keep_qual", C.c_uint8), ("normalize_header", C.c_uint8),
+        ("reserved", C.c_uint8 * 3), ("device", C.c_int32), ("n_format_threads", C.c_uint32),
+        ("max_batch_bytes", C.c_uint64),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("batch_seq", C.c_uint64), ("status", C.c_int32), ("n_lines", C.c_uint32), ("n_alleles", C.c_uint32),
+        ("n_errs", C.c_uint32), ("n_cmap_bytes", C.c_uint64), ("cmap_stride", C.c_uint32),
+        ("n_samples", C.c_uint32), ("lines", C.c_void_p), ("alleles", C.c_void_p), ("errs", C.c_void_p),
+        ("cmap", C.c_void_p), ("need_lines", C.c_uint64), ("need_alleles", C.c_uint64),
+        ("need_cmap_bytes", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32),
+    ]
+
+
+LINE_DTYPE = np.dtype([
+    ("off", "<u4"), ("len", "<u4"), ("fend", "<u4", (9,)), ("rec_first", "<u4"), ("n_rec", "<u4"),
+    ("n_fields", "<u4"), ("gt_task", "<u4"), ("status", "u1"), ("site_type", "u1"), ("pad", "u1", (2,))])
+ALLELE_DTYPE = np.dtype([
+    ("pos", "<i8"), ("line", "<u4"), ("alt_idx", "<u4"), ("alt_off", "<u4"), ("alt_len", "<u4"), ("ac", "<u4"),
+    ("an", "<u4"), ("n_het", "<u4"), ("n_hom", "<u4"), ("n_miss", "<u4"), ("cmap_off", "<u4"), ("ref", "u1"),
+    ("alt_base", "u1"), ("kind", "u1"), ("site_type", "u1"), ("trtv", "u1"), ("flags", "u1"), ("pad", "u1", (2,)),
+    ("gt_task", "<u4"), ("pad2", "<u4")])
+ERR_DTYPE = np.dtype([("line", "<u4"), ("alt_no", "<u4"), ("code", "<u4"), ("pad", "<u4")])
+assert LINE_DTYPE.itemsize == 64 and ALLELE_DTYPE.itemsize == 64 and ERR_DTYPE.itemsize == 16
+
+lib.bvcf_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Params)]
+lib.bvcf_create.restype = C.c_int
+lib.bvcf_destroy.argtypes = [C.c_void_p]
+lib.bvcf_destroy.restype = None
+lib.bvcf_last_error.argtypes = [C.c_void_p]
+lib.bvcf_last_error.restype = C.c_char_p
+lib.bvcf_version.restype = C.c_char_p
+lib.bvcf_reserve.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+lib.bvcf_alloc_pinned.argtypes = [C.c_size_t]
+lib.bvcf_alloc_pinned.restype = C.c_void_p
+lib.bvcf_free_pinned.argtypes = [C.c_void_p]
+lib.bvcf_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
+lib.bvcf_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
+lib.bvcf_collect.argtypes = [C.c_void_p, C.POINTER(Result)]
+lib.bvcf_bench_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float),
+                                  C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+lib.bvcf_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+lib.bvcf_config_defaults.argtypes = [C.POINTER(Config)]
+lib.bvcf_config_defaults.restype = None
+lib.bvcf_string_header.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t]
+lib.bvcf_string_header.restype = C.c_size_t
+lib.bvcf_format_tsv.argtypes = [C.POINTER(Config), C.POINTER(Result), C.c_void_p, C.POINTER(C.c_char_p),
+                                C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+lib.bvcf_run_buffer.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                C.POINTER(C.c_uint64)]
+lib.bvcf_run_fd.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+lib.bvcf_free.argtypes = [C.c_void_p]
+lib.bvcf_free.restype = None
+
+
+class BvcfError(RuntimeError):
+    def __init__(self, rc, msg):
+        super().__init__("bvcf error %d: %s" % (rc, msg))
+        self.rc = rc
+
+
+def make_config(cfg=None, device=0, max_batch_bytes=0, n_format_threads=0):
+    """cfg uses the key names of tests/golden/known_answers.json (emptyField, keepId, allow, ...).
+    The returned object keeps the byte strings alive."""
+    cfg = cfg or {}
+    c = Config()
+    lib.bvcf_config_defaults(C.byref(c))
+    keep = [cfg.get("emptyField", "!").encode(), cfg.get("fieldDelimiter", ";").encode(),
+            cfg.get("allow", "PASS,.").encode(), cfg.get("exclude", "").encode()]
+    c.empty_field, c.field_delimiter, c.allow_filter, c.exclude_filter = keep
+    c.keep_id = int(cfg.get("keepId", False))
+    c.keep_info = int(cfg.get("keepInfo", False))
+    c.keep_pos = int(cfg.get("keepPos", False))
+    c.normalize_header = int(cfg.get("normalizeHeader", True))
+    c.device = device
+    c.max_batch_bytes = max_batch_bytes
+    c.n_format_threads = n_format_threads
+    c._keep = keep
+    return c
+
+
+def string_header(cfg=None):
+    c = make_config(cfg)
+    buf = C.create_string_buffer(512)
+    n = lib.bvcf_string_header(C.byref(c), buf, len(buf))
+    return buf.raw[:n].decode()
+
+
+def run_buffer(vcf_bytes, cfg=None, device=0, max_batch_bytes=0, n_format_threads=0):
+    """readVcf on an in-memory VCF through the HIP path.
+    -> (rc, TSV body bytes (no header line), log text, n data lines)"""
+    c = make_config(cfg, device, max_batch_bytes, n_format_threads)
+    out, log = C.c_void_p(), C.c_void_p()
+    n_out, n_log, n_lines = C.c_size_t(), C.c_size_t(), C.c_uint64()
+    rc = lib.bvcf_run_buffer(C.byref(c), vcf_bytes, len(vcf_bytes), C.byref(out), C.byref(n_out), C.byref(log),
+                             C.byref(n_log), C.byref(n_lines))
+    o = C.string_at(out, n_out.value) if out.value else b""
+    e = C.string_at(log, n_log.value).decode(errors="replace") if log.value else ""
+    lib.bvcf_free(out)
+    lib.bvcf_free(log)
+    return rc, o, e, n_lines.value
+
+
+class Batch:
+    """numpy views (copied) of one collected bvcf_result"""
+
+    def __init__(self, r):
+        self.batch_seq = r.batch_seq
+        self.n_samples = r.n_samples
+        self.cmap_stride = r.cmap_stride
+        self.kernel_ms = r.kernel_ms
+
+        def arr(ptr, n, dt):
+            if not n:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer(C.string_at(ptr, n * dt.itemsize), dtype=dt).copy()
+
+        self.lines = arr(r.lines, r.n_lines, LINE_DTYPE)
+        self.alleles = arr(r.alleles, r.n_alleles, ALLELE_DTYPE)
+        self.errs = arr(r.errs, r.n_errs, ERR_DTYPE)
+        self.cmap = arr(r.cmap, r.n_cmap_bytes, np.dtype("u1"))
+
+    def classes(self, allele_row):
+        """per-sample class codes (0 none, 1 het, 2 hom, 3 missing) of one allele record"""
+        off = int(allele_row["cmap_off"])
+        ns = self.n_samples
+        m = self.cmap[off:off + (ns + 3) // 4]
+        return ((m[:, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)) & 3).reshape(-1)[:ns]
+
+
+class Ctx:
+    """one bvcf_ctx (one GPU)"""
+
+    def __init__(self, n_header_fields, allow="PASS,.", exclude="", device=0, eol_chars=1, eol_byte=b"\n",
+                 max_batch_bytes=0, max_lines=0, max_alleles=0, cmap_bytes=0, n_slots=0, want_class_maps=True):
+        p = Params()
+        p.abi_version = ABI_VERSION
+        p.device = device
+        p.n_header_fields = n_header_fields
+        p.eol_chars = eol_chars
+        p.eol_byte = eol_byte[0]
+        p.want_class_maps = int(want_class_maps)
+        self._keep = [allow.encode(), exclude.encode()]
+        p.allow_filter, p.exclude_filter = self._keep
+        p.max_batch_bytes = max_batch_bytes
+        p.max_lines = max_lines
+        p.max_alleles = max_alleles
+        p.cmap_bytes = cmap_bytes
+        p.n_slots = n_slots
+        self.h = C.c_void_p()
+        rc = lib.bvcf_create(C.byref(self.h), C.byref(p))
+        if rc:
+            raise BvcfError(rc, lib.bvcf_last_error(None).decode())
+
+    def close(self):
+        if self.h:
+            lib.bvcf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise BvcfError(rc, lib.bvcf_last_error(self.h).decode())
+
+    def submit(self, block, seq=0):
+        self._blk = block  # keep alive until collect
+        self._check(lib.bvcf_submit(self.h, block, len(block), seq))
+
+    def submit_device(self, dptr, nbytes, seq=0):
+        self._check(lib.bvcf_submit_device(self.h, dptr, nbytes, seq))
+
+    def reserve(self, lines, alleles, cmap_bytes):
+        self._check(lib.bvcf_reserve(self.h, lines, alleles, cmap_bytes))
+
+    def collect(self):
+        r = Result()
+        rc = lib.bvcf_collect(self.h, C.byref(r))
+        if rc == E_CAPACITY:
+            raise BvcfError(rc, "capacity: need lines=%d alleles=%d cmap=%d" % (r.need_lines, r.need_alleles, r.need_cmap_bytes))
+        self._check(rc)
+        return Batch(r)
+
+    def process(self, block):
+        self.submit(block)
+        return self.collect()
+
+    def bench_device(self, dptr, nbytes, iters):
+        chain = (C.c_float * iters)()
+        scan = (C.c_float * iters)()
+        counts = (C.c_uint64 * 4)()
+        self._check(lib.bvcf_bench_device(self.h, dptr, nbytes, iters, chain, scan, counts))
+        return list(chain), list(scan), list(counts)
+
+    def counters(self):
+        out = (C.c_uint64 * 8)()
+        self._check(lib.bvcf_counters(self.h, out))
+        return list(out)

@@ -1,0 +1,535 @@
+// bvcf_core.hip — ctx, slots, launches and the device half of the C-ABI (include/bvcf.h).
+//
+// A ctx owns n_slots independent batch slots on one GPU.  submit = H2D (or adopt a resident
+// block) + the five-kernel chain + D2H of the 24-byte counter block, all on the slot's stream;
+// collect = wait, size check, D2H of exactly the used parts of the result arrays.
+#include "bvcf_device.hip.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+using namespace bvcf_dev;
+
+namespace {
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_ctr = nullptr;
+  // device
+  uint8_t *d_in = nullptr;
+  uint32_t *d_census = nullptr, *d_group = nullptr, *d_line_off = nullptr;
+  bvcf_line *d_lines = nullptr;
+  bvcf_allele *d_alleles = nullptr;
+  bvcf_err *d_errs = nullptr;
+  uint8_t *d_cmap = nullptr;
+  GtTask *d_tasks = nullptr;
+  GtResult *d_results = nullptr;
+  BatchCounters *d_counters = nullptr;
+  // pinned host
+  BatchCounters *h_counters = nullptr;
+  bvcf_line *h_lines = nullptr;
+  bvcf_allele *h_alleles = nullptr;
+  bvcf_err *h_errs = nullptr;
+  uint8_t *h_cmap = nullptr;
+  // capacities this slot was allocated with
+  uint64_t cap_lines = 0, cap_alleles = 0, cap_cmap = 0, cap_census = 0;
+  // in-flight batch
+  bool busy = false;
+  uint64_t seq = 0;
+  size_t nbytes = 0;
+};
+
+}  // namespace
+
+struct bvcf_ctx {
+  bvcf_params p{};
+  int device = 0;
+  int n_cu = 0;
+  int gt_grid = 0;
+  uint32_t n_samples = 0;
+  uint32_t cmap_stride = 0;
+  uint64_t max_lines = 0, max_alleles = 0, max_cmap = 0;
+  FilterTable *d_filters = nullptr;
+  std::vector<Slot> slots;
+  size_t head = 0, tail = 0, in_flight = 0;  // ring of busy slots, oldest at tail
+  uint64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+#define HIP_TRY(ctx, expr)                                                               \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+      return BVCF_E_HIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; }
+
+// main.go:108-123: strings.Split(v, ",") then strings.TrimSpace
+int fill_filter(const char *text, bool star_is_nil, uint32_t *nil, uint32_t *n, uint16_t *off, uint16_t *len,
+                uint8_t *pool, uint32_t *pool_used) {
+  *nil = 1;
+  *n = 0;
+  if (!text || !*text) return 0;
+  if (star_is_nil && strcmp(text, "*") == 0) return 0;
+  *nil = 0;
+  size_t L = strlen(text), start = 0;
+  for (size_t i = 0; i <= L; i++) {
+    if (i != L && text[i] != ',') continue;
+    size_t a = start, e = i;
+    while (a < e && is_space(text[a])) a++;
+    while (e > a && is_space(text[e - 1])) e--;
+    if (*n >= 32 || *pool_used + (e - a) > 2048) return -1;
+    off[*n] = (uint16_t)*pool_used;
+    len[*n] = (uint16_t)(e - a);
+    memcpy(pool + *pool_used, text + a, e - a);
+    *pool_used += (uint32_t)(e - a);
+    (*n)++;
+    start = i + 1;
+  }
+  return 0;
+}
+
+void free_slot(Slot &s) {
+  if (s.stream) hipStreamSynchronize(s.stream);
+  hipFree(s.d_in);
+  hipFree(s.d_census);
+  hipFree(s.d_group);
+  hipFree(s.d_line_off);
+  hipFree(s.d_lines);
+  hipFree(s.d_alleles);
+  hipFree(s.d_errs);
+  hipFree(s.d_cmap);
+  hipFree(s.d_tasks);
+  hipFree(s.d_results);
+  hipFree(s.d_counters);
+  hipHostFree(s.h_counters);
+  hipHostFree(s.h_lines);
+  hipHostFree(s.h_alleles);
+  hipHostFree(s.h_errs);
+  hipHostFree(s.h_cmap);
+  if (s.ev_k0) hipEventDestroy(s.ev_k0);
+  if (s.ev_k1) hipEventDestroy(s.ev_k1);
+  if (s.ev_ctr) hipEventDestroy(s.ev_ctr);
+  if (s.stream) hipStreamDestroy(s.stream);
+  s = Slot{};
+}
+
+// (re)allocate the result arrays of a slot for the ctx's current capacities
+int alloc_results(bvcf_ctx *c, Slot &s) {
+  if (s.cap_lines == c->max_lines && s.cap_alleles == c->max_alleles && s.cap_cmap == c->max_cmap) return BVCF_OK;
+  hipFree(s.d_line_off);
+  hipFree(s.d_lines);
+  hipFree(s.d_alleles);
+  hipFree(s.d_errs);
+  hipFree(s.d_cmap);
+  hipFree(s.d_tasks);
+  hipFree(s.d_results);
+  hipHostFree(s.h_lines);
+  hipHostFree(s.h_alleles);
+  hipHostFree(s.h_errs);
+  hipHostFree(s.h_cmap);
+  s.d_line_off = nullptr;
+  s.d_lines = nullptr;
+  s.d_alleles = nullptr;
+  s.d_errs = nullptr;
+  s.d_cmap = nullptr;
+  s.d_tasks = nullptr;
+  s.d_results = nullptr;
+  s.h_lines = nullptr;
+  s.h_alleles = nullptr;
+  s.h_errs = nullptr;
+  s.h_cmap = nullptr;
+  s.cap_lines = s.cap_alleles = s.cap_cmap = 0;
+  HIP_TRY(c, hipMalloc(&s.d_line_off, (c->max_lines + 1) * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&s.d_lines, c->max_lines * sizeof(bvcf_line)));
+  HIP_TRY(c, hipMalloc(&s.d_alleles, c->max_alleles * sizeof(bvcf_allele)));
+  HIP_TRY(c, hipMalloc(&s.d_errs, c->max_alleles * sizeof(bvcf_err)));
+  HIP_TRY(c, hipMalloc(&s.d_cmap, c->max_cmap + 64));
+  HIP_TRY(c, hipMalloc(&s.d_tasks, c->max_alleles * sizeof(GtTask)));
+  HIP_TRY(c, hipMalloc(&s.d_results, c->max_alleles * sizeof(GtResult)));
+  HIP_TRY(c, hipHostMalloc(&s.h_lines, c->max_lines * sizeof(bvcf_line), hipHostMallocDefault));
+  HIP_TRY(c, hipHostMalloc(&s.h_alleles, c->max_alleles * sizeof(bvcf_allele), hipHostMallocDefault));
+  HIP_TRY(c, hipHostMalloc(&s.h_errs, c->max_alleles * sizeof(bvcf_err), hipHostMallocDefault));
+  HIP_TRY(c, hipHostMalloc(&s.h_cmap, c->max_cmap + 64, hipHostMallocDefault));
+  s.cap_lines = c->max_lines;
+  s.cap_alleles = c->max_alleles;
+  s.cap_cmap = c->max_cmap;
+  return BVCF_OK;
+}
+
+int alloc_slot(bvcf_ctx *c, Slot &s) {
+  HIP_TRY(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  HIP_TRY(c, hipEventCreate(&s.ev_k0));
+  HIP_TRY(c, hipEventCreate(&s.ev_k1));
+  HIP_TRY(c, hipEventCreate(&s.ev_ctr));
+  const uint64_t in_cap = c->p.max_batch_bytes + BVCF_DEVICE_PAD;
+  HIP_TRY(c, hipMalloc(&s.d_in, in_cap));
+  s.cap_census = (c->p.max_batch_bytes + kChunk - 1) / kChunk + 1;
+  HIP_TRY(c, hipMalloc(&s.d_census, s.cap_census * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&s.d_group, (s.cap_census / kScanGroup + 2) * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&s.d_counters, sizeof(BatchCounters)));
+  HIP_TRY(c, hipHostMalloc(&s.h_counters, sizeof(BatchCounters), hipHostMallocDefault));
+  return alloc_results(c, s);
+}
+
+KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) {
+  KernelArgs a{};
+  a.buf = d_src;
+  a.nbytes = (uint32_t)nbytes;
+  a.cap = (uint32_t)(nbytes + BVCF_DEVICE_PAD);
+  a.n_header = c->p.n_header_fields;
+  a.n_samples = c->n_samples;
+  a.eol_chars = c->p.eol_chars;
+  a.eol_byte = c->p.eol_byte;
+  a.want_cmap = c->p.want_class_maps;
+  a.cmap_stride = c->cmap_stride;
+  a.max_lines = (uint32_t)c->max_lines;
+  a.max_alleles = (uint32_t)c->max_alleles;
+  a.max_errs = (uint32_t)c->max_alleles;
+  a.max_tasks = (uint32_t)c->max_alleles;
+  a.max_cmap = c->max_cmap;
+  a.filters = c->d_filters;
+  a.census = s.d_census;
+  a.group_base = s.d_group;
+  a.line_off = s.d_line_off;
+  a.lines = s.d_lines;
+  a.alleles = s.d_alleles;
+  a.errs = s.d_errs;
+  a.cmap = s.d_cmap;
+  a.tasks = s.d_tasks;
+  a.results = s.d_results;
+  a.counters = s.d_counters;
+  return a;
+}
+
+// the kernel chain for one resident block; ev_gt0 / ev_gt1 (optional) bracket the genotype scan
+void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t ev_gt0, hipEvent_t ev_gt1) {
+  const uint32_t n_chunks = (a.nbytes + kChunk - 1) / kChunk;
+  const uint32_t n_groups = (n_chunks + kScanGroup - 1) / kScanGroup;
+  const uint32_t stream_grid = (uint32_t)std::min<uint64_t>((n_chunks + kWavesPerWg - 1) / kWavesPerWg,
+                                                            (uint64_t)c->n_cu * 8);
+  hipLaunchKernelGGL(k_count_eol, dim3(stream_grid ? stream_grid : 1), dim3(kWgThreads), 0, st, a, n_chunks);
+  hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, n_chunks);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
+  hipLaunchKernelGGL(k_scatter_eol, dim3(stream_grid ? stream_grid : 1), dim3(kWgThreads), 0, st, a, n_chunks);
+  hipLaunchKernelGGL(k_head, dim3(c->n_cu * 8), dim3(kWgThreads), 0, st, a);
+  if (a.n_samples) {
+    if (ev_gt0) hipEventRecord(ev_gt0, st);
+    hipLaunchKernelGGL(k_gt, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
+    if (ev_gt1) hipEventRecord(ev_gt1, st);
+    hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
+  } else {
+    if (ev_gt0) hipEventRecord(ev_gt0, st);
+    if (ev_gt1) hipEventRecord(ev_gt1, st);
+  }
+}
+
+int submit_common(bvcf_ctx *c, const uint8_t *host_block, const void *dev_block, size_t nbytes, uint64_t seq) {
+  if (!c) return BVCF_E_ARG;
+  if (nbytes > c->p.max_batch_bytes || nbytes >= 0xFFFFFF00ull) {
+    c->err = "block larger than max_batch_bytes";
+    return BVCF_E_TOO_BIG;
+  }
+  if (c->in_flight == c->slots.size()) {
+    c->err = "all slots in flight";
+    return BVCF_E_BUSY;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  Slot &s = c->slots[c->head];
+  int rc = alloc_results(c, s);
+  if (rc) return rc;
+  const uint8_t *src = (const uint8_t *)dev_block;
+  if (host_block) {
+    HIP_TRY(c, hipMemcpyAsync(s.d_in, host_block, nbytes, hipMemcpyHostToDevice, s.stream));
+    // the pad is read (and masked) by the last lanes of the last chunk: keep it defined
+    HIP_TRY(c, hipMemsetAsync(s.d_in + nbytes, '\n', BVCF_DEVICE_PAD, s.stream));
+    src = s.d_in;
+  }
+  KernelArgs a = make_args(c, s, src, nbytes);
+  HIP_TRY(c, hipEventRecord(s.ev_k0, s.stream));
+  launch_chain(c, a, s.stream, nullptr, nullptr);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(s.ev_k1, s.stream));
+  HIP_TRY(c, hipMemcpyAsync(s.h_counters, s.d_counters, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(c, hipEventRecord(s.ev_ctr, s.stream));
+  s.busy = true;
+  s.seq = seq;
+  s.nbytes = nbytes;
+  c->head = (c->head + 1) % c->slots.size();
+  c->in_flight++;
+  return BVCF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *bvcf_version(void) { return "bvcf-mi355x 0.1 (gfx950)"; }
+
+const char *bvcf_last_error(const bvcf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+void *bvcf_alloc_pinned(size_t nbytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, nbytes ? nbytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void bvcf_free_pinned(void *p) {
+  if (p) hipHostFree(p);
+}
+
+void bvcf_destroy(bvcf_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  for (auto &s : c->slots) free_slot(s);
+  hipFree(c->d_filters);
+  delete c;
+}
+
+int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
+  if (!out || !p) return BVCF_E_ARG;
+  *out = nullptr;
+  if (p->abi_version != BVCF_ABI_VERSION || p->n_header_fields < 1 || p->eol_chars < 1 || p->eol_chars > 2) {
+    g_create_err = "bad bvcf_params";
+    return BVCF_E_ARG;
+  }
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || p->device < 0 || p->device >= n_dev) {
+    // there is deliberately no CPU fallback
+    g_create_err = "no usable HIP device (libbvcf has no CPU fallback)";
+    return BVCF_E_NODEV;
+  }
+  bvcf_ctx *c = new bvcf_ctx();
+  c->p = *p;
+  c->device = p->device;
+  if (!c->p.max_batch_bytes) c->p.max_batch_bytes = 64ull << 20;
+  if (!c->p.n_slots) c->p.n_slots = 2;
+  if (!c->p.eol_byte) c->p.eol_byte = '\n';
+  c->n_samples = p->n_header_fields > 9 ? p->n_header_fields - 9 : 0;
+  c->cmap_stride = ((c->n_samples + 3) / 4 + 15) & ~15u;
+  const uint64_t min_line = std::max<uint64_t>(48, 2ull * p->n_header_fields);
+  c->max_lines = p->max_lines ? p->max_lines : c->p.max_batch_bytes / min_line + 4096;
+  c->max_alleles = p->max_alleles ? p->max_alleles : c->max_lines + c->max_lines / 2;
+  c->max_cmap = p->cmap_bytes ? p->cmap_bytes : c->p.max_batch_bytes / 8 + (1ull << 20);
+  c->max_cmap = (c->max_cmap + 63) & ~63ull;
+  auto fail = [&](int rc) {
+    g_create_err = c->err;
+    bvcf_destroy(c);
+    return rc;
+  };
+  if (hipSetDevice(c->device) != hipSuccess) {
+    c->err = "hipSetDevice failed";
+    return fail(BVCF_E_HIP);
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) {
+    c->err = "hipGetDeviceProperties failed";
+    return fail(BVCF_E_HIP);
+  }
+  c->n_cu = prop.multiProcessorCount;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gt, kWgThreads, 0) != hipSuccess || per_cu < 1)
+    per_cu = 4;
+  c->gt_grid = c->n_cu * per_cu;
+
+  FilterTable ft;
+  memset(&ft, 0, sizeof ft);
+  uint32_t used = 0;
+  if (fill_filter(p->allow_filter, true, &ft.allow_nil, &ft.allow_n, ft.allow_off, ft.allow_len, ft.text, &used) ||
+      fill_filter(p->exclude_filter, false, &ft.deny_nil, &ft.deny_n, ft.deny_off, ft.deny_len, ft.text, &used)) {
+    c->err = "too many / too long FILTER values (32 values, 2048 bytes)";
+    return fail(BVCF_E_ARG);
+  }
+  if (hipMalloc(&c->d_filters, sizeof ft) != hipSuccess ||
+      hipMemcpy(c->d_filters, &ft, sizeof ft, hipMemcpyHostToDevice) != hipSuccess) {
+    c->err = "filter table upload failed";
+    return fail(BVCF_E_HIP);
+  }
+  c->slots.resize(c->p.n_slots);
+  for (auto &s : c->slots) {
+    int rc = alloc_slot(c, s);
+    if (rc) return fail(rc);
+  }
+  *out = c;
+  return BVCF_OK;
+}
+
+int bvcf_reserve(bvcf_ctx *c, uint64_t lines, uint64_t alleles, uint64_t cmap_bytes) {
+  if (!c) return BVCF_E_ARG;
+  if (c->in_flight) {
+    c->err = "bvcf_reserve with batches in flight";
+    return BVCF_E_BUSY;
+  }
+  if (lines > 0xFFFFFFF0ull || alleles > 0xFFFFFFF0ull) return BVCF_E_ARG;
+  c->max_lines = std::max<uint64_t>(c->max_lines, lines);
+  c->max_alleles = std::max<uint64_t>(c->max_alleles, alleles);
+  c->max_cmap = std::max<uint64_t>(c->max_cmap, (cmap_bytes + 63) & ~63ull);
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (auto &s : c->slots) {
+    int rc = alloc_results(c, s);
+    if (rc) return rc;
+  }
+  return BVCF_OK;
+}
+
+int bvcf_submit(bvcf_ctx *c, const uint8_t *block, size_t nbytes, uint64_t batch_seq) {
+  if (!c || (!block && nbytes)) return BVCF_E_ARG;
+  static const uint8_t empty = 0;
+  return submit_common(c, block ? block : &empty, nullptr, nbytes, batch_seq);
+}
+
+int bvcf_submit_device(bvcf_ctx *c, const void *dblock, size_t nbytes, uint64_t batch_seq) {
+  if (!c || !dblock) return BVCF_E_ARG;
+  return submit_common(c, nullptr, dblock, nbytes, batch_seq);
+}
+
+int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
+  if (!c || !r) return BVCF_E_ARG;
+  if (!c->in_flight) {
+    c->err = "nothing to collect";
+    return BVCF_E_EMPTY;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  Slot &s = c->slots[c->tail];
+  auto release = [&]() {
+    s.busy = false;
+    c->tail = (c->tail + 1) % c->slots.size();
+    c->in_flight--;
+  };
+  hipError_t e = hipEventSynchronize(s.ev_ctr);
+  if (e != hipSuccess) {
+    c->err = std::string("kernel chain failed: ") + hipGetErrorString(e);
+    release();
+    return BVCF_E_HIP;
+  }
+  memset(r, 0, sizeof *r);
+  r->batch_seq = s.seq;
+  r->n_samples = c->n_samples;
+  r->cmap_stride = c->cmap_stride;
+  float ms = 0;
+  hipEventElapsedTime(&ms, s.ev_k0, s.ev_k1);
+  r->kernel_ms = ms;
+  const BatchCounters ctr = *s.h_counters;
+  const uint64_t need_alleles = std::max<uint64_t>(std::max<uint64_t>(ctr.n_alleles, ctr.n_errs), ctr.n_tasks);
+  if (ctr.n_lines > s.cap_lines || need_alleles > s.cap_alleles || ctr.cmap_bytes > s.cap_cmap) {
+    r->status = BVCF_E_CAPACITY;
+    r->need_lines = ctr.n_lines;
+    r->need_alleles = need_alleles;
+    r->need_cmap_bytes = ctr.cmap_bytes;
+    c->err = "batch exceeds reserved result capacity";
+    release();
+    return BVCF_E_CAPACITY;
+  }
+  const bool maps = c->p.want_class_maps && c->n_samples;
+  if (ctr.n_lines)
+    HIP_TRY(c, hipMemcpyAsync(s.h_lines, s.d_lines, ctr.n_lines * sizeof(bvcf_line), hipMemcpyDeviceToHost, s.stream));
+  if (ctr.n_alleles)
+    HIP_TRY(c, hipMemcpyAsync(s.h_alleles, s.d_alleles, ctr.n_alleles * sizeof(bvcf_allele), hipMemcpyDeviceToHost,
+                              s.stream));
+  if (ctr.n_errs)
+    HIP_TRY(c, hipMemcpyAsync(s.h_errs, s.d_errs, ctr.n_errs * sizeof(bvcf_err), hipMemcpyDeviceToHost, s.stream));
+  if (maps && ctr.cmap_bytes)
+    HIP_TRY(c, hipMemcpyAsync(s.h_cmap, s.d_cmap, ctr.cmap_bytes, hipMemcpyDeviceToHost, s.stream));
+  e = hipStreamSynchronize(s.stream);
+  if (e != hipSuccess) {
+    c->err = std::string("result copy failed: ") + hipGetErrorString(e);
+    release();
+    return BVCF_E_HIP;
+  }
+  // getAlleles' messages were recorded before the field-count verdict was known: a line that
+  // fails linePasses (main.go:537-539) never reaches getAlleles, so its messages are dropped here
+  uint32_t n_errs = 0;
+  for (uint32_t i = 0; i < ctr.n_errs; i++) {
+    const bvcf_err &er = s.h_errs[i];
+    if (er.line < ctr.n_lines && s.h_lines[er.line].status != BVCF_LINE_FIELDS) s.h_errs[n_errs++] = er;
+  }
+  r->status = BVCF_OK;
+  r->n_lines = ctr.n_lines;
+  r->n_alleles = ctr.n_alleles;
+  r->n_errs = n_errs;
+  r->n_cmap_bytes = maps ? ctr.cmap_bytes : 0;
+  r->lines = s.h_lines;
+  r->alleles = s.h_alleles;
+  r->errs = s.h_errs;
+  r->cmap = s.h_cmap;
+
+  uint64_t ok = 0, ac0 = 0;
+  for (uint32_t i = 0; i < ctr.n_lines; i++) ok += s.h_lines[i].status == BVCF_LINE_OK;
+  if (c->n_samples)
+    for (uint32_t i = 0; i < ctr.n_alleles; i++) ac0 += s.h_alleles[i].ac == 0;
+  c->totals[0] += ctr.n_lines;
+  c->totals[1] += ok;
+  c->totals[2] += ctr.n_alleles;
+  c->totals[3] += ac0;
+  c->totals[4] += n_errs;
+  c->totals[5] += s.nbytes;
+  c->totals[6] += r->n_cmap_bytes;
+  c->totals[7] += (uint64_t)(ms * 1e6);
+  release();
+  return BVCF_OK;
+}
+
+int bvcf_counters(bvcf_ctx *c, uint64_t out[8]) {
+  if (!c || !out) return BVCF_E_ARG;
+  memcpy(out, c->totals, sizeof c->totals);
+  return BVCF_OK;
+}
+
+int bvcf_bench_device(bvcf_ctx *c, const void *dblock, size_t nbytes, int iters, float *chain_ms, float *scan_ms,
+                      uint64_t counts[4]) {
+  if (!c || !dblock || iters < 1) return BVCF_E_ARG;
+  if (c->in_flight) {
+    c->err = "bvcf_bench_device with batches in flight";
+    return BVCF_E_BUSY;
+  }
+  if (nbytes > c->p.max_batch_bytes || nbytes >= 0xFFFFFF00ull) return BVCF_E_TOO_BIG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  Slot &s = c->slots[0];
+  int rc = alloc_results(c, s);
+  if (rc) return rc;
+  KernelArgs a = make_args(c, s, (const uint8_t *)dblock, nbytes);
+  std::vector<hipEvent_t> ev((size_t)iters * 4);
+  for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
+  for (int i = 0; i < iters; i++) {
+    HIP_TRY(c, hipEventRecord(ev[4 * i], s.stream));
+    launch_chain(c, a, s.stream, ev[4 * i + 1], ev[4 * i + 2]);
+    HIP_TRY(c, hipEventRecord(ev[4 * i + 3], s.stream));
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(s.h_counters, s.d_counters, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(c, hipStreamSynchronize(s.stream));
+  for (int i = 0; i < iters; i++) {
+    float t0 = 0, t1 = 0;
+    hipEventElapsedTime(&t0, ev[4 * i], ev[4 * i + 3]);
+    hipEventElapsedTime(&t1, ev[4 * i + 1], ev[4 * i + 2]);
+    if (chain_ms) chain_ms[i] = t0;
+    if (scan_ms) scan_ms[i] = t1;
+  }
+  for (auto &e : ev) hipEventDestroy(e);
+  if (counts) {
+    counts[0] = s.h_counters->n_lines;
+    counts[1] = s.h_counters->n_alleles;
+    counts[2] = s.h_counters->n_errs;
+    counts[3] = s.h_counters->cmap_bytes;
+  }
+  if (s.h_counters->n_lines > s.cap_lines || s.h_counters->n_alleles > s.cap_alleles ||
+      s.h_counters->n_tasks > s.cap_alleles || s.h_counters->cmap_bytes > s.cap_cmap) {
+    c->err = "bench block exceeds reserved result capacity";
+    return BVCF_E_CAPACITY;
+  }
+  return BVCF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1069 @@
+// bvcf_device.hip.h — gfx950 device code of the per-line variant pipeline.
+//
+// Kernels, in launch order per batch:
+//   k_count_eol    newline census per 1 KiB chunk              (readVcf's ReadBytes, main.go:354)
+//   k_scan_groups  exclusive scan of the census, level 1
+//   k_scan_top     level 2 + batch totals
+//   k_scatter_eol  line start offsets from the census           ("workQueue <- buff", main.go:366)
+//   k_head         16 lanes per line: tokenise the fixed columns, FILTER gate, getAlleles;
+//                  emits allele records and one genotype-scan task per (line, ALT index)
+//                                                                (main.go:535-545, 723-1038)
+//   k_gt           one wavefront per task: the per-sample GT byte scan -> ac/an/het/hom/missing
+//                  and the 2-bit class map.  THE HBM-bound kernel.   (main.go:1042-1194)
+//   k_finish       field-count verdict per line, scan results into the allele records
+//
+// Everything is byte/integer work bounded by the HBM read of the line bytes; no MFMA.
+// Loads are 16 B per lane, 1 KiB per wave-instruction, starting exactly at the byte the
+// record window starts at (unaligned dwordx4), so that in a regular sample region
+// ("x|y\t" per sample) every dword in a lane is exactly one sample field.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bvcf.h"
+
+namespace bvcf_dev {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerWg = 4;
+constexpr int kWgThreads = kWave * kWavesPerWg;
+constexpr uint32_t kChunk = 1024;      // bytes per wave-iteration (16 B x 64 lanes)
+constexpr uint32_t kScanGroup = 1024;  // census entries per level-1 scan group
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+
+// FILTER allow / deny sets (config.allowedFilters / excludedFilters, main.go:78-79)
+struct FilterTable {
+  uint32_t allow_nil, allow_n;
+  uint32_t deny_nil, deny_n;
+  uint16_t allow_off[32], allow_len[32];
+  uint16_t deny_off[32], deny_len[32];
+  uint8_t text[2048];
+};
+
+// device-resident batch state
+struct BatchCounters {
+  uint32_t n_lines;      // lines found by the census (may exceed max_lines)
+  uint32_t n_alleles;    // bvcf_allele slots requested
+  uint32_t n_errs;
+  uint32_t n_tasks;      // genotype-scan tasks requested
+  unsigned long long cmap_bytes;  // class-map bytes requested
+};
+
+// one genotype scan: all samples of one line against one ALT index
+struct GtTask {
+  uint32_t line;
+  uint32_t allele;       // alleleNum = ALT index + 1 (main.go:552)
+  uint32_t s_begin;      // first byte after the FORMAT column's TAB
+  uint32_t cend;         // end of the line content (terminator excluded)
+  uint32_t cmap_off;     // BVCF_NO_CMAP if no class map is wanted
+  uint32_t pad[3];
+};
+
+// makeHetHomozygotes' return values for one task, plus the fields it walked
+struct GtResult {
+  uint32_t ac, an, n_het, n_hom, n_miss;
+  uint32_t n_fields;     // sample fields present on the line
+  uint32_t pad[2];
+};
+
+struct KernelArgs {
+  const uint8_t *buf;
+  uint32_t nbytes;       // bytes of whole lines
+  uint32_t cap;          // bytes that may be read (nbytes + pad)
+  uint32_t n_header;     // len(header)
+  uint32_t n_samples;    // len(header) - 9, or 0
+  uint32_t eol_chars;
+  uint32_t eol_byte;
+  uint32_t want_cmap;
+  uint32_t cmap_stride;
+  uint32_t max_lines, max_alleles, max_errs, max_tasks;
+  unsigned long long max_cmap;
+  const FilterTable *filters;
+  uint32_t *census;      // [n_chunks] newline count per chunk -> exclusive prefix within group
+  uint32_t *group_base;  // [n_groups]
+  uint32_t *line_off;    // [max_lines + 1]
+  bvcf_line *lines;
+  bvcf_allele *alleles;
+  bvcf_err *errs;
+  uint8_t *cmap;
+  GtTask *tasks;
+  GtResult *results;
+  BatchCounters *counters;
+};
+
+// ------------------------------------------------------------------ wave helpers
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+  return v;
+}
+
+// exclusive prefix sum over the 64 lanes; *total receives the wave sum
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, kWave);
+    if (lane_id() >= d) inc += t;
+  }
+  *total = __shfl(inc, kWave - 1, kWave);
+  return inc - v;
+}
+
+__device__ __forceinline__ uint32_t bcast0(uint32_t v) { return __shfl(v, 0, kWave); }
+
+// 16 bytes at buf+off for this lane (any alignment); zeros if the window leaves [0, cap)
+__device__ __forceinline__ u32x4 load16(const uint8_t *buf, uint32_t off, uint32_t cap) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (off + 16u <= cap) v = *reinterpret_cast<const u32x4_u *>(buf + off);
+  return v;
+}
+
+// 0x80 in every byte of x that is zero, exact (no borrow artefacts)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x) {
+  uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  return ~(t | x | 0x7F7F7F7Fu);
+}
+
+// 4-bit mask: bit k set iff byte k of d equals c
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t d, uint32_t c4) {
+  uint32_t z = zero_bytes(d ^ c4) >> 7;  // bits 0,8,16,24
+  return ((z * 0x00204081u) >> 21) & 0xFu;
+}
+
+// 16-bit mask over the lane's 16 bytes
+__device__ __forceinline__ uint32_t eq_mask16(u32x4 v, uint32_t c) {
+  uint32_t c4 = c * 0x01010101u;
+  return eq_mask4(v.x, c4) | (eq_mask4(v.y, c4) << 4) | (eq_mask4(v.z, c4) << 8) | (eq_mask4(v.w, c4) << 12);
+}
+
+// bits [0, n) of a 16-bit mask, n may be <= 0 or >= 16
+__device__ __forceinline__ uint32_t low_bits16(int n) {
+  return n <= 0 ? 0u : (n >= 16 ? 0xFFFFu : ((1u << n) - 1u));
+}
+
+// ------------------------------------------------------------------ line index
+
+// newline census: one wave per 1 KiB chunk
+__global__ __launch_bounds__(kWgThreads) void k_count_eol(KernelArgs a, uint32_t n_chunks) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  for (uint32_t c = wave; c < n_chunks; c += stride) {
+    const uint32_t off = c * kChunk + 16u * lane;
+    u32x4 v = load16(a.buf, off, a.cap);
+    uint32_t m = eq_mask16(v, a.eol_byte) & low_bits16((int)a.nbytes - (int)off);
+    uint32_t tot = wave_sum(__popc(m));
+    if (lane == 0) a.census[c] = tot;
+  }
+}
+
+// level 1: exclusive scan inside groups of kScanGroup census entries; group totals out
+__global__ __launch_bounds__(kWgThreads) void k_scan_groups(KernelArgs a, uint32_t n_chunks) {
+  __shared__ uint32_t s_wave[kWavesPerWg];
+  const int lane = lane_id();
+  const int w = threadIdx.x >> 6;
+  const uint32_t g = blockIdx.x;
+  const uint32_t base = g * kScanGroup + threadIdx.x * 4u;  // 4 entries per thread
+  uint32_t e[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) e[i] = (base + i < n_chunks) ? a.census[base + i] : 0u;
+  uint32_t mine = e[0] + e[1] + e[2] + e[3];
+  uint32_t wtot;
+  uint32_t pre = wave_excl_scan(mine, &wtot);
+  if (lane == 0) s_wave[w] = wtot;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int i = 0; i < w; i++) wbase += s_wave[i];
+  uint32_t run = wbase + pre;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (base + i < n_chunks) a.census[base + i] = run;
+    run += e[i];
+  }
+  if (threadIdx.x == kWgThreads - 1) a.group_base[g] = run;  // group total (scanned next)
+}
+
+// level 2: exclusive scan of the group totals (single workgroup), batch line count, counters reset
+__global__ __launch_bounds__(1024) void k_scan_top(KernelArgs a, uint32_t n_groups) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t per = (n_groups + 1023u) / 1024u;
+  const uint32_t lo = threadIdx.x * per;
+  uint32_t sum = 0;
+  for (uint32_t i = 0; i < per; i++)
+    if (lo + i < n_groups) sum += a.group_base[lo + i];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  // Hillis-Steele over 1024 partials
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t t = threadIdx.x >= (unsigned)d ? s_part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    s_part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = s_part[threadIdx.x] - sum;
+  for (uint32_t i = 0; i < per; i++) {
+    if (lo + i < n_groups) {
+      uint32_t v = a.group_base[lo + i];
+      a.group_base[lo + i] = run;
+      run += v;
+    }
+  }
+  if (threadIdx.x == 1023) {
+    a.counters->n_lines = s_part[1023];
+    a.counters->n_alleles = 0;
+    a.counters->n_errs = 0;
+    a.counters->n_tasks = 0;
+    a.counters->cmap_bytes = 0ull;
+    a.line_off[0] = 0u;
+  }
+}
+
+// line_off[i + 1] = offset just past line i's terminator
+__global__ __launch_bounds__(kWgThreads) void k_scatter_eol(KernelArgs a, uint32_t n_chunks) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  for (uint32_t c = wave; c < n_chunks; c += stride) {
+    const uint32_t next = (c + 1 < n_chunks && ((c + 1) % kScanGroup) != 0) ? a.census[c + 1] : 0xFFFFFFFFu;
+    const uint32_t mine = a.census[c];
+    // chunks without a terminator are skipped without touching the text again
+    if (next == mine) continue;
+    const uint32_t off = c * kChunk + 16u * lane;
+    u32x4 v = load16(a.buf, off, a.cap);
+    uint32_t m = eq_mask16(v, a.eol_byte) & low_bits16((int)a.nbytes - (int)off);
+    uint32_t tot;
+    uint32_t pre = wave_excl_scan(__popc(m), &tot);
+    uint32_t idx = a.group_base[c / kScanGroup] + mine + pre;
+    while (m) {
+      uint32_t k = __ffs(m) - 1;
+      m &= m - 1;
+      if (idx < a.max_lines) a.line_off[idx + 1] = off + k + 1;
+      idx++;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ getAlleles (one lane)
+
+struct Span {
+  uint32_t off, len;
+};
+
+// strconv.Atoi on buf[s.off .. +len): optional sign, digits, must fit int64 (main.go:752,824)
+__device__ inline bool go_atoi(const uint8_t *buf, Span s, long long *out) {
+  if (s.len == 0) return false;
+  uint32_t i = 0;
+  bool neg = false;
+  uint8_t c0 = buf[s.off];
+  if (c0 == '+' || c0 == '-') {
+    neg = c0 == '-';
+    i = 1;
+    if (s.len == 1) return false;
+  }
+  unsigned long long v = 0;
+  const unsigned long long lim = neg ? 9223372036854775808ull : 9223372036854775807ull;
+  #pragma nounroll
+  for (; i < s.len; i++) {
+    uint32_t d = (uint32_t)buf[s.off + i] - '0';
+    if (d > 9u) return false;
+    if (v > (lim - d) / 10ull) return false;
+    v = v * 10ull + d;
+  }
+  *out = neg ? (long long)(0ull - v) : (long long)v;
+  return true;
+}
+
+__device__ __forceinline__ bool is_actg(uint8_t c) { return c == 'A' || c == 'C' || c == 'T' || c == 'G'; }
+
+// parse.GetTrTv restated (oracle/bvcf_oracle.c orc_get_trtv)
+__device__ __forceinline__ uint8_t trtv_of(uint8_t ref, uint8_t alt) {
+  if (!is_actg(ref) || !is_actg(alt)) return 0;
+  bool tr = (ref == 'A' && alt == 'G') || (ref == 'G' && alt == 'A') || (ref == 'C' && alt == 'T') ||
+            (ref == 'T' && alt == 'C');
+  return tr ? 1 : 2;
+}
+
+// per-allele GT statistics (makeHetHomozygotes' return values)
+struct GtStats {
+  uint32_t ac, an, n_het, n_hom, n_miss;
+};
+
+// lane-0 state of one line's getAlleles evaluation
+struct AlleleCtx {
+  const uint8_t *buf;
+  Span chrom, pos, ref, alt;
+  long long int_pos;   // intPos, main.go:767
+  bool pos_bad;        // Atoi failed: the ALT loop is over (main.go:826-829)
+  uint32_t line;
+};
+
+// what one ALT token yields
+struct AlleleEval {
+  uint32_t n;          // records this token produces
+  uint32_t err;        // BVCF_ERR_* to log, 0 if none
+  bool stop;           // "Invalid POS": break out of the ALT loop
+  // single-record description (n == 1 and !mnp)
+  bool mnp;            // records are the differing bases of an equal-length block
+  long long pos;
+  bool pos_text;
+  uint8_t ref, alt_base, kind;
+  uint32_t alt_off, alt_len;
+};
+
+// The single-ALT-byte path, main.go:735-765.  t is the whole ALT field (1 byte).
+__device__ inline void eval_single(AlleleCtx &c, AlleleEval &e) {
+  const uint8_t *b = c.buf;
+  e = AlleleEval{};
+  const uint8_t a0 = b[c.alt.off];
+  if (a0 != 'A' && a0 != 'C' && a0 != 'G' && a0 != 'T') {
+    e.err = BVCF_ERR_BAD_ALT1;
+    return;
+  }
+  if (c.ref.len == 1) {
+    e.n = 1;
+    e.pos_text = true;
+    e.ref = b[c.ref.off];
+    e.alt_base = a0;
+    e.kind = BVCF_ALT_BASE;
+    e.alt_len = 1;
+    return;
+  }
+  if (c.ref.len == 0) {
+    e.err = BVCF_ERR_EMPTY_REF;
+    return;
+  }
+  if (a0 != b[c.ref.off]) {
+    e.err = BVCF_ERR_DEL1_1;
+    return;
+  }
+  long long p;
+  if (!go_atoi(b, c.pos, &p)) {
+    e.err = BVCF_ERR_POS1;
+    return;
+  }
+  e.n = 1;
+  e.pos = p + 1;
+  e.ref = b[c.ref.off + 1];
+  e.kind = BVCF_ALT_DEL;
+  e.alt_len = c.ref.len - 1;
+}
+
+// One token of strings.Split(alt, ","), main.go:774-999.  t = token span.
+__device__ inline void eval_token(AlleleCtx &c, Span t, AlleleEval &e) {
+  const uint8_t *b = c.buf;
+  e = AlleleEval{};
+  // altIsValid, main.go:456-474 (empty token: Go would panic; invalid here)
+  bool valid = t.len > 0;
+  #pragma nounroll
+  for (uint32_t i = 0; i < t.len && valid; i++) valid = is_actg(b[t.off + i]);
+  if (!valid) {
+    e.err = BVCF_ERR_BAD_ALT;
+    return;
+  }
+  const uint32_t nref = c.ref.len, nt = t.len;
+  if (nref == 1) {  // main.go:786-815
+    if (nt == 1) {
+      e.n = 1;
+      e.pos_text = true;
+      e.ref = b[c.ref.off];
+      e.alt_base = b[t.off];
+      e.kind = BVCF_ALT_BASE;
+      e.alt_len = 1;
+      return;
+    }
+    if (b[t.off] != b[c.ref.off]) {
+      e.err = BVCF_ERR_INS1;
+      return;
+    }
+    e.n = 1;
+    e.pos_text = true;
+    e.ref = b[c.ref.off];
+    e.kind = BVCF_ALT_INS;
+    e.alt_off = t.off + 1;
+    e.alt_len = nt - 1;
+    return;
+  }
+  // main.go:822-830
+  if (c.int_pos == 0) {
+    long long p;
+    if (!go_atoi(b, c.pos, &p)) {
+      e.err = BVCF_ERR_POS;
+      e.stop = true;
+      return;
+    }
+    c.int_pos = p;
+  }
+  if (nt == 1) {  // main.go:832-847
+    if (b[t.off] != b[c.ref.off]) {
+      e.err = BVCF_ERR_DEL1;
+      return;
+    }
+    e.n = 1;
+    e.pos = c.int_pos + 1;
+    e.ref = b[c.ref.off + 1];
+    e.kind = BVCF_ALT_DEL;
+    e.alt_len = nref - 1;
+    return;
+  }
+  if (nt == nref) {  // main.go:855-873
+    uint32_t n = 0;
+    #pragma nounroll
+    for (uint32_t i = 0; i < nref; i++) n += b[c.ref.off + i] != b[t.off + i];
+    e.n = n;
+    e.mnp = true;
+    return;
+  }
+  if (nt > nref) {  // main.go:899-958
+    int r = 0;
+    const int lt = (int)nt, lr = (int)nref;
+    #pragma nounroll
+    while (lt + r > 0 && lr + r > 1 && b[t.off + lt + r - 1] == b[c.ref.off + lr + r - 1]) r--;
+    const int offset = lr + r;
+    #pragma nounroll
+    for (int i = 0; i < offset; i++)
+      if (b[c.ref.off + i] != b[t.off + i]) {
+        e.err = BVCF_ERR_MIXED;
+        return;
+      }
+    e.n = 1;
+    e.pos = c.int_pos + offset - 1;
+    e.ref = b[c.ref.off + offset - 1];
+    e.kind = BVCF_ALT_INS;
+    e.alt_off = t.off + offset;
+    e.alt_len = (uint32_t)(lt + r - offset);
+    return;
+  }
+  {  // main.go:971-998
+    int r = 0;
+    const int lt = (int)nt, lr = (int)nref;
+    #pragma nounroll
+    while (lt + r > 1 && lr + r > 0 && b[t.off + lt + r - 1] == b[c.ref.off + lr + r - 1]) r--;
+    const int offset = lt + r;
+    #pragma nounroll
+    for (int i = 0; i < offset; i++)
+      if (b[c.ref.off + i] != b[t.off + i]) {
+        e.err = BVCF_ERR_MIXED;
+        return;
+      }
+    e.n = 1;
+    e.pos = c.int_pos + offset;
+    e.ref = b[c.ref.off + offset];
+    e.kind = BVCF_ALT_DEL;
+    e.alt_len = (uint32_t)(lr + r - offset);
+  }
+}
+
+// next token of the ALT field starting at *cursor (relative to alt.off); false when exhausted
+__device__ inline bool next_token(const AlleleCtx &c, uint32_t *cursor, Span *t) {
+  if (*cursor > c.alt.len) return false;
+  uint32_t s = *cursor, i = s;
+  #pragma nounroll
+  while (i < c.alt.len && c.buf[c.alt.off + i] != ',') i++;
+  t->off = c.alt.off + s;
+  t->len = i - s;
+  *cursor = i + 1;
+  return true;
+}
+
+__device__ inline void log_err(const KernelArgs &a, uint32_t line, uint32_t alt_no, uint32_t code) {
+  uint32_t i = atomicAdd(&a.counters->n_errs, 1u);
+  if (i < a.max_errs) {
+    bvcf_err e;
+    e.line = line;
+    e.alt_no = alt_no;
+    e.code = code;
+    e.pad = 0;
+    a.errs[i] = e;
+  }
+}
+
+// ------------------------------------------------------------------ GT scan (whole wave)
+
+// Exact restatement of one sample field of makeHetHomozygotes (main.go:1057-1190) for the
+// allele whose decimal text is itoa(a): byte-serial, used for irregular lines.
+// p = field start, cend = end of line content; a field ends at '\t' or cend.
+__device__ inline void classify_field(const uint8_t *buf, uint32_t p, uint32_t cend, uint32_t a, uint32_t a_ndigits,
+                                      uint32_t *cls, uint32_t *altc, uint32_t *gtc) {
+  auto getc = [&](uint32_t q) -> uint32_t { return q < cend ? (uint32_t)buf[q] : (uint32_t)'\t'; };
+  *altc = 0;
+  *gtc = 0;
+  *cls = BVCF_CLS_NONE;
+  // fast gate, main.go:1063-1064: (len == 3 || g[3] == ':') && g[1] in {'|','/'}
+  uint32_t c0 = getc(p), c1 = '\t', c2 = '\t', c3 = '\t';
+  if (c0 != '\t') {
+    c1 = getc(p + 1);
+    if (c1 != '\t') {
+      c2 = getc(p + 2);
+      if (c2 != '\t') c3 = getc(p + 3);
+    }
+  }
+  const bool have3 = c0 != '\t' && c1 != '\t' && c2 != '\t';
+  if (have3 && (c3 == '\t' || c3 == ':') && (c1 == '|' || c1 == '/')) {
+    if (c0 == '0' && c2 == '0') {
+      *gtc = 2;
+      return;
+    }
+    if (a_ndigits == 1) {
+      const uint32_t ac = '0' + a;
+      if ((c0 == '0' && c2 == ac) || (c0 == ac && c2 == '0')) {
+        *gtc = 2;
+        *altc = 1;
+        *cls = BVCF_CLS_HET;
+        return;
+      }
+      if (c0 == ac && c2 == ac) {
+        *gtc = 2;
+        *altc = 2;
+        *cls = BVCF_CLS_HOM;
+        return;
+      }
+    }
+    if (c0 == '.' || c2 == '.') {
+      *cls = BVCF_CLS_MISSING;
+      return;
+    }
+  }
+  // general path, main.go:1126-1190.  f = field up to the first ':'
+  uint32_t nf = 0;
+  bool has_bar = false, has_slash = false;
+  #pragma nounroll
+  for (;; nf++) {
+    uint32_t ch = getc(p + nf);
+    if (ch == '\t' || ch == ':') break;
+    has_bar |= ch == '|';
+    has_slash |= ch == '/';
+  }
+  const uint32_t sep = has_bar ? '|' : (has_slash ? '/' : 0xFFFFFFFFu);
+  uint32_t alt_count = 0, gt_count = 0;
+  // token state
+  uint32_t tlen = 0;
+  unsigned long long val = 0;
+  bool digits = true, lead0 = false, dot = false;
+  #pragma nounroll
+  for (uint32_t k = 0; k <= nf; k++) {
+    uint32_t ch = k < nf ? getc(p + k) : sep;
+    if (k == nf || ch == sep) {
+      if (tlen == 1 && dot) {  // allele == "." => whole sample missing, nothing counted
+        *cls = BVCF_CLS_MISSING;
+        return;
+      }
+      if (tlen >= 1 && tlen <= 10 && digits && !lead0 && val == (unsigned long long)a) alt_count++;
+      gt_count++;
+      tlen = 0;
+      val = 0;
+      digits = true;
+      lead0 = false;
+      dot = false;
+      continue;
+    }
+    if (tlen == 0) {
+      dot = ch == '.';
+      lead0 = ch == '0';
+    }
+    uint32_t d = ch - '0';
+    if (d > 9u)
+      digits = false;
+    else if (tlen < 11)
+      val = val * 10ull + d;
+    tlen++;
+  }
+  *gtc = gt_count;
+  *altc = alt_count;
+  if (alt_count != 0) *cls = alt_count == gt_count ? BVCF_CLS_HOM : BVCF_CLS_HET;
+}
+
+// fast-path test and classification of one dword == one "x|y<TAB>" sample field.
+// returns cls (0..3) in bits 0-1 and sets bit 31 if the dword is not a regular field.
+__device__ __forceinline__ uint32_t fast_field(uint32_t w, uint32_t a_char) {
+  const uint32_t b0 = w & 0xFFu, b2 = (w >> 16) & 0xFFu;
+  const uint32_t frame = w & 0xFF00FF00u;
+  const bool ok_frame = frame == 0x09007C00u || frame == 0x09002F00u;  // '|' or '/', then TAB
+  const bool d0 = b0 == '.', d2 = b2 == '.';
+  const bool ok0 = (b0 - '0') <= 9u || d0;
+  const bool ok2 = (b2 - '0') <= 9u || d2;
+  const uint32_t altc = (uint32_t)(b0 == a_char) + (uint32_t)(b2 == a_char);
+  const uint32_t cls = (d0 || d2) ? 3u : altc;
+  return cls | ((ok_frame && ok0 && ok2) ? 0u : 0x80000000u);
+}
+
+// Regular sample region: exactly 4 bytes per sample.  Returns false (stats untouched) if any
+// field is irregular.  cmap may be nullptr.
+__device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint32_t ns, uint32_t allele, uint8_t *cmap,
+                                    GtStats *st) {
+  const int lane = lane_id();
+  // alleles >= 10 never match a one-character GT allele: compare against an impossible byte
+  const uint32_t a_char = allele <= 9 ? ('0' + allele) : 0x100u;
+  const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;
+  uint32_t bad = 0;
+  uint32_t acc = 0;  // packed byte counters: [none, het, hom, miss]
+  uint32_t het = 0, hom = 0, miss = 0;
+  u32x4 v = load16(a.buf, s_begin + 16u * lane, a.cap);
+  for (uint32_t c = 0; c < n_chunks; c++) {
+    u32x4 nxt = {0u, 0u, 0u, 0u};
+    if (c + 1 < n_chunks) nxt = load16(a.buf, s_begin + (c + 1) * kChunk + 16u * lane, a.cap);
+    const uint32_t f0 = c * 256u + 4u * lane;  // sample index of v.x
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if (c + 1 == n_chunks) {
+      // tail: slots past the last sample become "0|0\t"; the last sample's terminator byte
+      // (eol or '\r') stands in for its TAB
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (f0 + j >= ns) w[j] = 0x09307C30u;
+        if (f0 + j == ns - 1) w[j] = (w[j] & 0x00FFFFFFu) | 0x09000000u;
+      }
+    }
+    uint32_t byte = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t r = fast_field(w[j], a_char);
+      bad |= r;
+      uint32_t cls = r & 3u;
+      byte |= cls << (2 * j);
+      acc += 1u << (8 * cls);
+    }
+    if (cmap && f0 < ns) cmap[c * 64u + lane] = (uint8_t)byte;
+    if ((c & 31u) == 31u) {  // byte counters hold <= 128 before spilling
+      het += (acc >> 8) & 0xFFu;
+      hom += (acc >> 16) & 0xFFu;
+      miss += acc >> 24;
+      acc = 0;
+    }
+    v = nxt;
+  }
+  het += (acc >> 8) & 0xFFu;
+  hom += (acc >> 16) & 0xFFu;
+  miss += acc >> 24;
+  if (__any((int)(bad >> 31))) return false;
+  st->n_het = wave_sum(het);
+  st->n_hom = wave_sum(hom);
+  st->n_miss = wave_sum(miss);
+  st->ac = st->n_het + 2u * st->n_hom;
+  st->an = 2u * (ns - st->n_miss);
+  return true;
+}
+
+// Any sample region: delimiter masks per lane, wave prefix-sum for the sample index, byte-serial
+// field classification.  *n_tabs receives the number of TABs in [s_begin, cend).
+__device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, uint32_t cend, uint32_t ns,
+                                       uint32_t allele, uint8_t *cmap, GtStats *st, uint32_t *n_tabs) {
+  const int lane = lane_id();
+  uint32_t a_nd = 1;
+  for (uint32_t t = allele; t >= 10; t /= 10) a_nd++;
+  if (cmap) {  // zero this allele's map, then OR classes in
+    for (uint32_t i = lane * 4u; i < a.cmap_stride; i += kWave * 4u) *reinterpret_cast<uint32_t *>(cmap + i) = 0u;
+    __builtin_amdgcn_s_waitcnt(0);  // stores retired before the atomics below touch the same words
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+  uint32_t ac = 0, an = 0, het = 0, hom = 0, miss = 0;
+  uint32_t tabs_before = 0;       // TABs in earlier chunks
+  uint32_t prev_last_tab = 1;     // byte before the region start behaves like a TAB (field start)
+  for (uint32_t base = s_begin; base < cend; base += kChunk) {
+    const uint32_t off = base + 16u * lane;
+    u32x4 v = load16(a.buf, off, a.cap);
+    const uint32_t valid = low_bits16((int)cend - (int)off);
+    const uint32_t m = eq_mask16(v, '\t') & valid;
+    uint32_t tot;
+    const uint32_t pre = wave_excl_scan(__popc(m), &tot);
+    // field starts: the byte after each TAB, plus the region start
+    uint32_t carry = __shfl_up(m >> 15, 1, kWave) & 1u;
+    if (lane == 0) carry = prev_last_tab;
+    uint32_t starts = ((m << 1) | carry) & valid & 0xFFFFu;
+    while (starts) {
+      const uint32_t k = __ffs(starts) - 1;
+      starts &= starts - 1;
+      // sample index = TABs before this byte
+      const uint32_t s = tabs_before + pre + __popc(m & ((1u << k) - 1u));
+      if (s < ns) {
+        uint32_t cls, altc, gtc;
+        classify_field(a.buf, off + k, cend, allele, a_nd, &cls, &altc, &gtc);
+        ac += altc;
+        an += gtc;
+        het += cls == BVCF_CLS_HET;
+        hom += cls == BVCF_CLS_HOM;
+        miss += cls == BVCF_CLS_MISSING;
+        if (cmap && cls) atomicOr(reinterpret_cast<uint32_t *>(cmap + (s >> 4) * 4u), cls << (2u * (s & 15u)));
+      }
+    }
+    // a trailing empty field (line content ends with a TAB) starts at cend: it is sample `tabs` too
+    prev_last_tab = __shfl(m >> 15, kWave - 1, kWave) & 1u;
+    tabs_before += tot;
+  }
+  // a field that starts exactly at cend (empty last field) was not visited above
+  if (lane == 0) {
+    const bool empty_last = (cend == s_begin) || (cend > s_begin && a.buf[cend - 1] == '\t');
+    if (empty_last && tabs_before < ns) an += 1;  // "" is one non-matching allele token
+  }
+  st->ac = wave_sum(ac);
+  st->an = wave_sum(an);
+  st->n_het = wave_sum(het);
+  st->n_hom = wave_sum(hom);
+  st->n_miss = wave_sum(miss);
+  *n_tabs = tabs_before;
+}
+
+
+// ------------------------------------------------------------------ k_gt: one wave per task
+
+__global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
+  const int lane = lane_id();
+  const uint32_t n_tasks = min(a.counters->n_tasks, a.max_tasks);
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  const uint32_t ns = a.n_samples;
+  for (uint32_t ti = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); ti < n_tasks; ti += stride) {
+    const GtTask t = a.tasks[ti];
+    uint8_t *cm = t.cmap_off != BVCF_NO_CMAP ? a.cmap + t.cmap_off : nullptr;
+    GtStats st = {0, 0, 0, 0, 0};
+    uint32_t n_fields;
+    // regular region: 4 bytes per sample, every dword of a lane is one "x|y<TAB>" field
+    if (t.cend + 1u - t.s_begin == 4u * ns && gt_scan_fast(a, t.s_begin, ns, t.allele, cm, &st)) {
+      n_fields = ns;
+    } else {
+      uint32_t tabs;
+      gt_scan_general(a, t.s_begin, t.cend, ns, t.allele, cm, &st, &tabs);
+      n_fields = tabs + 1u;
+    }
+    if (lane == 0) {
+      GtResult r;
+      r.ac = st.ac;
+      r.an = st.an;
+      r.n_het = st.n_het;
+      r.n_hom = st.n_hom;
+      r.n_miss = st.n_miss;
+      r.n_fields = n_fields;
+      r.pad[0] = r.pad[1] = 0;
+      a.results[ti] = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_head: 16 lanes per line
+
+constexpr int kGroup = 16;                       // lanes per line in k_head
+constexpr int kGroupsPerWg = kWgThreads / kGroup;
+constexpr uint32_t kWindow = kGroup * 16;        // bytes per group step
+
+__device__ __forceinline__ int glane() { return threadIdx.x & (kGroup - 1); }
+
+// exclusive prefix sum inside a 16-lane group; *total = group sum
+__device__ __forceinline__ uint32_t group_excl_scan(uint32_t v, uint32_t *total) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < kGroup; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, kGroup);
+    if (glane() >= d) inc += t;
+  }
+  *total = __shfl(inc, kGroup - 1, kGroup);
+  return inc - v;
+}
+
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+  for (int d = kGroup / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, kGroup);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t gbcast0(uint32_t v) { return __shfl(v, 0, kGroup); }
+
+__device__ inline bool filter_in(const uint8_t *buf, Span f, const uint16_t *off, const uint16_t *len, uint32_t n,
+                                 const uint8_t *text) {
+#pragma nounroll
+  for (uint32_t i = 0; i < n; i++) {
+    if (len[i] != f.len) continue;
+    bool eq = true;
+#pragma nounroll
+    for (uint32_t k = 0; k < f.len && eq; k++) eq = buf[f.off + k] == text[off[i] + k];
+    if (eq) return true;
+  }
+  return false;
+}
+
+__device__ inline void write_allele(const KernelArgs &a, uint32_t idx, uint32_t line, uint32_t alt_idx,
+                                    const AlleleEval &e, long long pos, uint8_t ref, uint8_t alt_base,
+                                    uint8_t site_type, uint32_t task, uint32_t cmap_off) {
+  bvcf_allele r;
+  r.pos = pos;
+  r.line = line;
+  r.alt_idx = alt_idx;
+  r.alt_off = e.alt_off;
+  r.alt_len = e.mnp ? 1u : e.alt_len;
+  r.ac = 0;
+  r.an = 0;
+  r.n_het = 0;
+  r.n_hom = 0;
+  r.n_miss = 0;
+  r.cmap_off = cmap_off;
+  r.ref = ref;
+  r.alt_base = alt_base;
+  r.kind = e.mnp ? (uint8_t)BVCF_ALT_BASE : e.kind;
+  r.site_type = site_type;
+  r.trtv = (site_type == BVCF_SITE_MULTI || r.kind != BVCF_ALT_BASE) ? 0 : trtv_of(ref, alt_base);
+  r.flags = (!e.mnp && e.pos_text) ? BVCF_ALLELE_POS_TEXT : 0;
+  r.pad[0] = r.pad[1] = 0;
+  r.gt_task = task;
+  r.pad2 = 0;
+  a.alleles[idx] = r;
+}
+
+// append a genotype-scan task; returns its index (valid only if < max_tasks)
+__device__ inline uint32_t push_task(const KernelArgs &a, uint32_t line, uint32_t allele, uint32_t s_begin,
+                                     uint32_t cend, bool want_map, uint32_t *cmap_off) {
+  const uint32_t ti = atomicAdd(&a.counters->n_tasks, 1u);
+  uint32_t cm = BVCF_NO_CMAP;
+  if (want_map) {
+    const unsigned long long o = atomicAdd(&a.counters->cmap_bytes, (unsigned long long)a.cmap_stride);
+    if (o + a.cmap_stride <= a.max_cmap) cm = (uint32_t)o;
+  }
+  *cmap_off = cm;
+  if (ti < a.max_tasks) {
+    GtTask t;
+    t.line = line;
+    t.allele = allele;
+    t.s_begin = s_begin;
+    t.cend = cend;
+    t.cmap_off = cm;
+    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    a.tasks[ti] = t;
+  }
+  return ti;
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
+  __shared__ uint32_t s_tab[kGroupsPerWg][12];
+  const int gl = glane();
+  const int g = threadIdx.x / kGroup;
+  volatile uint32_t *tab = s_tab[g];
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t stride = gridDim.x * kGroupsPerWg;
+  const uint32_t need = min(9u, a.n_header - 1u);  // TABs that bound the fixed columns we read
+  const uint32_t ns = a.n_samples;
+  const bool maps = a.want_cmap && ns > 0;
+
+  for (uint32_t line = blockIdx.x * kGroupsPerWg + g; line < n_lines; line += stride) {
+    const uint32_t ls = a.line_off[line];
+    const uint32_t le = a.line_off[line + 1];
+    const uint32_t len = le - ls >= a.eol_chars ? le - ls - a.eol_chars : 0u;  // chomp, main.go:535
+    const uint32_t cend = ls + len;
+
+    // ---- tokenise the fixed columns: strings.Split(row, "\t"), main.go:535
+    uint32_t found = 0;
+    uint32_t base = ls;
+    for (; base < cend && found < need; base += kWindow) {
+      const uint32_t off = base + 16u * gl;
+      u32x4 v = load16(a.buf, off, a.cap);
+      uint32_t m = eq_mask16(v, '\t') & low_bits16((int)cend - (int)off);
+      uint32_t tot;
+      uint32_t r = found + group_excl_scan(__popc(m), &tot);
+      while (m && r < need) {
+        tab[r] = off + __ffs(m) - 1;
+        m &= m - 1;
+        r++;
+      }
+      found += tot;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    uint32_t status = BVCF_LINE_OK;
+    uint32_t n_fields = 0;
+    if (found < need) {
+      status = BVCF_LINE_FIELDS;
+      n_fields = found + 1;
+    } else if (ns == 0) {
+      // no samples: every TAB after the last fixed column is an extra field.  `found` already
+      // counts the TABs of the windows read so far; count the rest of the line.
+      uint32_t extra = 0;
+      for (; base < cend; base += kWindow) {
+        const uint32_t off = base + 16u * gl;
+        u32x4 v = load16(a.buf, off, a.cap);
+        extra += __popc(eq_mask16(v, '\t') & low_bits16((int)cend - (int)off));
+      }
+      n_fields = found + group_sum(extra) + 1;
+      if (n_fields != a.n_header) status = BVCF_LINE_FIELDS;
+    }
+
+    // field i = [fstart(i), tab[i]) ; fields beyond the line: empty at cend
+    auto fspan = [&](uint32_t i) -> Span {
+      Span s;
+      s.off = i == 0 ? ls : tab[i - 1] + 1;
+      const uint32_t e = i < need ? tab[i] : cend;
+      s.len = e - s.off;
+      return s;
+    };
+
+    uint32_t rec_first = 0, n_rec = 0, site_type = 0, first_task = 0;
+
+    // ---- everything below is the group leader's serial work
+    if (gl == 0 && status == BVCF_LINE_OK) {
+      // FILTER gate, main.go:447-454
+      if (a.n_header > 6) {
+        const FilterTable *ft = a.filters;
+        Span f = fspan(6);
+        if (!ft->allow_nil && !filter_in(a.buf, f, ft->allow_off, ft->allow_len, ft->allow_n, ft->text))
+          status = BVCF_LINE_FILTER;
+        else if (!ft->deny_nil && filter_in(a.buf, f, ft->deny_off, ft->deny_len, ft->deny_n, ft->text))
+          status = BVCF_LINE_FILTER;
+      }
+    }
+    if (gl == 0 && status == BVCF_LINE_OK) {
+      // getAlleles, main.go:723-1038
+      AlleleCtx c;
+      c.buf = a.buf;
+      c.chrom = fspan(0);
+      c.pos = fspan(1);
+      c.ref = fspan(3);
+      c.alt = fspan(4);
+      c.int_pos = 0;
+      c.pos_bad = false;
+      c.line = line;
+      const uint32_t s_begin = need == 9 ? tab[8] + 1 : cend;
+
+      // mode 0: REF == ALT; 1: single-byte ALT path; 2: ALT token loop; 3: empty REF (Go panics)
+      uint32_t n_commas = 0;
+      bool same = c.alt.len == c.ref.len;
+#pragma nounroll
+      for (uint32_t i = 0; i < c.alt.len; i++) {
+        const uint8_t ch = a.buf[c.alt.off + i];
+        n_commas += ch == ',';
+        if (same) same = ch == a.buf[c.ref.off + i];
+      }
+      const uint32_t mode = same ? 0u : (c.alt.len == 1 ? 1u : (c.ref.len == 0 ? 3u : 2u));
+      if (mode == 0) log_err(a, line, 0, BVCF_ERR_SAME);
+      if (mode == 3) log_err(a, line, 0, BVCF_ERR_EMPTY_REF);
+
+      // Output slots by upper bound: a token yields <= max(1, its length) records (equal-length
+      // blocks expand per differing base, main.go:855-873), so ALT's length bounds the line.
+      const uint32_t rec_cap = mode == 1 ? 1u : (mode == 2 ? c.alt.len : 0u);
+      uint32_t rec_base = 0;
+      if (rec_cap) rec_base = atomicAdd(&a.counters->n_alleles, rec_cap);
+      const bool fits = (unsigned long long)rec_base + rec_cap <= a.max_alleles;
+
+      // With samples, the scan for ALT #1 always runs: it also settles len(record) == len(header).
+      uint32_t task0 = 0, cm0 = BVCF_NO_CMAP;
+      if (ns > 0) {
+        task0 = push_task(a, line, 1, s_begin, cend, maps && (mode == 1 || mode == 2), &cm0);
+        first_task = task0;
+      }
+
+      uint32_t cur = 0, emitted = 0;
+      if (mode == 1 || mode == 2) {
+#pragma nounroll
+        for (uint32_t k = 0;; k++) {
+          AlleleEval e;
+          Span t;
+          if (mode == 1) {
+            if (k > 0) break;
+            eval_single(c, e);
+            t = c.alt;
+          } else {
+            if (!next_token(c, &cur, &t)) break;
+            eval_token(c, t, e);
+          }
+          if (e.err) log_err(a, line, (e.err == BVCF_ERR_POS) ? 0u : k + 1u, e.err);
+          if (e.stop) break;
+          if (!e.n) continue;
+          uint32_t task = task0, cm_off = cm0;
+          if (ns > 0 && k > 0) task = push_task(a, line, k + 1, s_begin, cend, maps, &cm_off);
+          if (fits) {
+            // type call, main.go:1004-1037 (single-ALT path: main.go:743,764)
+            uint8_t stype;
+            if (n_commas > 0)
+              stype = BVCF_SITE_MULTI;
+            else if (!e.mnp && e.kind == BVCF_ALT_DEL)
+              stype = BVCF_SITE_DEL;
+            else if (!e.mnp && e.kind == BVCF_ALT_INS)
+              stype = BVCF_SITE_INS;
+            else
+              stype = e.n > 1 ? BVCF_SITE_MNP : BVCF_SITE_SNP;
+            site_type = stype;
+            if (e.mnp) {
+              uint32_t j = 0;
+#pragma nounroll
+              for (uint32_t i = 0; i < c.ref.len; i++) {
+                const uint8_t rb = a.buf[c.ref.off + i], ab = a.buf[t.off + i];
+                if (rb == ab) continue;
+                write_allele(a, rec_base + emitted + j, line, k, e, c.int_pos + (long long)i, rb, ab, stype, task,
+                             cm_off);
+                j++;
+              }
+            } else {
+              write_allele(a, rec_base + emitted, line, k, e, e.pos, e.ref, e.alt_base, stype, task, cm_off);
+            }
+          }
+          emitted += e.n;
+        }
+      }
+      if (emitted == 0)
+        status = BVCF_LINE_NOALLELE;  // k_finish may still turn this into FIELDS
+      else if (fits) {
+        rec_first = rec_base;
+        n_rec = emitted;
+      }
+      n_fields = 0;  // settled by k_finish from the scan when there are samples
+      if (ns == 0) n_fields = a.n_header;
+    }
+
+    // ---- line record
+    if (gl == 0) {
+      bvcf_line L;
+      L.off = ls;
+      L.len = len;
+#pragma unroll
+      for (uint32_t i = 0; i < 9; i++) L.fend[i] = (i < need && i < found) ? tab[i] - ls : len;
+      L.rec_first = rec_first;
+      L.n_rec = n_rec;
+      L.n_fields = n_fields;
+      L.gt_task = first_task;
+      L.status = (uint8_t)status;
+      L.site_type = (uint8_t)site_type;
+      L.pad[0] = L.pad[1] = 0;
+      a.lines[line] = L;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------ k_finish
+
+// One thread per line and per allele record: the field-count half of linePasses (main.go:449) from
+// the scan of ALT #1, and the scan results copied into the records that reference them.
+__global__ __launch_bounds__(kWgThreads) void k_finish(KernelArgs a) {
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t n_alleles = min(a.counters->n_alleles, a.max_alleles);
+  const uint32_t n_tasks = min(a.counters->n_tasks, a.max_tasks);
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nthreads = gridDim.x * blockDim.x;
+  if (a.n_samples == 0) return;
+  for (uint32_t i = tid; i < n_lines; i += nthreads) {
+    bvcf_line *L = &a.lines[i];
+    const uint32_t st = L->status;
+    if (st != BVCF_LINE_OK && st != BVCF_LINE_NOALLELE) continue;
+    if (L->gt_task >= n_tasks) continue;
+    const uint32_t nf = 9u + a.results[L->gt_task].n_fields;
+    L->n_fields = nf;
+    if (nf != a.n_header) {
+      L->status = BVCF_LINE_FIELDS;
+      L->n_rec = 0;
+    }
+  }
+  for (uint32_t i = tid; i < n_alleles; i += nthreads) {
+    bvcf_allele *r = &a.alleles[i];
+    const uint32_t t = r->gt_task;
+    if (t >= n_tasks) continue;  // unused slot of an upper-bound reservation
+    const GtResult g = a.results[t];
+    r->ac = g.ac;
+    r->an = g.an;
+    r->n_het = g.n_het;
+    r->n_hom = g.n_hom;
+    r->n_miss = g.n_miss;
+  }
+}
+
+}  // namespace bvcf_dev

@@ -1,0 +1,589 @@
+// bvcf_host.cpp — host half of the path, above the C-ABI: the counterpart of readVcf's preamble and
+// producer loop (main.go:241-396) and of processLines' TSV assembly (main.go:566-695).
+//
+// Nothing here computes what the kernels compute: rows are assembled from bvcf_result only.
+#include "../../include/bvcf.h"
+
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// parse.Header (main.go:224), pinned by main_test.go:79-80
+const char *const kBaseHeader[15] = {"chrom",       "pos",           "type",         "ref",          "alt",
+                                     "trTv",        "heterozygotes", "heterozygosity", "homozygotes", "homozygosity",
+                                     "missingGenos", "missingness",  "ac",           "an",           "sampleMaf"};
+
+// parse.Snp / Ins / Del / Mnp / Multi
+const char *const kSiteNames[5] = {"SNP", "INS", "DEL", "MNP", "MULTIALLELIC"};
+
+const char *or_default(const char *s, const char *d) { return s ? s : d; }
+
+void append_ll(std::string &o, long long v) {
+  char tmp[32];
+  int n = snprintf(tmp, sizeof tmp, "%lld", v);
+  o.append(tmp, (size_t)n);
+}
+
+// strconv.FormatFloat(x, 'G', 3, 64) (main.go:627); "%.3G" is identical on [0, 1]
+void append_g3(std::string &o, double x) {
+  char tmp[64];
+  int n = snprintf(tmp, sizeof tmp, "%.3G", x);
+  o.append(tmp, (size_t)n);
+}
+
+struct Names {
+  const char *const *ptr;
+  const uint32_t *len;
+};
+
+// strings.Join(names of samples with class `want`, fieldDelimiter)
+void join_class(std::string &o, const uint8_t *cmap, uint32_t ns, unsigned want, const Names &nm, const char *delim,
+                size_t ndelim) {
+  bool first = true;
+  const uint32_t nbytes = (ns + 3) / 4;
+  for (uint32_t b = 0; b < nbytes; b++) {
+    const unsigned byte = cmap[b];
+    if (!byte) continue;
+    for (unsigned j = 0; j < 4; j++) {
+      if (((byte >> (2 * j)) & 3u) != want) continue;
+      const uint32_t s = b * 4 + j;
+      if (s >= ns) break;
+      if (!first) o.append(delim, ndelim);
+      o.append(nm.ptr[s], nm.len[s]);
+      first = false;
+    }
+  }
+}
+
+const char *err_text(uint32_t code) {
+  switch (code) {
+    case BVCF_ERR_SAME: return "REF == ALT";
+    case BVCF_ERR_BAD_ALT1:
+    case BVCF_ERR_BAD_ALT: return "ALT not ACTG";
+    case BVCF_ERR_DEL1_1:
+    case BVCF_ERR_DEL1: return "1st base REF != ALT";
+    case BVCF_ERR_POS1:
+    case BVCF_ERR_POS: return "Invalid POS";
+    case BVCF_ERR_INS1: return "1st base ALT != REF";
+    case BVCF_ERR_MIXED: return "Mixed indel/snp sites not supported";
+    case BVCF_ERR_EMPTY_REF: return "empty REF";
+  }
+  return "?";
+}
+
+// one log line in the reference's formats (main.go:730-986)
+void append_err(std::string &log, const bvcf_err &e, const bvcf_line &L, const uint8_t *block) {
+  const char *row = (const char *)block + L.off;
+  log.append(row, L.fend[0]);  // chrom
+  log.push_back(':');
+  log.append(row + L.fend[0] + 1, L.fend[1] - L.fend[0] - 1);  // pos
+  char tmp[64];
+  switch (e.code) {
+    case BVCF_ERR_SAME: log.append(" : "); break;
+    case BVCF_ERR_BAD_ALT1:
+    case BVCF_ERR_DEL1_1:
+    case BVCF_ERR_POS1: log.append(" ALT #1 "); break;
+    case BVCF_ERR_BAD_ALT:
+    case BVCF_ERR_INS1: log.append(tmp, (size_t)snprintf(tmp, sizeof tmp, " ALT #%u ", e.alt_no)); break;
+    case BVCF_ERR_DEL1:
+    case BVCF_ERR_MIXED: log.append(tmp, (size_t)snprintf(tmp, sizeof tmp, " ALT#%u ", e.alt_no)); break;
+    default: log.push_back(' '); break;
+  }
+  log.append(err_text(e.code));
+  log.push_back('\n');
+}
+
+// rows of lines [lo, hi), main.go:566-695
+void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm, uint32_t lo,
+                  uint32_t hi, std::string &out) {
+  const char *empty = or_default(c->empty_field, "!");
+  const char *delim = or_default(c->field_delimiter, ";");
+  const size_t ndelim = strlen(delim);
+  const uint32_t ns = r->n_samples;
+  const double num_samples = (double)ns;
+  for (uint32_t li = lo; li < hi; li++) {
+    const bvcf_line &L = r->lines[li];
+    if (L.status != BVCF_LINE_OK) continue;
+    const char *row = (const char *)block + L.off;
+    auto fstart = [&](int i) -> uint32_t { return i ? L.fend[i - 1] + 1 : 0; };
+    for (uint32_t k = 0; k < L.n_rec; k++) {
+      const bvcf_allele &A = r->alleles[L.rec_first + k];
+      // main.go:555-560: with samples, an allele nobody carries is skipped
+      if (ns > 0 && A.ac == 0) continue;
+      // main.go:570-574
+      const uint32_t nchrom = L.fend[0];
+      if (nchrom < 4 || row[0] != 'c') out.append("chr");
+      out.append(row, nchrom);
+      out.push_back('\t');
+      if (A.flags & BVCF_ALLELE_POS_TEXT)
+        out.append(row + fstart(1), L.fend[1] - fstart(1));
+      else
+        append_ll(out, A.pos);
+      out.push_back('\t');
+      out.append(kSiteNames[A.site_type < 5 ? A.site_type : 0]);
+      out.push_back('\t');
+      out.push_back((char)A.ref);
+      out.push_back('\t');
+      if (A.kind == BVCF_ALT_BASE) {
+        out.push_back((char)A.alt_base);
+      } else if (A.kind == BVCF_ALT_INS) {
+        out.push_back('+');
+        out.append((const char *)block + A.alt_off, A.alt_len);
+      } else {
+        out.push_back('-');
+        append_ll(out, A.alt_len);
+      }
+      out.push_back('\t');
+      out.push_back((char)('0' + A.trtv));  // main.go:602-606
+      out.push_back('\t');
+
+      const double effective = num_samples - (double)A.n_miss;  // main.go:563
+      const uint8_t *cm = (A.cmap_off != BVCF_NO_CMAP && r->cmap) ? r->cmap + A.cmap_off : nullptr;
+      struct {
+        uint32_t n;
+        unsigned cls;
+        double denom;
+      } lists[3] = {{A.n_het, BVCF_CLS_HET, effective}, {A.n_hom, BVCF_CLS_HOM, effective},
+                    {A.n_miss, BVCF_CLS_MISSING, num_samples}};
+      for (int q = 0; q < 3; q++) {  // main.go:612-656
+        if (lists[q].n == 0 || !cm) {
+          out.append(empty);
+          out.append("\t0");
+        } else {
+          join_class(out, cm, ns, lists[q].cls, nm, delim, ndelim);
+          out.push_back('\t');
+          append_g3(out, (double)lists[q].n / lists[q].denom);
+        }
+        out.push_back('\t');
+      }
+      append_ll(out, A.ac);  // main.go:661-671
+      out.push_back('\t');
+      append_ll(out, A.an);
+      out.push_back('\t');
+      if (A.ac == 0)
+        out.push_back('0');
+      else
+        append_g3(out, (double)A.ac / (double)A.an);
+      if (c->keep_pos) {  // main.go:674-692
+        out.push_back('\t');
+        out.append(row + fstart(1), L.fend[1] - fstart(1));
+      }
+      if (c->keep_id) {
+        out.push_back('\t');
+        out.append(row + fstart(2), L.fend[2] - fstart(2));
+      }
+      if (c->keep_info) {
+        out.push_back('\t');
+        append_ll(out, A.alt_idx);
+        out.push_back('\t');
+        out.append(row + fstart(7), L.fend[7] - fstart(7));
+      }
+      out.push_back('\n');
+    }
+  }
+}
+
+void format_batch(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm,
+                  unsigned n_threads, std::string &out, std::string &log) {
+  // log lines in input order (stable: one line's messages keep their ALT order)
+  if (r->n_errs) {
+    std::vector<uint32_t> idx(r->n_errs);
+    for (uint32_t i = 0; i < r->n_errs; i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return r->errs[x].line < r->errs[y].line; });
+    for (uint32_t i : idx) append_err(log, r->errs[i], r->lines[r->errs[i].line], block);
+  }
+  if (n_threads <= 1 || r->n_lines < 4 * n_threads) {
+    format_lines(c, r, block, nm, 0, r->n_lines, out);
+    return;
+  }
+  std::vector<std::string> parts(n_threads);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < n_threads; t++) {
+    const uint32_t lo = (uint32_t)((uint64_t)r->n_lines * t / n_threads);
+    const uint32_t hi = (uint32_t)((uint64_t)r->n_lines * (t + 1) / n_threads);
+    th.emplace_back([=, &parts, &nm]() { format_lines(c, r, block, nm, lo, hi, parts[t]); });
+  }
+  for (auto &x : th) x.join();
+  for (auto &p : parts) out.append(p);
+}
+
+char *dup_out(const std::string &s, size_t *n) {
+  char *p = (char *)malloc(s.size() + 1);
+  if (!p) return nullptr;
+  memcpy(p, s.data(), s.size());
+  p[s.size()] = 0;
+  *n = s.size();
+  return p;
+}
+
+// ---- readVcf's preamble, main.go:250-304
+
+struct Preamble {
+  uint8_t eol_byte = '\n';
+  uint32_t eol_chars = 1;
+  std::vector<std::string> header;  // normalised
+  size_t data_off = 0;              // first byte after the #CHROM line
+};
+
+// returns 0, 1 = need more input, <0 = fatal (message in *msg)
+int parse_preamble(const uint8_t *in, size_t n, bool at_eof, bool normalize, Preamble *pre, std::string *msg) {
+  // parse.FindEndOfLine(reader, ""): consume line 1, learn the terminator ("\r\n"/"\r": unpinned)
+  size_t i = 0;
+  for (;; i++) {
+    if (i >= n) {
+      if (!at_eof) return 1;
+      *msg = "EOF";
+      return -1;
+    }
+    if (in[i] == '\n') break;
+    if (in[i] == '\r') {
+      if (i + 1 >= n) {
+        if (!at_eof) return 1;
+        *msg = "EOF";
+        return -1;
+      }
+      if (in[i + 1] == '\n') {
+        pre->eol_chars = 2;
+      } else {
+        pre->eol_byte = '\r';
+      }
+      break;
+    }
+  }
+  // main.go:256-264
+  if (!memmem(in, i, "##fileformat=VCFv4", 18)) {
+    *msg = "Not a VCF file";
+    return -1;
+  }
+  size_t pos = i + pre->eol_chars;
+  // main.go:266-294
+  while (pos < n) {
+    const uint8_t *e = (const uint8_t *)memchr(in + pos, pre->eol_byte, n - pos);
+    if (!e) break;
+    const size_t row_len = (size_t)(e - (in + pos)) + 1;
+    const uint8_t *row = in + pos;
+    pos += row_len;
+    if (row_len < pre->eol_chars) continue;
+    const size_t body = row_len - pre->eol_chars;
+    const uint8_t *tab = (const uint8_t *)memchr(row, '\t', body);
+    const size_t f0 = tab ? (size_t)(tab - row) : body;
+    if (f0 == 6 && memcmp(row, "#CHROM", 6) == 0) {
+      size_t s = 0;
+      for (size_t k = 0; k <= body; k++) {
+        if (k != body && row[k] != '\t') continue;
+        std::string f((const char *)row + s, k - s);
+        // parse.NormalizeHeader, main.go:296 (restated: '.' -> '_'; parity unpinned)
+        if (normalize) std::replace(f.begin(), f.end(), '.', '_');
+        pre->header.push_back(std::move(f));
+        s = k + 1;
+      }
+      pre->data_off = pos;
+      return 0;
+    }
+  }
+  if (!at_eof) return 1;
+  *msg = "No header found";
+  return -1;
+}
+
+struct Run {
+  const bvcf_config *cfg;
+  bvcf_ctx *ctx = nullptr;
+  Preamble pre;
+  std::vector<const char *> name_ptr;
+  std::vector<uint32_t> name_len;
+  unsigned n_threads = 1;
+  uint64_t max_batch = 0;
+};
+
+int open_ctx(Run &R, std::string *msg) {
+  if (R.pre.header.size() < 8) {
+    // the reference indexes record[6] / record[7] unguarded: out of contract
+    *msg = "Malformed header: fewer than 8 fields";
+    return BVCF_E_FATAL;
+  }
+  bvcf_params p;
+  memset(&p, 0, sizeof p);
+  p.abi_version = BVCF_ABI_VERSION;
+  p.device = R.cfg->device;
+  p.n_header_fields = (uint32_t)R.pre.header.size();
+  p.eol_chars = R.pre.eol_chars;
+  p.eol_byte = R.pre.eol_byte;
+  p.want_class_maps = 1;
+  p.allow_filter = R.cfg->allow_filter;
+  p.exclude_filter = R.cfg->exclude_filter;
+  p.max_batch_bytes = R.max_batch;
+  p.n_slots = 2;
+  int rc = bvcf_create(&R.ctx, &p);
+  if (rc) {
+    *msg = std::string("bvcf_create: ") + bvcf_last_error(nullptr);
+    return rc;
+  }
+  for (size_t i = 9; i < R.pre.header.size(); i++) {
+    R.name_ptr.push_back(R.pre.header[i].data());
+    R.name_len.push_back((uint32_t)R.pre.header[i].size());
+  }
+  R.n_threads = R.cfg->n_format_threads ? R.cfg->n_format_threads : std::max(1u, std::thread::hardware_concurrency());
+  return BVCF_OK;
+}
+
+// submit one block and collect it, growing the result reservation when the batch asks for it
+int process_block(Run &R, const uint8_t *block, size_t n, uint64_t seq, bvcf_result *res, std::string *msg) {
+  for (int attempt = 0; attempt < 4; attempt++) {
+    int rc = bvcf_submit(R.ctx, block, n, seq);
+    if (rc) {
+      *msg = std::string("bvcf_submit: ") + bvcf_last_error(R.ctx);
+      return rc;
+    }
+    rc = bvcf_collect(R.ctx, res);
+    if (rc == BVCF_OK) return rc;
+    if (rc != BVCF_E_CAPACITY) {
+      *msg = std::string("bvcf_collect: ") + bvcf_last_error(R.ctx);
+      return rc;
+    }
+    rc = bvcf_reserve(R.ctx, res->need_lines + res->need_lines / 4 + 64, res->need_alleles + res->need_alleles / 4 + 64,
+                      res->need_cmap_bytes + res->need_cmap_bytes / 4 + 4096);
+    if (rc) {
+      *msg = std::string("bvcf_reserve: ") + bvcf_last_error(R.ctx);
+      return rc;
+    }
+  }
+  *msg = "result reservation did not converge";
+  return BVCF_E_CAPACITY;
+}
+
+}  // namespace
+
+extern "C" {
+
+void bvcf_config_defaults(bvcf_config *c) {
+  memset(c, 0, sizeof *c);
+  c->empty_field = "!";
+  c->field_delimiter = ";";
+  c->allow_filter = "PASS,.";
+  c->exclude_filter = "";
+  c->normalize_header = 1;
+}
+
+size_t bvcf_string_header(const bvcf_config *c, char *out, size_t cap) {
+  std::string h;
+  for (int i = 0; i < 15; i++) {
+    if (i) h.push_back('\t');
+    h.append(kBaseHeader[i]);
+  }
+  if (c->keep_pos) h.append("\tvcfPos");
+  if (c->keep_id) h.append("\tid");
+  if (c->keep_info) h.append("\talleleIdx\tinfo");
+  if (out && cap > h.size()) memcpy(out, h.c_str(), h.size() + 1);
+  return h.size();
+}
+
+void bvcf_free(void *p) { free(p); }
+
+int bvcf_format_tsv(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const char *const *sample_names,
+                    const uint32_t *sample_name_lens, char **out, size_t *n_out, char **log, size_t *n_log) {
+  if (!c || !r || !out || !n_out) return BVCF_E_ARG;
+  if (r->n_samples && (!sample_names || !sample_name_lens)) return BVCF_E_ARG;
+  std::string o, l;
+  Names nm{sample_names, sample_name_lens};
+  const unsigned nt = c->n_format_threads ? c->n_format_threads : std::max(1u, std::thread::hardware_concurrency());
+  format_batch(c, r, block, nm, nt, o, l);
+  *out = dup_out(o, n_out);
+  if (log && n_log) *log = dup_out(l, n_log);
+  return *out ? BVCF_OK : BVCF_E_NOMEM;
+}
+
+int bvcf_run_buffer(const bvcf_config *c, const uint8_t *vcf, size_t n, char **out, size_t *n_out, char **log,
+                    size_t *n_log, uint64_t *n_lines_in) {
+  if (!c || (!vcf && n) || !out || !n_out || !log || !n_log) return BVCF_E_ARG;
+  std::string o, l, msg;
+  Run R;
+  R.cfg = c;
+  R.max_batch = c->max_batch_bytes ? c->max_batch_bytes : (64ull << 20);
+  uint64_t lines_in = 0;
+  int rc = parse_preamble(vcf, n, true, c->normalize_header, &R.pre, &msg);
+  if (rc < 0) {
+    l = msg + "\n";
+    rc = BVCF_E_FATAL;
+  } else {
+    rc = open_ctx(R, &msg);
+    if (rc) l = msg + "\n";
+  }
+  if (rc == BVCF_OK) {
+    if (R.pre.header.size() == 9)  // main.go:507-509
+      l.append("Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n");
+    Names nm{R.name_ptr.data(), R.name_len.data()};
+    size_t pos = R.pre.data_off;
+    uint64_t seq = 0;
+    while (pos < n) {
+      // whole lines only; an unterminated tail is dropped (main.go:354-358)
+      size_t end = std::min<size_t>(n, pos + R.max_batch);
+      const uint8_t *last = (const uint8_t *)memrchr(vcf + pos, R.pre.eol_byte, end - pos);
+      if (!last) {
+        if (end == n) break;
+        msg = "a line is longer than max_batch_bytes";
+        l.append(msg + "\n");
+        rc = BVCF_E_TOO_BIG;
+        break;
+      }
+      const size_t nb = (size_t)(last - (vcf + pos)) + 1;
+      bvcf_result res;
+      rc = process_block(R, vcf + pos, nb, seq++, &res, &msg);
+      if (rc) {
+        l.append(msg + "\n");
+        break;
+      }
+      lines_in += res.n_lines;
+      format_batch(c, &res, vcf + pos, nm, R.n_threads, o, l);
+      pos += nb;
+    }
+  }
+  if (R.ctx) bvcf_destroy(R.ctx);
+  if (n_lines_in) *n_lines_in = lines_in;
+  *out = dup_out(o, n_out);
+  *log = dup_out(l, n_log);
+  return rc;
+}
+
+static int write_all(int fd, const char *p, size_t n) {
+  while (n) {
+    ssize_t w = write(fd, p, n);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return -1;
+    }
+    p += w;
+    n -= (size_t)w;
+  }
+  return 0;
+}
+
+int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_t *n_lines_in) {
+  if (!c) return BVCF_E_ARG;
+  std::string msg;
+  Run R;
+  R.cfg = c;
+  R.max_batch = c->max_batch_bytes ? c->max_batch_bytes : (64ull << 20);
+  uint64_t lines_in = 0;
+  auto fatal = [&](const std::string &m, int rc) {
+    std::string t = m + "\n";
+    write_all(fd_err, t.data(), t.size());
+    if (R.ctx) bvcf_destroy(R.ctx);
+    return rc;
+  };
+
+  // fmt.Fprintln(writer, stringHeader(config)), main.go:199
+  {
+    char h[512];
+    size_t hn = bvcf_string_header(c, h, sizeof h);
+    h[hn] = '\n';
+    if (write_all(fd_out, h, hn + 1)) return fatal("write failed", BVCF_E_FATAL);
+  }
+
+  // two pinned read buffers: the GPU works on one while the other fills (main.go:192, 349-380)
+  const size_t cap = R.max_batch;
+  uint8_t *bufs[2] = {(uint8_t *)bvcf_alloc_pinned(cap), (uint8_t *)bvcf_alloc_pinned(cap)};
+  if (!bufs[0] || !bufs[1]) {
+    // no device => no pinned memory either; fail loudly, there is no CPU path
+    bvcf_free_pinned(bufs[0]);
+    bvcf_free_pinned(bufs[1]);
+    return fatal("cannot allocate pinned host memory (no usable HIP device?)", BVCF_E_NODEV);
+  }
+  int cur = 0;
+  size_t fill = 0;
+  bool eof = false, have_pre = false;
+  std::string out, log;
+  int rc = BVCF_OK;
+  uint64_t seq = 0;
+  auto cleanup = [&]() {
+    bvcf_free_pinned(bufs[0]);
+    bvcf_free_pinned(bufs[1]);
+  };
+
+  while (!(eof && fill == 0)) {
+    while (!eof && fill < cap) {
+      ssize_t got = read(fd_in, bufs[cur] + fill, cap - fill);
+      if (got < 0) {
+        if (errno == EINTR) continue;
+        cleanup();
+        return fatal(std::string("read: ") + strerror(errno), BVCF_E_FATAL);
+      }
+      if (got == 0) {
+        eof = true;
+        break;
+      }
+      fill += (size_t)got;
+    }
+    size_t start = 0;
+    if (!have_pre) {
+      int pr = parse_preamble(bufs[cur], fill, eof || fill == cap, c->normalize_header, &R.pre, &msg);
+      if (pr != 0) {
+        cleanup();
+        return fatal(pr > 0 ? "VCF preamble larger than max_batch_bytes" : msg, BVCF_E_FATAL);
+      }
+      have_pre = true;
+      rc = open_ctx(R, &msg);
+      if (rc) {
+        cleanup();
+        return fatal(msg, rc);
+      }
+      if (R.pre.header.size() == 9)
+        log.append("Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n");
+      start = R.pre.data_off;
+    }
+    const uint8_t *last = fill > start ? (const uint8_t *)memrchr(bufs[cur] + start, R.pre.eol_byte, fill - start) : nullptr;
+    if (!last) {
+      if (eof) break;  // unterminated tail: dropped (main.go:354-358)
+      if (fill == cap) {
+        cleanup();
+        return fatal("a line is longer than max_batch_bytes", BVCF_E_TOO_BIG);
+      }
+      continue;
+    }
+    const size_t nb = (size_t)(last - (bufs[cur] + start)) + 1;
+    bvcf_result res;
+    rc = process_block(R, bufs[cur] + start, nb, seq++, &res, &msg);
+    if (rc) {
+      cleanup();
+      return fatal(msg, rc);
+    }
+    lines_in += res.n_lines;
+    out.clear();
+    Names nm{R.name_ptr.data(), R.name_len.data()};
+    format_batch(c, &res, bufs[cur] + start, nm, R.n_threads, out, log);
+    if (write_all(fd_out, out.data(), out.size())) {
+      cleanup();
+      return fatal("write failed", BVCF_E_FATAL);
+    }
+    if (!log.empty()) {
+      write_all(fd_err, log.data(), log.size());
+      log.clear();
+    }
+    // carry the partial line into the other buffer
+    const size_t tail = fill - (start + nb);
+    memcpy(bufs[cur ^ 1], bufs[cur] + start + nb, tail);
+    cur ^= 1;
+    fill = tail;
+    if (eof && tail && !memchr(bufs[cur], R.pre.eol_byte, tail)) break;
+  }
+  if (!have_pre) {
+    cleanup();
+    return fatal("EOF", BVCF_E_FATAL);
+  }
+  if (!log.empty()) write_all(fd_err, log.data(), log.size());
+  cleanup();
+  if (R.ctx) bvcf_destroy(R.ctx);
+  if (n_lines_in) *n_lines_in = lines_in;
+  return BVCF_OK;
+}
+
+}  // extern "C"

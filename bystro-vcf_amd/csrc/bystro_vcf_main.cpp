@@ -1,0 +1,171 @@
+// bystro-vcf — stdin VCF -> stdout TSV, the reference's process surface (main.go:82-217) over libbvcf.
+//
+// Flag names, defaults and the order of optional output columns are the reference's
+// (setup(), main.go:84-99).  Go's `flag` accepts -x and --x, "--x=v" and "--x v"; bools take
+// presence or =true/false; parsing stops at the first non-flag argument.
+#include <errno.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <string>
+
+#include "../../include/bvcf.h"
+
+namespace {
+
+struct Cli {
+  std::string in, out, err, dosage, sample, fam, empty = "!", delim = ";", cpu_profile;
+  std::string allow = "PASS,.", exclude;
+  bool no_out = false, keep_id = false, keep_qual = false, keep_pos = false, keep_info = false;
+  int device = 0;
+  unsigned long long batch_mb = 0;
+};
+
+bool parse_bool(const char *v, bool *out) {
+  // strconv.ParseBool
+  static const char *t[] = {"1", "t", "T", "TRUE", "true", "True"};
+  static const char *f[] = {"0", "f", "F", "FALSE", "false", "False"};
+  for (auto s : t)
+    if (!strcmp(v, s)) return *out = true, true;
+  for (auto s : f)
+    if (!strcmp(v, s)) return *out = false, true;
+  return false;
+}
+
+int parse(int argc, char **argv, Cli &c) {
+  struct B {
+    const char *name;
+    bool *v;
+  } bools[] = {{"noOut", &c.no_out}, {"keepId", &c.keep_id}, {"keepQual", &c.keep_qual},
+               {"keepPos", &c.keep_pos}, {"keepInfo", &c.keep_info}};
+  struct S {
+    const char *name;
+    std::string *v;
+  } strs[] = {{"in", &c.in}, {"fam", &c.fam}, {"err", &c.err}, {"out", &c.out}, {"dosageOutput", &c.dosage},
+              {"sample", &c.sample}, {"emptyField", &c.empty}, {"fieldDelimiter", &c.delim},
+              {"cpuProfile", &c.cpu_profile}, {"allowFilter", &c.allow}, {"excludeFilter", &c.exclude}};
+  for (int i = 1; i < argc; i++) {
+    const char *a = argv[i];
+    if (a[0] != '-' || !a[1]) break;  // first non-flag ends parsing
+    a++;
+    if (*a == '-') a++;
+    if (!*a) break;  // "--" terminator
+    std::string name(a);
+    std::string val;
+    bool has_val = false;
+    size_t eq = name.find('=');
+    if (eq != std::string::npos) {
+      val = name.substr(eq + 1);
+      name = name.substr(0, eq);
+      has_val = true;
+    }
+    bool done = false;
+    for (auto &b : bools)
+      if (name == b.name) {
+        if (!has_val)
+          *b.v = true;
+        else if (!parse_bool(val.c_str(), b.v)) {
+          fprintf(stderr, "invalid boolean value \"%s\" for -%s: parse error\n", val.c_str(), name.c_str());
+          return 2;
+        }
+        done = true;
+      }
+    if (done) continue;
+    for (auto &s : strs)
+      if (name == s.name) {
+        if (!has_val) {
+          if (i + 1 >= argc) {
+            fprintf(stderr, "flag needs an argument: -%s\n", name.c_str());
+            return 2;
+          }
+          val = argv[++i];
+        }
+        *s.v = val;
+        done = true;
+      }
+    if (done) continue;
+    // extensions of this build (not in the reference)
+    if (name == "device" || name == "batchMB") {
+      if (!has_val) {
+        if (i + 1 >= argc) {
+          fprintf(stderr, "flag needs an argument: -%s\n", name.c_str());
+          return 2;
+        }
+        val = argv[++i];
+      }
+      if (name == "device")
+        c.device = atoi(val.c_str());
+      else
+        c.batch_mb = strtoull(val.c_str(), nullptr, 10);
+      continue;
+    }
+    fprintf(stderr, "flag provided but not defined: -%s\n", name.c_str());
+    return 2;
+  }
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  Cli c;
+  int rc = parse(argc, argv, c);
+  if (rc) return rc;
+
+  int fd_in = 0, fd_out = 1, fd_err = 2;
+  if (!c.in.empty()) {  // main.go:138-147
+    fd_in = open(c.in.c_str(), O_RDONLY);
+    if (fd_in < 0) {
+      fprintf(stderr, "open %s: %s\n", c.in.c_str(), strerror(errno));
+      return 1;
+    }
+  }
+  if (!c.err.empty()) {  // main.go:150-156 (the reference opens this read-only; we open it for append)
+    fd_err = open(c.err.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (fd_err < 0) {
+      fprintf(stderr, "open %s: %s\n", c.err.c_str(), strerror(errno));
+      return 1;
+    }
+  }
+  if (c.no_out && !c.out.empty()) {  // main.go:160-162
+    dprintf(fd_err, "Cannot specify --noOut and --out\n");
+    return 1;
+  }
+  if (c.no_out && c.dosage.empty()) {  // main.go:164-166
+    dprintf(fd_err, "When specifying --noOut, must specify --dosageOutput\n");
+    return 1;
+  }
+  if (!c.dosage.empty() || c.no_out) {
+    dprintf(fd_err, "--dosageOutput / --noOut (Arrow dosage matrix) are outside this build's scope\n");
+    return 1;
+  }
+  if (!c.out.empty()) {  // main.go:172
+    fd_out = open(c.out.c_str(), O_WRONLY | O_CREAT, 0644);
+    if (fd_out < 0) {
+      dprintf(fd_err, "open %s: %s\n", c.out.c_str(), strerror(errno));
+      return 1;
+    }
+  }
+
+  bvcf_config cfg;
+  bvcf_config_defaults(&cfg);
+  cfg.empty_field = c.empty.c_str();
+  cfg.field_delimiter = c.delim.c_str();
+  cfg.allow_filter = c.allow.c_str();
+  cfg.exclude_filter = c.exclude.c_str();
+  cfg.keep_id = c.keep_id;
+  cfg.keep_info = c.keep_info;
+  cfg.keep_pos = c.keep_pos;
+  cfg.keep_qual = c.keep_qual;
+  cfg.device = c.device;
+  if (c.batch_mb) cfg.max_batch_bytes = c.batch_mb << 20;
+  const char *raw = getenv("BVCF_RAW_SAMPLE_NAMES");
+  if (raw && *raw == '1') cfg.normalize_header = 0;
+
+  uint64_t n_lines = 0;
+  rc = bvcf_run_fd(&cfg, fd_in, fd_out, fd_err, &n_lines);
+  return rc == BVCF_OK ? 0 : 1;  // log.Fatal exits 1
+}

@@ -1,0 +1,249 @@
+/*
+ * bvcf.h — C-ABI of libbvcf.so: the MI355X-native replacement for bystro-vcf's
+ * per-line variant pipeline (reference /root/reference/main.go @ 2024_10_08).
+ *
+ * The reference has no FFI boundary; the path is the goroutine body
+ *     processLines(header, numChars, config, queue, writer, complete, arrowWriter)   main.go:476-477
+ * and the pure functions it calls:
+ *     linePasses(record, header, allowed, excluded)            main.go:447-454
+ *     altIsValid(alt)                                          main.go:456-474
+ *     getAlleles(chrom, pos, ref, alt)                         main.go:723-1038
+ *     makeHetHomozygotes(fields, header, alleleNum, ...)       main.go:1042-1194
+ *     parse.GetTrTv(ref, alt)                                  main.go:602-606
+ * fed by readVcf's 64-line batches (main.go:349-380).  A cgo caller replaces
+ * `workQueue <- buff` with bvcf_submit() and the body of processLines with
+ * bvcf_collect() + its own TSV assembly (or bvcf_format_tsv()); see INTEGRATION.md.
+ *
+ * Everything is plain C: pointers, sizes, fixed-width integers.  No callbacks,
+ * no exceptions, nothing aborts: every function returns 0 or a negative
+ * bvcf_status.  A ctx is single-caller; distinct ctxs (one per GPU) are
+ * independent.  There is NO CPU fallback: without a HIP device bvcf_create fails.
+ */
+#ifndef BVCF_H
+#define BVCF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVCF_ABI_VERSION 1
+
+typedef enum {
+  BVCF_OK = 0,
+  BVCF_E_ARG = -1,        /* bad argument */
+  BVCF_E_HIP = -2,        /* HIP runtime error (bvcf_last_error has the text) */
+  BVCF_E_NODEV = -3,      /* no usable HIP device */
+  BVCF_E_BUSY = -4,       /* all slots in flight: collect first */
+  BVCF_E_EMPTY = -5,      /* nothing to collect */
+  BVCF_E_TOO_BIG = -6,    /* block larger than max_batch_bytes */
+  BVCF_E_CAPACITY = -7,   /* batch needs more lines/alleles/class-map bytes than reserved;
+                             bvcf_result.need_* say how many; grow with bvcf_reserve or split */
+  BVCF_E_NOMEM = -8,
+  BVCF_E_FATAL = -9       /* the reference's log.Fatal paths (bvcf_run_*) */
+} bvcf_status;
+
+/* line verdicts, cf. main.go:537-545 */
+enum {
+  BVCF_LINE_OK = 0,        /* passed the gate and produced >= 1 allele */
+  BVCF_LINE_FIELDS = 1,    /* len(record) != len(header)            (linePasses) */
+  BVCF_LINE_FILTER = 2,    /* FILTER not allowed / excluded         (linePasses) */
+  BVCF_LINE_NOALLELE = 3   /* getAlleles returned no alleles (reasons in the error list) */
+};
+
+/* parse.Snp / Ins / Del / Mnp / Multi, main.go:743,764,1013-1037 */
+enum { BVCF_SITE_SNP = 0, BVCF_SITE_INS = 1, BVCF_SITE_DEL = 2, BVCF_SITE_MNP = 3, BVCF_SITE_MULTI = 4 };
+
+/* how bvcf_allele describes the output `alt` text */
+enum {
+  BVCF_ALT_BASE = 0,  /* one base: alt_base */
+  BVCF_ALT_INS = 1,   /* "+" followed by block[alt_off .. alt_off+alt_len) */
+  BVCF_ALT_DEL = 2    /* "-" followed by decimal alt_len */
+};
+
+/* 2-bit per-sample classes of the class map (sample s: byte s/4, bits 2*(s%4)) */
+enum { BVCF_CLS_NONE = 0, BVCF_CLS_HET = 1, BVCF_CLS_HOM = 2, BVCF_CLS_MISSING = 3 };
+
+/* reasons getAlleles logs, main.go:42-50 with the formats of main.go:730-986 */
+enum {
+  BVCF_ERR_SAME = 1,        /* "%s:%s : REF == ALT"                              main.go:730 */
+  BVCF_ERR_BAD_ALT1 = 2,    /* "%s:%s ALT #1 ALT not ACTG"   (single-ALT path)   main.go:737 */
+  BVCF_ERR_DEL1_1 = 3,      /* "%s:%s ALT #1 1st base REF != ALT"                main.go:748 */
+  BVCF_ERR_POS1 = 4,        /* "%s:%s ALT #1 Invalid POS"                        main.go:755 */
+  BVCF_ERR_BAD_ALT = 5,     /* "%s:%s ALT #%d ALT not ACTG"                      main.go:782 */
+  BVCF_ERR_INS1 = 6,        /* "%s:%s ALT #%d 1st base ALT != REF"               main.go:798 */
+  BVCF_ERR_POS = 7,         /* "%s:%s Invalid POS"                               main.go:827 */
+  BVCF_ERR_DEL1 = 8,        /* "%s:%s ALT#%d 1st base REF != ALT"                main.go:835 */
+  BVCF_ERR_MIXED = 9,       /* "%s:%s ALT#%d Mixed indel/snp sites not supported" main.go:934,986 */
+  BVCF_ERR_EMPTY_REF = 10   /* empty REF (a Go panic in the reference; rejected here) */
+};
+
+#define BVCF_ALLELE_POS_TEXT 1u /* bvcf_allele.flags: output pos is the POS field verbatim */
+#define BVCF_NO_CMAP 0xFFFFFFFFu
+#define BVCF_DEVICE_PAD 64      /* bytes a device-resident block must own past nbytes */
+
+typedef struct bvcf_ctx bvcf_ctx;
+
+/* ctx configuration: what processLines closes over (main.go:494-509) */
+typedef struct {
+  uint32_t abi_version;       /* BVCF_ABI_VERSION */
+  int32_t device;             /* HIP device ordinal */
+  uint32_t n_header_fields;   /* len(header) incl. the 9 fixed columns (main.go:449,505) */
+  uint32_t eol_chars;         /* numChars: 1 for "\n", 2 for "\r\n" (main.go:250,535) */
+  uint8_t eol_byte;           /* endOfLineByte, '\n' unless the file uses lone '\r' */
+  uint8_t want_class_maps;    /* needsLabels: emit the 2-bit class maps (main.go:502) */
+  uint8_t reserved0[2];
+  const char *allow_filter;   /* --allowFilter text; NULL, "" or "*" = allow all (main.go:98,108-114) */
+  const char *exclude_filter; /* --excludeFilter text; NULL or "" = none (main.go:99,117-123) */
+  uint64_t max_batch_bytes;   /* largest block bvcf_submit accepts (0 = 64 MiB) */
+  uint32_t max_lines;         /* 0 = derived from max_batch_bytes and n_header_fields */
+  uint32_t max_alleles;       /* 0 = 2 * max_lines */
+  uint64_t cmap_bytes;        /* class-map arena (0 = max_batch_bytes / 8 + 1 MiB) */
+  uint32_t n_slots;           /* batches in flight (0 = 2) */
+  uint32_t reserved1;
+} bvcf_params;
+
+/* one input line; 64 bytes */
+typedef struct {
+  uint32_t off;        /* line start, bytes from block start */
+  uint32_t len;        /* bytes without the terminator */
+  uint32_t fend[9];    /* end (exclusive, relative to off) of fields 0..8; missing fields = len.
+                          field i starts at (i ? fend[i-1]+1 : 0) */
+  uint32_t rec_first;  /* first bvcf_allele of this line */
+  uint32_t n_rec;      /* number of output alleles (MNPs expand, rejected ALTs vanish) */
+  uint32_t n_fields;   /* len(record) */
+  uint32_t gt_task;    /* internal: first genotype-scan task of this line */
+  uint8_t status;      /* BVCF_LINE_* */
+  uint8_t site_type;   /* BVCF_SITE_* when status == OK */
+  uint8_t pad[2];
+} bvcf_line;
+
+/* one output allele == one candidate TSV row (dropped by the caller when samples exist and ac == 0,
+ * main.go:558-560); 64 bytes */
+typedef struct {
+  int64_t pos;         /* output position unless flags & BVCF_ALLELE_POS_TEXT */
+  uint32_t line;       /* index into lines[] */
+  uint32_t alt_idx;    /* 0-based VCF ALT index: the alleleIdx column (main.go:687) */
+  uint32_t alt_off;    /* BVCF_ALT_INS: block offset of the inserted bases */
+  uint32_t alt_len;    /* INS: inserted bases; DEL: deleted bases (the N of "-N"); BASE: 1 */
+  uint32_t ac;         /* totalAltCount  (main.go:1170) */
+  uint32_t an;         /* totalGtCount   (main.go:1169) */
+  uint32_t n_het;      /* len(hets)      */
+  uint32_t n_hom;      /* len(homs)      */
+  uint32_t n_miss;     /* len(missing)   */
+  uint32_t cmap_off;   /* byte offset of this allele's class map in cmap[], or BVCF_NO_CMAP */
+  uint8_t ref;         /* refs[i] */
+  uint8_t alt_base;    /* BVCF_ALT_BASE: the base */
+  uint8_t kind;        /* BVCF_ALT_* */
+  uint8_t site_type;   /* BVCF_SITE_* */
+  uint8_t trtv;        /* 0 / 1 / 2 (main.go:602-606) */
+  uint8_t flags;
+  uint8_t pad[2];
+  uint32_t gt_task;    /* internal: genotype-scan task that produced ac..n_miss */
+  uint32_t pad2;
+} bvcf_allele;
+
+/* one message getAlleles would log; 16 bytes */
+typedef struct {
+  uint32_t line;
+  uint32_t alt_no;     /* the %d of "ALT #%d" (1-based), 0 if the format has none */
+  uint32_t code;       /* BVCF_ERR_* */
+  uint32_t pad;
+} bvcf_err;
+
+/* a collected batch.  All pointers are library-owned pinned host memory, valid until the next
+ * bvcf_collect / bvcf_destroy on the same ctx. */
+typedef struct {
+  uint64_t batch_seq;
+  int32_t status;            /* BVCF_OK or BVCF_E_CAPACITY (then only need_* are meaningful) */
+  uint32_t n_lines;
+  uint32_t n_alleles;
+  uint32_t n_errs;
+  uint64_t n_cmap_bytes;
+  uint32_t cmap_stride;      /* bytes per class map: ceil(n_samples/4) rounded up to 16 */
+  uint32_t n_samples;
+  const bvcf_line *lines;
+  const bvcf_allele *alleles;
+  const bvcf_err *errs;      /* unordered; filter by lines[e.line].status != FIELDS/FILTER is done on device */
+  const uint8_t *cmap;
+  uint64_t need_lines, need_alleles, need_cmap_bytes;
+  float kernel_ms;           /* device time of the kernel chain for this batch (HIP events) */
+  uint32_t reserved;
+} bvcf_result;
+
+/* ---- lifecycle ---- */
+int bvcf_create(bvcf_ctx **out, const bvcf_params *p);
+void bvcf_destroy(bvcf_ctx *ctx);
+const char *bvcf_last_error(const bvcf_ctx *ctx);
+const char *bvcf_version(void);
+int bvcf_reserve(bvcf_ctx *ctx, uint64_t lines, uint64_t alleles, uint64_t cmap_bytes);
+
+/* pinned host memory for blocks handed to bvcf_submit (hipHostMalloc) */
+void *bvcf_alloc_pinned(size_t nbytes);
+void bvcf_free_pinned(void *p);
+
+/* ---- the hot path ---- */
+/* block: whole lines only (ends with a terminator; an unterminated tail is ignored, cf. main.go:354-358).
+ * Asynchronous; the block must stay valid until the matching bvcf_collect returns. */
+int bvcf_submit(bvcf_ctx *ctx, const uint8_t *block, size_t nbytes, uint64_t batch_seq);
+/* same, block already resident on ctx's device; it must own BVCF_DEVICE_PAD bytes past nbytes */
+int bvcf_submit_device(bvcf_ctx *ctx, const void *dblock, size_t nbytes, uint64_t batch_seq);
+/* blocks until the oldest submitted batch is done */
+int bvcf_collect(bvcf_ctx *ctx, bvcf_result *r);
+/* device-resident variant used by benchmarks: runs the kernel chain `iters` times back to back on a
+ * resident block without copying results to the host; returns the HIP-event time of each chain and
+ * of its dominant kernel (the per-line scan) in ms, plus the batch's counts. */
+int bvcf_bench_device(bvcf_ctx *ctx, const void *dblock, size_t nbytes, int iters, float *chain_ms,
+                      float *scan_ms, uint64_t counts[4] /* lines, alleles, errs, cmap bytes */);
+
+/* running totals since bvcf_create: {lines_in, lines_ok, alleles_out, alleles_ac0, errs,
+ * bytes_in, cmap_bytes, kernel_ns} */
+int bvcf_counters(bvcf_ctx *ctx, uint64_t out[8]);
+
+/* ---- host side of the path: header, TSV assembly, whole-stream driver ---- */
+
+/* mirrors main.go:63-80 `Config` */
+typedef struct {
+  const char *empty_field;      /* --emptyField      "!" */
+  const char *field_delimiter;  /* --fieldDelimiter  ";" */
+  const char *allow_filter;     /* --allowFilter     "PASS,." */
+  const char *exclude_filter;   /* --excludeFilter   "" */
+  uint8_t keep_id, keep_info, keep_pos, keep_qual; /* keepQual is parsed and never read (main.go:94) */
+  uint8_t normalize_header;     /* parse.NormalizeHeader restatement ('.' -> '_'), default 1 */
+  uint8_t reserved[3];
+  int32_t device;               /* HIP device ordinal */
+  uint32_t n_format_threads;    /* 0 = hardware concurrency */
+  uint64_t max_batch_bytes;     /* 0 = 64 MiB */
+} bvcf_config;
+
+void bvcf_config_defaults(bvcf_config *c); /* setup() defaults, main.go:84-99 */
+
+/* stringHeader(config), main.go:219-239: writes the tab-joined header (no newline), returns its
+ * length (or the length needed if cap is too small) */
+size_t bvcf_string_header(const bvcf_config *c, char *out, size_t cap);
+
+/* TSV rows for one collected batch, in input order (main.go:566-695).  sample_names[i] /
+ * sample_name_lens[i]: the (normalised) header fields 9.. ; appends to a malloc'd buffer the caller
+ * releases with bvcf_free.  Also renders the error list as the reference's log lines into *log. */
+int bvcf_format_tsv(const bvcf_config *c, const bvcf_result *r, const uint8_t *block,
+                    const char *const *sample_names, const uint32_t *sample_name_lens,
+                    char **out, size_t *n_out, char **log, size_t *n_log);
+
+/* readVcf(config, reader, writer) on an in-memory VCF (main.go:241-396): preamble checks, header,
+ * block cutting, submit/collect, TSV.  Output rows in input order, without the header line.
+ * Returns BVCF_OK, or BVCF_E_FATAL with the reference's message in *log. */
+int bvcf_run_buffer(const bvcf_config *c, const uint8_t *vcf, size_t n, char **out, size_t *n_out,
+                    char **log, size_t *n_log, uint64_t *n_lines_in);
+
+/* the same over file descriptors (the CLI): reads fd_in to EOF, writes header + rows to fd_out and
+ * log lines to fd_err */
+int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_t *n_lines_in);
+
+void bvcf_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BVCF_H */

@@ -1,0 +1,177 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle and with the reference's own
+known answers / golden output.  Integer, byte and text results must be identical."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import vcfgen
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H8 = ["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO"]
+
+
+@pytest.fixture(scope="module")
+def bv():
+    import bystro_vcf_amd as b
+    return b
+
+
+def both(bv, vcf, cfg=None, **kw):
+    """run the oracle and the HIP path on the same bytes; assert identical TSV and log"""
+    rc_o, out_o, log_o, n_o = orc.run(vcf, cfg)
+    rc_g, out_g, log_g, n_g = bv.run_buffer(vcf, cfg, **kw)
+    assert (rc_g != 0) == (rc_o != 0), (rc_g, rc_o, log_g)
+    assert n_g == n_o
+    if out_g != out_o:
+        a, b = out_o.split(b"\n"), out_g.split(b"\n")
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert x == y, "row %d differs:\noracle: %r\nhip:    %r" % (i, x[:300], y[:300])
+        assert len(a) == len(b)
+    assert log_g == log_o
+    return out_g, log_g
+
+
+def test_end_to_end_known_answers(bv, known_answers):
+    from test_oracle import check_rows
+    for case in known_answers["end_to_end"]:
+        out, _ = both(bv, case["vcf"].encode(), case["config"])
+        check_rows(case, out)
+
+
+def test_get_alleles_known_answers(bv, known_answers):
+    hdr = "##fileformat=VCFv4.x\n" + "\t".join(H8) + "\n"
+    for case in known_answers["get_alleles"]:
+        rec = "\t".join([case["chrom"], case["pos"], ".", case["ref"], case["alt"], ".", "PASS", "."]) + "\n"
+        rc, out, _, _ = bv.run_buffer((hdr + rec).encode(), {"allow": ""})
+        assert rc == 0
+        rows = [r.split("\t") for r in out.decode().split("\n") if r]
+        got = [[r[1], r[3], r[4]] for r in rows]
+        assert got == [a[:3] for a in case["alleles"]], case["cite"]
+        if rows:
+            assert {r[2] for r in rows} == {case["type"]}, case["cite"]
+
+
+def test_make_het_hom_known_answers(bv, known_answers):
+    """per-allele ac/an/het/hom/missing straight from bvcf_collect"""
+    for case in known_answers["make_het_hom"]:
+        fields = case["line"].split("\t")[:case["n_header"]]  # drop the tests' stray 14th field
+        a = int(case["allele"])
+        fields[4] = ",".join("TGAC"[:max(a, 1)])
+        line = ("\t".join(fields) + "\n").encode()
+        ctx = bv.Ctx(case["n_header"], allow="")
+        b = ctx.process(line)
+        ctx.close()
+        assert b.lines["status"][0] == bv.LINE_OK, case["cite"]
+        rec = [r for r in b.alleles[: b.lines["n_rec"][0] + b.lines["rec_first"][0]] if r["alt_idx"] == a - 1][0]
+        got = (int(rec["n_hom"]), int(rec["n_het"]), int(rec["n_miss"]), int(rec["ac"]), int(rec["an"]))
+        want = (case["n_hom"], case["n_het"], case["n_missing"], case["ac"], case["an"])
+        assert got == want, case["cite"]
+        cls = b.classes(rec)
+        ocls, _, _, _ = orc.make_het_hom(case["line"], case["n_header"], case["allele"])
+        assert cls.tolist() == ocls, case["cite"]
+
+
+def test_golden_1kg(bv, golden_1kg):
+    """the reference's regression pair: 19 747 rows x 2 504 samples -> 19 821 rows"""
+    vcf, want_sorted, _ = golden_1kg
+    out, log = both(bv, vcf)
+    rows = out.split(b"\n")
+    assert rows[-1] == b"" and len(rows) - 1 == 19821
+    assert sorted(rows[:-1]) == want_sorted
+    assert log.count("ALT not ACTG") == 17
+
+
+def test_golden_1kg_small_batches_and_flags(bv, golden_1kg):
+    vcf = golden_1kg[0]
+    cut = vcf[: vcf.index(b"\n", 40_000_000) + 1]
+    cfg = {"keepId": True, "keepInfo": True, "keepPos": True, "allow": "PASS", "emptyField": "NA", "fieldDelimiter": "|"}
+    both(bv, cut, cfg, max_batch_bytes=3 << 20)
+
+
+def test_example_query_vcf(bv):
+    """BASELINE config 0: examples/test.query.vcf (60 samples, GT:AD:DP:GQ:PL, FILTER '.')"""
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "test.query.vcf.gz"), "rb") as f:
+        vcf = f.read()
+    out, _ = both(bv, vcf)
+    assert len(out.split(b"\n")) - 1 == 879
+    both(bv, vcf, {"keepId": True, "keepInfo": True, "allow": "*"})
+
+
+@pytest.mark.parametrize("seed,n_lines,n_samples,fmt_extra,weird", [
+    (1, 400, 0, False, 0.05), (2, 400, 1, False, 0.1), (3, 300, 7, False, 0.1), (4, 300, 64, False, 0.02),
+    (5, 200, 255, False, 0.02), (6, 200, 256, False, 0.0), (7, 200, 257, False, 0.01), (8, 150, 1000, False, 0.002),
+    (9, 200, 33, True, 0.05), (10, 100, 300, True, 0.01), (11, 60, 2504, False, 0.001), (12, 300, 5, False, 0.5),
+])
+def test_fuzz_parity(bv, seed, n_lines, n_samples, fmt_extra, weird):
+    vcf = vcfgen.gen_vcf(seed, n_lines, n_samples, fmt_extra, weird)
+    both(bv, vcf, {"allow": ""})
+    both(bv, vcf, {"keepId": True, "keepInfo": True, "keepPos": True, "exclude": "q10"})
+
+
+def test_crlf_and_lone_cr(bv):
+    v = vcfgen.gen_vcf(21, 120, 9, weird=0.05, eol="\r\n")
+    both(bv, v, {"allow": ""})
+
+
+def test_unterminated_tail_and_empty_body(bv):
+    h = vcfgen.header(3).encode()
+    both(bv, h)
+    both(bv, h + b"1\t5\t.\tA\tG\t.\tPASS\t.\tGT\t0|1\t1|1\t0|0\n1\t6\t.\tA\tC\t.\tPASS\t.\tGT\t0|1\t1|1\t0|0")
+    both(bv, h + b"1\t5\t.\tA\tG\t.\tPASS\t.\tGT\t0|1\t1|1\t")          # empty last sample field
+    both(bv, h + b"1\t5\t.\tA\tG\t.\tPASS\t.\tGT\t0|1\t1|1\t\n")
+    both(bv, h + b"1\t5\t.\tA\tG\t.\tPASS\t.\tGT\t\t\t\n", {"allow": ""})
+    both(bv, h + b"1\t5\t.\tA\tG\t.\tPASS\t.\tGT\n", {"allow": ""})      # region missing entirely
+    both(bv, h + b"1\t5\t.\tA\tG\t.\tPASS\t.\tGT\t\n", {"allow": ""})
+
+
+def test_long_info_pushes_samples_past_first_window(bv):
+    h = vcfgen.header(300).encode()
+    gts = b"\t".join([b"0|1", b"1|1", b"0|0"] * 100)
+    for n in (10, 200, 240, 1000, 1024, 5000):
+        line = b"7\t100\t.\tA\tG\t.\tPASS\t" + b"X" * n + b"\tGT\t" + gts + b"\n"
+        both(bv, h + line * 3)
+
+
+def test_result_capacity_growth(bv):
+    """a tiny reservation must surface as BVCF_E_CAPACITY, then succeed after bvcf_reserve"""
+    vcf = vcfgen.gen_vcf(31, 500, 40, weird=0.0)
+    body = vcf[vcf.index(b"#CHROM"):]
+    body = body[body.index(b"\n") + 1:]
+    ctx = bv.Ctx(49, allow="", max_lines=16, max_alleles=16, cmap_bytes=64)
+    ctx.submit(body)
+    with pytest.raises(bv.BvcfError) as ei:
+        ctx.collect()
+    assert ei.value.rc == bv.E_CAPACITY
+    ctx.reserve(1000, 4000, 1 << 20)
+    b = ctx.process(body)
+    assert len(b.lines) == body.count(b"\n")
+    ctx.close()
+    both(bv, vcf, {"allow": ""})
+
+
+def test_device_resident_submit_matches_host_submit(bv):
+    import torch
+    vcf = vcfgen.gen_vcf(41, 200, 100, weird=0.01)
+    body = vcf[vcf.index(b"#CHROM"):]
+    body = body[body.index(b"\n") + 1:]
+    ctx = bv.Ctx(109, allow="")
+    a = ctx.process(body)
+    t = torch.zeros(len(body) + bv.DEVICE_PAD, dtype=torch.uint8, device="cuda")
+    t[: len(body)] = torch.frombuffer(bytearray(body), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    ctx.submit_device(t.data_ptr(), len(body))
+    b = ctx.collect()
+    ctx.close()
+    for f in ("off", "len", "n_rec", "status", "n_fields"):
+        assert (a.lines[f] == b.lines[f]).all()
+    assert len(a.alleles) == len(b.alleles)
+    for la, lb in zip(a.lines, b.lines):
+        ra = a.alleles[la["rec_first"]: la["rec_first"] + la["n_rec"]]
+        rb = b.alleles[lb["rec_first"]: lb["rec_first"] + lb["n_rec"]]
+        for f in ("pos", "alt_idx", "ac", "an", "n_het", "n_hom", "n_miss", "ref", "kind", "trtv"):
+            assert (ra[f] == rb[f]).all()
