@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — variants/sec of the HIP per-line variant pipeline on 1KG-chr1-shaped synthetic VCF.
+
+    python bench.py --gpus N --steps K --warmup W            (N == 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  A step = one pass of the whole kernel chain (line index, head/getAlleles,
+genotype scan, finish) over one resident batch of `--rows` synthetic rows (BASELINE.json configs[2]:
+2 504 samples, biallelic SNPs, ~10 164 B/row).  `--blocks` distinct batches are generated on the
+device before timing and visited round-robin, each far larger than the 256 MiB Infinity Cache, so
+every step streams its text from HBM.  Records are independent: rank r owns its own rows (weak
+scaling), no collective in the data path; the per-rank variant counts are summed over RCCL at the end.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_gt, the genotype scan):
+achieved = algorithmic GT-text bytes per launch / its mean HIP-event duration inside the timed
+region.  `cpu_baseline` (rank 0, N == 1 only) times the CPU oracle — the C restatement of the
+reference algorithm, kind "port" — on a bounded sample of the same row model.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(profile, rows_total=100_000, chunk=25_000):
+    """the oracle (oracle/bvcf_oracle.c), all host cores, on a bounded sample of the same rows"""
+    import benchgen as bg
+    import oracle_lib as orc
+
+    cfg = bg.make_cfg(profile)
+    hdr = bg.header(cfg)
+    cores = os.cpu_count() or 1
+    elapsed, rows, out_rows = 0.0, 0, 0
+    for first in range(0, rows_total, chunk):
+        vcf = hdr + bg.rows_host(cfg, 10_000_000 + first, chunk)
+        t0 = time.perf_counter()
+        rc, out, _, n = orc.run(vcf, None, n_threads=cores)
+        elapsed += time.perf_counter() - t0
+        assert rc == 0 and n == chunk
+        rows += n
+        out_rows += out.count(b"\n")
+    return {
+        "value": rows / elapsed, "unit": "variants/s", "cores": cores, "kind": "port",
+        "sample": "%d rows of the same synthetic %s stream (%d-row chunks), oracle/bvcf_oracle.c with %d worker "
+                  "threads over 64-line batches, output discarded; %.1f s wall" % (rows, profile, chunk, cores, elapsed),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=131072, help="rows per step per GPU")
+    ap.add_argument("--blocks", type=int, default=4, help="distinct resident batches per GPU")
+    ap.add_argument("--profile", default="c3", choices=["c2", "c3", "c4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import benchgen as bg
+    import bystro_vcf_amd as bv
+
+    cfg = bg.make_cfg(args.profile)
+    ns = cfg.n_samples
+    # ---- synthetic batches, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)
+    blocks, sizes = [], []
+    for b in range(args.blocks):
+        first = (rank * args.blocks + b) * args.rows
+        t, nbytes = bg.rows_device(cfg, first, args.rows, pad=bv.DEVICE_PAD)
+        blocks.append(t)
+        sizes.append(nbytes)
+    max_bytes = max(sizes)
+    stride = ((ns + 3) // 4 + 15) & ~15
+    n_alt_cap = args.rows * (4 if args.profile == "c4" else 1) + 1024
+    ctx = bv.Ctx(bg.n_header_fields(cfg), device=local_rank, max_batch_bytes=max_bytes, n_slots=1,
+                 max_lines=args.rows + 16, max_alleles=n_alt_cap, cmap_bytes=n_alt_cap * stride + 4096)
+    ptrs = [t.data_ptr() for t in blocks]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warm-up, then exactly K timed steps between barrier + synchronize on both sides
+    if args.warmup:
+        ctx.bench_device(ptrs, sizes, args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    chain_ms, gt_ms, counts = ctx.bench_device(ptrs, sizes, args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    assert counts[0] == args.rows, counts
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    n_var = torch.tensor([float(args.rows * args.steps)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)   # slowest rank
+        dist.all_reduce(n_var, op=dist.ReduceOp.SUM)  # the final count gather over RCCL/xGMI
+    elapsed = float(t_el.item())
+    total_variants = float(n_var.item())
+
+    if rank == 0:
+        mean_bytes = sum(sizes[i % args.blocks] for i in range(args.steps)) / args.steps
+        gt_mean_ms = sum(gt_ms) / len(gt_ms)
+        chain_mean_ms = sum(chain_ms) / len(chain_ms)
+        # algorithmic bytes of one k_gt launch: the GT text of every row, 4 bytes per sample
+        gt_bytes = args.rows * 4 * ns
+        achieved = gt_bytes / (gt_mean_ms * 1e-3) / 1e9 if ns else None
+        pmc = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "k_gt_hbm_traffic.json")) as f:
+                pmc = json.load(f).get(args.profile, {}).get("traffic_bytes_per_launch_per_row")
+        except OSError:
+            pass
+        line = {
+            "metric": "variants/sec",
+            "value": total_variants / elapsed,
+            "unit": "variants/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": {"c2": "BASELINE configs[1]: sites-only, 1M biallelic SNPs, 0 samples",
+                             "c3": "BASELINE configs[2]: 1KG-Phase3 chr1-shaped, 2504 samples, biallelic SNPs",
+                             "c4": "BASELINE configs[3]: 2504 samples, 20% multiallelic + 15% indels"}[args.profile],
+                "rows_per_step_per_gpu": args.rows, "resident_batches_per_gpu": args.blocks,
+                "bytes_per_row": mean_bytes / args.rows, "n_samples": ns,
+                "flags": "default (--allowFilter PASS,.), class maps on", "input": "resident in HBM",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_gt", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                "traffic": (pmc * args.rows) if pmc else None,
+                "algorithmic_bytes_per_launch": gt_bytes, "mean_launch_ms": gt_mean_ms,
+            },
+            "chain": {"mean_ms": chain_mean_ms, "text_GBps": mean_bytes / (chain_mean_ms * 1e-3) / 1e9,
+                      "frac_of_hbm_peak": mean_bytes / (chain_mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "variants_per_min": total_variants / elapsed * 60,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.profile)
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,8 +100,8 @@ lib.bvcf_free_pinned.argtypes = [C.c_void_p]
 lib.bvcf_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
 lib.bvcf_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
 lib.bvcf_collect.argtypes = [C.c_void_p, C.POINTER(Result)]
-lib.bvcf_bench_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float),
-                                  C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+lib.bvcf_bench_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
 lib.bvcf_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 lib.bvcf_config_defaults.argtypes = [C.POINTER(Config)]
 lib.bvcf_config_defaults.restype = None
@@ -185,6 +185,15 @@ class Batch:
         self.errs = arr(r.errs, r.n_errs, ERR_DTYPE)
         self.cmap = arr(r.cmap, r.n_cmap_bytes, np.dtype("u1"))
 
+    def records(self, i):
+        """the output alleles of line i, in order"""
+        L = self.lines[i]
+        n = int(L["n_rec"])
+        if n == 0:
+            return self.alleles[:0]
+        idx = [i] + [int(L["rec_first"]) + j - 1 for j in range(1, n)]
+        return self.alleles[idx]
+
     def classes(self, allele_row):
         """per-sample class codes (0 none, 1 het, 2 hom, 3 missing) of one allele record"""
         off = int(allele_row["cmap_off"])
@@ -254,11 +263,16 @@ class Ctx:
         self.submit(block)
         return self.collect()
 
-    def bench_device(self, dptr, nbytes, iters):
+    def bench_device(self, dptrs, nbytes, iters):
+        """kernel chain `iters` times over resident blocks (rotating); results stay on the device.
+        -> (chain ms per step, genotype-scan ms per step, [lines, alleles, errs, cmap bytes, tasks])"""
+        n = len(dptrs)
+        ptrs = (C.c_void_p * n)(*dptrs)
+        sizes = (C.c_size_t * n)(*nbytes)
         chain = (C.c_float * iters)()
         scan = (C.c_float * iters)()
-        counts = (C.c_uint64 * 4)()
-        self._check(lib.bvcf_bench_device(self.h, dptr, nbytes, iters, chain, scan, counts))
+        counts = (C.c_uint64 * 5)()
+        self._check(lib.bvcf_bench_device(self.h, ptrs, sizes, n, iters, chain, scan, counts))
         return list(chain), list(scan), list(counts)
 
     def counters(self):

@@ -321,8 +321,10 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   c->cmap_stride = ((c->n_samples + 3) / 4 + 15) & ~15u;
   const uint64_t min_line = std::max<uint64_t>(48, 2ull * p->n_header_fields);
   c->max_lines = p->max_lines ? p->max_lines : c->p.max_batch_bytes / min_line + 4096;
-  c->max_alleles = p->max_alleles ? p->max_alleles : c->max_lines + c->max_lines / 2;
-  c->max_cmap = p->cmap_bytes ? p->cmap_bytes : c->p.max_batch_bytes / 8 + (1ull << 20);
+  c->max_alleles = p->max_alleles ? p->max_alleles : 2 * c->max_lines + 1024;
+  if (c->max_alleles < c->max_lines + 64) c->max_alleles = c->max_lines + 64;  // slot i belongs to line i
+  c->max_cmap = p->cmap_bytes ? p->cmap_bytes : (c->max_lines + c->max_lines / 2) * (uint64_t)c->cmap_stride + (1ull << 20);
+  if (c->max_cmap > 0xFFFFFF00ull) c->max_cmap = 0xFFFFFF00ull;  // cmap_off is 32-bit
   c->max_cmap = (c->max_cmap + 63) & ~63ull;
   auto fail = [&](int rc) {
     g_create_err = c->err;
@@ -374,8 +376,8 @@ int bvcf_reserve(bvcf_ctx *c, uint64_t lines, uint64_t alleles, uint64_t cmap_by
   }
   if (lines > 0xFFFFFFF0ull || alleles > 0xFFFFFFF0ull) return BVCF_E_ARG;
   c->max_lines = std::max<uint64_t>(c->max_lines, lines);
-  c->max_alleles = std::max<uint64_t>(c->max_alleles, alleles);
-  c->max_cmap = std::max<uint64_t>(c->max_cmap, (cmap_bytes + 63) & ~63ull);
+  c->max_alleles = std::max<uint64_t>(std::max<uint64_t>(c->max_alleles, alleles), c->max_lines + 64);
+  c->max_cmap = std::min<uint64_t>(std::max<uint64_t>(c->max_cmap, (cmap_bytes + 63) & ~63ull), 0xFFFFFF00ull);
   HIP_TRY(c, hipSetDevice(c->device));
   for (auto &s : c->slots) {
     int rc = alloc_results(c, s);
@@ -422,26 +424,30 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   hipEventElapsedTime(&ms, s.ev_k0, s.ev_k1);
   r->kernel_ms = ms;
   const BatchCounters ctr = *s.h_counters;
-  const uint64_t need_alleles = std::max<uint64_t>(std::max<uint64_t>(ctr.n_alleles, ctr.n_errs), ctr.n_tasks);
-  if (ctr.n_lines > s.cap_lines || need_alleles > s.cap_alleles || ctr.cmap_bytes > s.cap_cmap) {
+  // slot i of alleles[] / tasks / class maps belongs to line i; the counters count the extras
+  const uint64_t n_alleles = (uint64_t)ctr.n_lines + ctr.n_alleles;
+  const uint64_t n_tasks = (uint64_t)ctr.n_lines + ctr.n_tasks;
+  const uint64_t need_alleles = std::max<uint64_t>(std::max<uint64_t>(n_alleles, ctr.n_errs), n_tasks);
+  const bool maps = c->p.want_class_maps && c->n_samples;
+  const uint64_t cmap_bytes = maps ? n_tasks * c->cmap_stride : 0;
+  if (ctr.n_lines > s.cap_lines || need_alleles > s.cap_alleles || cmap_bytes > s.cap_cmap) {
     r->status = BVCF_E_CAPACITY;
     r->need_lines = ctr.n_lines;
     r->need_alleles = need_alleles;
-    r->need_cmap_bytes = ctr.cmap_bytes;
+    r->need_cmap_bytes = cmap_bytes;
     c->err = "batch exceeds reserved result capacity";
     release();
     return BVCF_E_CAPACITY;
   }
-  const bool maps = c->p.want_class_maps && c->n_samples;
   if (ctr.n_lines)
     HIP_TRY(c, hipMemcpyAsync(s.h_lines, s.d_lines, ctr.n_lines * sizeof(bvcf_line), hipMemcpyDeviceToHost, s.stream));
-  if (ctr.n_alleles)
-    HIP_TRY(c, hipMemcpyAsync(s.h_alleles, s.d_alleles, ctr.n_alleles * sizeof(bvcf_allele), hipMemcpyDeviceToHost,
+  if (n_alleles)
+    HIP_TRY(c, hipMemcpyAsync(s.h_alleles, s.d_alleles, n_alleles * sizeof(bvcf_allele), hipMemcpyDeviceToHost,
                               s.stream));
   if (ctr.n_errs)
     HIP_TRY(c, hipMemcpyAsync(s.h_errs, s.d_errs, ctr.n_errs * sizeof(bvcf_err), hipMemcpyDeviceToHost, s.stream));
-  if (maps && ctr.cmap_bytes)
-    HIP_TRY(c, hipMemcpyAsync(s.h_cmap, s.d_cmap, ctr.cmap_bytes, hipMemcpyDeviceToHost, s.stream));
+  if (cmap_bytes)
+    HIP_TRY(c, hipMemcpyAsync(s.h_cmap, s.d_cmap, cmap_bytes, hipMemcpyDeviceToHost, s.stream));
   e = hipStreamSynchronize(s.stream);
   if (e != hipSuccess) {
     c->err = std::string("result copy failed: ") + hipGetErrorString(e);
@@ -457,21 +463,26 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   }
   r->status = BVCF_OK;
   r->n_lines = ctr.n_lines;
-  r->n_alleles = ctr.n_alleles;
+  r->n_alleles = (uint32_t)n_alleles;
   r->n_errs = n_errs;
-  r->n_cmap_bytes = maps ? ctr.cmap_bytes : 0;
+  r->n_cmap_bytes = cmap_bytes;
   r->lines = s.h_lines;
   r->alleles = s.h_alleles;
   r->errs = s.h_errs;
   r->cmap = s.h_cmap;
 
-  uint64_t ok = 0, ac0 = 0;
-  for (uint32_t i = 0; i < ctr.n_lines; i++) ok += s.h_lines[i].status == BVCF_LINE_OK;
-  if (c->n_samples)
-    for (uint32_t i = 0; i < ctr.n_alleles; i++) ac0 += s.h_alleles[i].ac == 0;
+  uint64_t ok = 0, ac0 = 0, recs = 0;
+  for (uint32_t i = 0; i < ctr.n_lines; i++) {
+    const bvcf_line &L = s.h_lines[i];
+    if (L.status != BVCF_LINE_OK) continue;
+    ok++;
+    recs += L.n_rec;
+    if (c->n_samples)
+      for (uint32_t j = 0; j < L.n_rec; j++) ac0 += s.h_alleles[j ? L.rec_first + j - 1 : i].ac == 0;
+  }
   c->totals[0] += ctr.n_lines;
   c->totals[1] += ok;
-  c->totals[2] += ctr.n_alleles;
+  c->totals[2] += recs;
   c->totals[3] += ac0;
   c->totals[4] += n_errs;
   c->totals[5] += s.nbytes;
@@ -487,22 +498,23 @@ int bvcf_counters(bvcf_ctx *c, uint64_t out[8]) {
   return BVCF_OK;
 }
 
-int bvcf_bench_device(bvcf_ctx *c, const void *dblock, size_t nbytes, int iters, float *chain_ms, float *scan_ms,
-                      uint64_t counts[4]) {
-  if (!c || !dblock || iters < 1) return BVCF_E_ARG;
+int bvcf_bench_device(bvcf_ctx *c, const void *const *dblocks, const size_t *nbytes, int n_blocks, int iters,
+                      float *chain_ms, float *gt_ms, uint64_t counts[5]) {
+  if (!c || !dblocks || !nbytes || n_blocks < 1 || iters < 1) return BVCF_E_ARG;
   if (c->in_flight) {
     c->err = "bvcf_bench_device with batches in flight";
     return BVCF_E_BUSY;
   }
-  if (nbytes > c->p.max_batch_bytes || nbytes >= 0xFFFFFF00ull) return BVCF_E_TOO_BIG;
+  for (int b = 0; b < n_blocks; b++)
+    if (!dblocks[b] || nbytes[b] > c->p.max_batch_bytes || nbytes[b] >= 0xFFFFFF00ull) return BVCF_E_TOO_BIG;
   HIP_TRY(c, hipSetDevice(c->device));
   Slot &s = c->slots[0];
   int rc = alloc_results(c, s);
   if (rc) return rc;
-  KernelArgs a = make_args(c, s, (const uint8_t *)dblock, nbytes);
   std::vector<hipEvent_t> ev((size_t)iters * 4);
   for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
   for (int i = 0; i < iters; i++) {
+    KernelArgs a = make_args(c, s, (const uint8_t *)dblocks[i % n_blocks], nbytes[i % n_blocks]);
     HIP_TRY(c, hipEventRecord(ev[4 * i], s.stream));
     launch_chain(c, a, s.stream, ev[4 * i + 1], ev[4 * i + 2]);
     HIP_TRY(c, hipEventRecord(ev[4 * i + 3], s.stream));
@@ -515,17 +527,21 @@ int bvcf_bench_device(bvcf_ctx *c, const void *dblock, size_t nbytes, int iters,
     hipEventElapsedTime(&t0, ev[4 * i], ev[4 * i + 3]);
     hipEventElapsedTime(&t1, ev[4 * i + 1], ev[4 * i + 2]);
     if (chain_ms) chain_ms[i] = t0;
-    if (scan_ms) scan_ms[i] = t1;
+    if (gt_ms) gt_ms[i] = t1;
   }
   for (auto &e : ev) hipEventDestroy(e);
+  const BatchCounters ctr = *s.h_counters;
   if (counts) {
-    counts[0] = s.h_counters->n_lines;
-    counts[1] = s.h_counters->n_alleles;
-    counts[2] = s.h_counters->n_errs;
-    counts[3] = s.h_counters->cmap_bytes;
+    counts[0] = ctr.n_lines;
+    counts[1] = (uint64_t)ctr.n_lines + ctr.n_alleles;
+    counts[2] = ctr.n_errs;
+    counts[3] = ((uint64_t)ctr.n_lines + ctr.n_tasks) * c->cmap_stride;
+    counts[4] = (uint64_t)ctr.n_lines + ctr.n_tasks;
   }
-  if (s.h_counters->n_lines > s.cap_lines || s.h_counters->n_alleles > s.cap_alleles ||
-      s.h_counters->n_tasks > s.cap_alleles || s.h_counters->cmap_bytes > s.cap_cmap) {
+  const uint64_t b_need = std::max<uint64_t>(std::max<uint64_t>((uint64_t)ctr.n_lines + ctr.n_alleles, ctr.n_errs),
+                                             (uint64_t)ctr.n_lines + ctr.n_tasks);
+  if (ctr.n_lines > s.cap_lines || b_need > s.cap_alleles ||
+      (c->p.want_class_maps && c->n_samples && ((uint64_t)ctr.n_lines + ctr.n_tasks) * c->cmap_stride > s.cap_cmap)) {
     c->err = "bench block exceeds reserved result capacity";
     return BVCF_E_CAPACITY;
   }

@@ -225,27 +225,40 @@ __global__ __launch_bounds__(1024) void k_scan_top(KernelArgs a, uint32_t n_grou
   }
 }
 
-// line_off[i + 1] = offset just past line i's terminator
+// line_off[i + 1] = offset just past line i's terminator.  A wave looks at 64 census entries at
+// once (one per lane) and revisits only the chunks that hold a terminator.
 __global__ __launch_bounds__(kWgThreads) void k_scatter_eol(KernelArgs a, uint32_t n_chunks) {
   const int lane = lane_id();
   const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
-  const uint32_t stride = gridDim.x * kWavesPerWg;
-  for (uint32_t c = wave; c < n_chunks; c += stride) {
-    const uint32_t next = (c + 1 < n_chunks && ((c + 1) % kScanGroup) != 0) ? a.census[c + 1] : 0xFFFFFFFFu;
-    const uint32_t mine = a.census[c];
-    // chunks without a terminator are skipped without touching the text again
-    if (next == mine) continue;
-    const uint32_t off = c * kChunk + 16u * lane;
-    u32x4 v = load16(a.buf, off, a.cap);
-    uint32_t m = eq_mask16(v, a.eol_byte) & low_bits16((int)a.nbytes - (int)off);
-    uint32_t tot;
-    uint32_t pre = wave_excl_scan(__popc(m), &tot);
-    uint32_t idx = a.group_base[c / kScanGroup] + mine + pre;
-    while (m) {
-      uint32_t k = __ffs(m) - 1;
-      m &= m - 1;
-      if (idx < a.max_lines) a.line_off[idx + 1] = off + k + 1;
-      idx++;
+  const uint32_t stride = gridDim.x * kWavesPerWg * kWave;
+  for (uint32_t c0 = wave * kWave; c0 < n_chunks; c0 += stride) {
+    const uint32_t c = c0 + lane;
+    uint32_t mine = 0, cnt = 0;
+    if (c < n_chunks) {
+      mine = a.census[c];
+      // exclusive prefixes restart at group boundaries; the last chunk of a group (and of the
+      // batch) cannot be sized from its successor, so it is always revisited
+      const bool has_next = c + 1 < n_chunks && ((c + 1) % kScanGroup) != 0;
+      cnt = has_next ? a.census[c + 1] - mine : 1u;
+      mine += a.group_base[c / kScanGroup];
+    }
+    unsigned long long todo = __ballot(cnt != 0);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const uint32_t cc = c0 + src;
+      uint32_t idx = __shfl(mine, src, kWave);
+      const uint32_t off = cc * kChunk + 16u * lane;
+      u32x4 v = load16(a.buf, off, a.cap);
+      uint32_t m = eq_mask16(v, a.eol_byte) & low_bits16((int)a.nbytes - (int)off);
+      uint32_t tot;
+      idx += wave_excl_scan(__popc(m), &tot);
+      while (m) {
+        const uint32_t k = __ffs(m) - 1;
+        m &= m - 1;
+        if (idx < a.max_lines) a.line_off[idx + 1] = off + k + 1;
+        idx++;
+      }
     }
   }
 }
@@ -713,11 +726,12 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
 
 __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
   const int lane = lane_id();
-  const uint32_t n_tasks = min(a.counters->n_tasks, a.max_tasks);
+  const uint32_t n_tasks = min(min(a.counters->n_lines, a.max_lines) + a.counters->n_tasks, a.max_tasks);
   const uint32_t stride = gridDim.x * kWavesPerWg;
   const uint32_t ns = a.n_samples;
   for (uint32_t ti = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); ti < n_tasks; ti += stride) {
     const GtTask t = a.tasks[ti];
+    if (t.allele == 0) continue;  // line rejected before getAlleles: nothing to scan
     uint8_t *cm = t.cmap_off != BVCF_NO_CMAP ? a.cmap + t.cmap_off : nullptr;
     GtStats st = {0, 0, 0, 0, 0};
     uint32_t n_fields;
@@ -811,16 +825,15 @@ __device__ inline void write_allele(const KernelArgs &a, uint32_t idx, uint32_t 
   a.alleles[idx] = r;
 }
 
-// append a genotype-scan task; returns its index (valid only if < max_tasks)
-__device__ inline uint32_t push_task(const KernelArgs &a, uint32_t line, uint32_t allele, uint32_t s_begin,
-                                     uint32_t cend, bool want_map, uint32_t *cmap_off) {
-  const uint32_t ti = atomicAdd(&a.counters->n_tasks, 1u);
+constexpr uint32_t kNoTask = 0xFFFFFFFFu;
+
+// Write genotype-scan task `ti`.  Slots are deterministic: task i < n_lines is "line i, ALT #1",
+// tasks past n_lines are the further ALT indices of multiallelic lines; the class map of task ti
+// lives at ti * cmap_stride.  allele == 0 marks a line that needs no scan.
+__device__ inline uint32_t put_task(const KernelArgs &a, uint32_t ti, uint32_t line, uint32_t allele, uint32_t s_begin,
+                                    uint32_t cend, bool want_map) {
   uint32_t cm = BVCF_NO_CMAP;
-  if (want_map) {
-    const unsigned long long o = atomicAdd(&a.counters->cmap_bytes, (unsigned long long)a.cmap_stride);
-    if (o + a.cmap_stride <= a.max_cmap) cm = (uint32_t)o;
-  }
-  *cmap_off = cm;
+  if (want_map && ((unsigned long long)ti + 1ull) * a.cmap_stride <= a.max_cmap) cm = ti * a.cmap_stride;
   if (ti < a.max_tasks) {
     GtTask t;
     t.line = line;
@@ -831,7 +844,7 @@ __device__ inline uint32_t push_task(const KernelArgs &a, uint32_t line, uint32_
     t.pad[0] = t.pad[1] = t.pad[2] = 0;
     a.tasks[ti] = t;
   }
-  return ti;
+  return cm;
 }
 
 __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
@@ -898,7 +911,8 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       return s;
     };
 
-    uint32_t rec_first = 0, n_rec = 0, site_type = 0, first_task = 0;
+    uint32_t rec_first = 0, n_rec = 0, site_type = 0;
+    bool task_written = false, primary_written = false;
 
     // ---- everything below is the group leader's serial work
     if (gl == 0 && status == BVCF_LINE_OK) {
@@ -938,18 +952,34 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       if (mode == 0) log_err(a, line, 0, BVCF_ERR_SAME);
       if (mode == 3) log_err(a, line, 0, BVCF_ERR_EMPTY_REF);
 
-      // Output slots by upper bound: a token yields <= max(1, its length) records (equal-length
-      // blocks expand per differing base, main.go:855-873), so ALT's length bounds the line.
-      const uint32_t rec_cap = mode == 1 ? 1u : (mode == 2 ? c.alt.len : 0u);
-      uint32_t rec_base = 0;
-      if (rec_cap) rec_base = atomicAdd(&a.counters->n_alleles, rec_cap);
-      const bool fits = (unsigned long long)rec_base + rec_cap <= a.max_alleles;
+      // Record slots are deterministic for the first record (index == line) and reserved by upper
+      // bound for the rest: a token yields one record, or one per differing base when it is as
+      // long as a multi-base REF (main.go:855-873).  Biallelic lines therefore need no atomics.
+      uint32_t bound = 0;
+      if (mode == 1) bound = 1;
+      if (mode == 2) {
+        uint32_t tl = 0;
+#pragma nounroll
+        for (uint32_t i = 0; i <= c.alt.len; i++) {
+          if (i == c.alt.len || a.buf[c.alt.off + i] == ',') {
+            bound += (tl == c.ref.len && c.ref.len > 1) ? c.ref.len : 1u;
+            tl = 0;
+          } else {
+            tl++;
+          }
+        }
+      }
+      uint32_t extra_base = 0;
+      if (bound > 1) extra_base = n_lines + atomicAdd(&a.counters->n_alleles, bound - 1);
+      const bool fits = bound <= 1 || (unsigned long long)extra_base + (bound - 1) <= a.max_alleles;
+      // slot of this line's j-th record
+      auto slot = [&](uint32_t j) -> uint32_t { return j == 0 ? line : extra_base + j - 1; };
 
       // With samples, the scan for ALT #1 always runs: it also settles len(record) == len(header).
-      uint32_t task0 = 0, cm0 = BVCF_NO_CMAP;
+      uint32_t cm0 = BVCF_NO_CMAP;
       if (ns > 0) {
-        task0 = push_task(a, line, 1, s_begin, cend, maps && (mode == 1 || mode == 2), &cm0);
-        first_task = task0;
+        cm0 = put_task(a, line, line, 1, s_begin, cend, maps && (mode == 1 || mode == 2));
+        task_written = true;
       }
 
       uint32_t cur = 0, emitted = 0;
@@ -969,8 +999,12 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
           if (e.err) log_err(a, line, (e.err == BVCF_ERR_POS) ? 0u : k + 1u, e.err);
           if (e.stop) break;
           if (!e.n) continue;
-          uint32_t task = task0, cm_off = cm0;
-          if (ns > 0 && k > 0) task = push_task(a, line, k + 1, s_begin, cend, maps, &cm_off);
+          uint32_t task = line, cm_off = cm0;
+          if (ns > 0 && k > 0) {
+            task = n_lines + atomicAdd(&a.counters->n_tasks, 1u);
+            cm_off = put_task(a, task, line, k + 1, s_begin, cend, maps);
+          }
+          if (ns == 0) task = kNoTask;
           if (fits) {
             // type call, main.go:1004-1037 (single-ALT path: main.go:743,764)
             uint8_t stype;
@@ -989,23 +1023,26 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
               for (uint32_t i = 0; i < c.ref.len; i++) {
                 const uint8_t rb = a.buf[c.ref.off + i], ab = a.buf[t.off + i];
                 if (rb == ab) continue;
-                write_allele(a, rec_base + emitted + j, line, k, e, c.int_pos + (long long)i, rb, ab, stype, task,
-                             cm_off);
+                write_allele(a, slot(emitted + j), line, k, e, c.int_pos + (long long)i, rb, ab, stype, task, cm_off);
                 j++;
               }
             } else {
-              write_allele(a, rec_base + emitted, line, k, e, e.pos, e.ref, e.alt_base, stype, task, cm_off);
+              write_allele(a, slot(emitted), line, k, e, e.pos, e.ref, e.alt_base, stype, task, cm_off);
             }
           }
           emitted += e.n;
         }
       }
+      // reserved but unused slots must not look like records to k_finish
+      if (fits)
+#pragma nounroll
+        for (uint32_t j = emitted > 1 ? emitted : 1; j < bound; j++) a.alleles[slot(j)].gt_task = kNoTask;
+      if (emitted) primary_written = true;
+      if (fits) rec_first = extra_base;
       if (emitted == 0)
         status = BVCF_LINE_NOALLELE;  // k_finish may still turn this into FIELDS
-      else if (fits) {
-        rec_first = rec_base;
+      else if (fits)
         n_rec = emitted;
-      }
       n_fields = 0;  // settled by k_finish from the scan when there are samples
       if (ns == 0) n_fields = a.n_header;
     }
@@ -1020,11 +1057,14 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       L.rec_first = rec_first;
       L.n_rec = n_rec;
       L.n_fields = n_fields;
-      L.gt_task = first_task;
+      L.gt_task = line;
       L.status = (uint8_t)status;
       L.site_type = (uint8_t)site_type;
       L.pad[0] = L.pad[1] = 0;
       a.lines[line] = L;
+      // every line owns task slot `line` and record slot `line`: mark the ones it did not fill
+      if (ns > 0 && !task_written) put_task(a, line, line, 0, cend, cend, false);
+      if (!primary_written && line < a.max_alleles) a.alleles[line].gt_task = kNoTask;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1036,8 +1076,8 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
 // the scan of ALT #1, and the scan results copied into the records that reference them.
 __global__ __launch_bounds__(kWgThreads) void k_finish(KernelArgs a) {
   const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
-  const uint32_t n_alleles = min(a.counters->n_alleles, a.max_alleles);
-  const uint32_t n_tasks = min(a.counters->n_tasks, a.max_tasks);
+  const uint32_t n_alleles = min(n_lines + a.counters->n_alleles, a.max_alleles);
+  const uint32_t n_tasks = min(n_lines + a.counters->n_tasks, a.max_tasks);
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nthreads = gridDim.x * blockDim.x;
   if (a.n_samples == 0) return;
@@ -1045,8 +1085,7 @@ __global__ __launch_bounds__(kWgThreads) void k_finish(KernelArgs a) {
     bvcf_line *L = &a.lines[i];
     const uint32_t st = L->status;
     if (st != BVCF_LINE_OK && st != BVCF_LINE_NOALLELE) continue;
-    if (L->gt_task >= n_tasks) continue;
-    const uint32_t nf = 9u + a.results[L->gt_task].n_fields;
+    const uint32_t nf = 9u + a.results[i].n_fields;
     L->n_fields = nf;
     if (nf != a.n_header) {
       L->status = BVCF_LINE_FIELDS;
@@ -1056,7 +1095,7 @@ __global__ __launch_bounds__(kWgThreads) void k_finish(KernelArgs a) {
   for (uint32_t i = tid; i < n_alleles; i += nthreads) {
     bvcf_allele *r = &a.alleles[i];
     const uint32_t t = r->gt_task;
-    if (t >= n_tasks) continue;  // unused slot of an upper-bound reservation
+    if (t >= n_tasks) continue;  // kNoTask: slot without a record
     const GtResult g = a.results[t];
     r->ac = g.ac;
     r->an = g.an;

@@ -116,7 +116,7 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
     const char *row = (const char *)block + L.off;
     auto fstart = [&](int i) -> uint32_t { return i ? L.fend[i - 1] + 1 : 0; };
     for (uint32_t k = 0; k < L.n_rec; k++) {
-      const bvcf_allele &A = r->alleles[L.rec_first + k];
+      const bvcf_allele &A = r->alleles[k ? L.rec_first + k - 1 : li];
       // main.go:555-560: with samples, an allele nobody carries is skipped
       if (ns > 0 && A.ac == 0) continue;
       // main.go:570-574

@@ -99,8 +99,8 @@ typedef struct {
   const char *exclude_filter; /* --excludeFilter text; NULL or "" = none (main.go:99,117-123) */
   uint64_t max_batch_bytes;   /* largest block bvcf_submit accepts (0 = 64 MiB) */
   uint32_t max_lines;         /* 0 = derived from max_batch_bytes and n_header_fields */
-  uint32_t max_alleles;       /* 0 = 2 * max_lines */
-  uint64_t cmap_bytes;        /* class-map arena (0 = max_batch_bytes / 8 + 1 MiB) */
+  uint32_t max_alleles;       /* slots of alleles[] (>= max_lines); 0 = 2 * max_lines + 1024 */
+  uint64_t cmap_bytes;        /* class-map arena, one map per (line, ALT index); 0 = 1.5 maps per line */
   uint32_t n_slots;           /* batches in flight (0 = 2) */
   uint32_t reserved1;
 } bvcf_params;
@@ -111,7 +111,7 @@ typedef struct {
   uint32_t len;        /* bytes without the terminator */
   uint32_t fend[9];    /* end (exclusive, relative to off) of fields 0..8; missing fields = len.
                           field i starts at (i ? fend[i-1]+1 : 0) */
-  uint32_t rec_first;  /* first bvcf_allele of this line */
+  uint32_t rec_first;  /* where this line's 2nd.. output alleles start (see bvcf_result.alleles) */
   uint32_t n_rec;      /* number of output alleles (MNPs expand, rejected ALTs vanish) */
   uint32_t n_fields;   /* len(record) */
   uint32_t gt_task;    /* internal: first genotype-scan task of this line */
@@ -165,6 +165,10 @@ typedef struct {
   uint32_t cmap_stride;      /* bytes per class map: ceil(n_samples/4) rounded up to 16 */
   uint32_t n_samples;
   const bvcf_line *lines;
+  /* output allele j of line i is alleles[i] for j == 0 and alleles[lines[i].rec_first + j - 1] after
+   * that: slot i always belongs to line i (no allocation, no atomics for biallelic lines), further
+   * alleles of multiallelic / MNP lines follow the first n_lines slots.  n_alleles is the array
+   * length, not the number of valid records. */
   const bvcf_allele *alleles;
   const bvcf_err *errs;      /* unordered; filter by lines[e.line].status != FIELDS/FILTER is done on device */
   const uint8_t *cmap;
@@ -192,11 +196,14 @@ int bvcf_submit(bvcf_ctx *ctx, const uint8_t *block, size_t nbytes, uint64_t bat
 int bvcf_submit_device(bvcf_ctx *ctx, const void *dblock, size_t nbytes, uint64_t batch_seq);
 /* blocks until the oldest submitted batch is done */
 int bvcf_collect(bvcf_ctx *ctx, bvcf_result *r);
-/* device-resident variant used by benchmarks: runs the kernel chain `iters` times back to back on a
- * resident block without copying results to the host; returns the HIP-event time of each chain and
- * of its dominant kernel (the per-line scan) in ms, plus the batch's counts. */
-int bvcf_bench_device(bvcf_ctx *ctx, const void *dblock, size_t nbytes, int iters, float *chain_ms,
-                      float *scan_ms, uint64_t counts[4] /* lines, alleles, errs, cmap bytes */);
+/* device-resident variant used by benchmarks: runs the kernel chain `iters` times back to back, step i
+ * on resident block i % n_blocks (each owning BVCF_DEVICE_PAD bytes past its nbytes), leaving the
+ * results in device memory.  HIP events on the launch stream give, per step, the time of the whole
+ * chain (chain_ms[i]) and of its dominant kernel, the genotype scan (gt_ms[i]).  counts receives
+ * {lines, alleles, errs, class-map bytes, tasks} of the last step.  Returns after the last step
+ * has finished. */
+int bvcf_bench_device(bvcf_ctx *ctx, const void *const *dblocks, const size_t *nbytes, int n_blocks, int iters,
+                      float *chain_ms, float *gt_ms, uint64_t counts[5]);
 
 /* running totals since bvcf_create: {lines_in, lines_ok, alleles_out, alleles_ac0, errs,
  * bytes_in, cmap_bytes, kernel_ns} */

@@ -67,7 +67,7 @@ def test_make_het_hom_known_answers(bv, known_answers):
         b = ctx.process(line)
         ctx.close()
         assert b.lines["status"][0] == bv.LINE_OK, case["cite"]
-        rec = [r for r in b.alleles[: b.lines["n_rec"][0] + b.lines["rec_first"][0]] if r["alt_idx"] == a - 1][0]
+        rec = [r for r in b.records(0) if r["alt_idx"] == a - 1][0]
         got = (int(rec["n_hom"]), int(rec["n_het"]), int(rec["n_miss"]), int(rec["ac"]), int(rec["an"]))
         want = (case["n_hom"], case["n_het"], case["n_missing"], case["ac"], case["an"])
         assert got == want, case["cite"]
@@ -170,8 +170,7 @@ def test_device_resident_submit_matches_host_submit(bv):
     for f in ("off", "len", "n_rec", "status", "n_fields"):
         assert (a.lines[f] == b.lines[f]).all()
     assert len(a.alleles) == len(b.alleles)
-    for la, lb in zip(a.lines, b.lines):
-        ra = a.alleles[la["rec_first"]: la["rec_first"] + la["n_rec"]]
-        rb = b.alleles[lb["rec_first"]: lb["rec_first"] + lb["n_rec"]]
+    for i in range(len(a.lines)):
+        ra, rb = a.records(i), b.records(i)
         for f in ("pos", "alt_idx", "ac", "an", "n_het", "n_hom", "n_miss", "ref", "kind", "trtv"):
             assert (ra[f] == rb[f]).all()

@@ -1,0 +1,81 @@
+"""The bench's synthetic row model: device generator == host generator, and HIP path == oracle on it
+(BASELINE configs 1-3 shapes at sizes the oracle finishes in seconds)."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import benchgen as bg
+    import bystro_vcf_amd as bv
+    return bg, bv
+
+
+@pytest.mark.parametrize("profile,first,n", [("c2", 0, 5000), ("c3", 123456, 600), ("c4", 999, 600)])
+def test_device_rows_equal_host_rows(mods, profile, first, n):
+    bg, bv = mods
+    cfg = bg.make_cfg(profile)
+    host = bg.rows_host(cfg, first, n)
+    t, nbytes = bg.rows_device(cfg, first, n)
+    assert nbytes == len(host)
+    assert bytes(t[:nbytes].cpu().numpy()) == host
+
+
+@pytest.mark.parametrize("profile,n,cfgd", [
+    ("c2", 20000, {}),
+    ("c3", 3000, {}),
+    ("c4", 3000, {"keepId": True, "keepInfo": True}),
+])
+def test_parity_on_bench_shapes(mods, profile, n, cfgd):
+    bg, bv = mods
+    cfg = bg.make_cfg(profile)
+    vcf = bg.header(cfg) + bg.rows_host(cfg, 5_000_000, n)
+    rc_o, out_o, log_o, n_o = orc.run(vcf, cfgd, n_threads=8)
+    rc_g, out_g, log_g, n_g = bv.run_buffer(vcf, cfgd, max_batch_bytes=8 << 20)
+    assert rc_o == 0 and rc_g == 0 and n_o == n_g == n
+    assert out_g == out_o
+    assert log_g == log_o
+    if profile == "c4":
+        assert log_g.count("\n") > 0 and out_g.count(b"MULTIALLELIC") > 0 and out_g.count(b"\tDEL\t") > 0
+
+
+def test_full_size_properties_c3(mods):
+    """BASELINE-size batch (131 072 rows x 2 504 samples, 1.33 GB) through the device-resident entry:
+    size-independent properties instead of an oracle run: every row is a passing biallelic SNP,
+    an == 2*ns, ac == n_het + 2*n_hom, ac > 0, and two passes give identical counters."""
+    import torch
+    bg, bv = mods
+    cfg = bg.make_cfg("c3")
+    rows = 131072
+    t, nbytes = bg.rows_device(cfg, 777_000_000, rows, pad=bv.DEVICE_PAD)
+    stride = ((cfg.n_samples + 3) // 4 + 15) & ~15
+    ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=1, max_lines=rows + 16,
+                 max_alleles=rows + 1024, cmap_bytes=(rows + 1024) * stride)
+    ctx.submit_device(t.data_ptr(), nbytes)
+    b = ctx.collect()
+    assert len(b.lines) == rows and (b.lines["status"] == bv.LINE_OK).all()
+    assert (b.lines["n_rec"] == 1).all() and (b.lines["n_fields"] == bg.n_header_fields(cfg)).all()
+    al = b.alleles[:rows]
+    assert (al["an"] == 2 * cfg.n_samples).all() and (al["n_miss"] == 0).all()
+    assert (al["ac"] == al["n_het"] + 2 * al["n_hom"]).all() and (al["ac"] > 0).all()
+    # class maps agree with the counters on a sample of rows
+    for i in np.linspace(0, rows - 1, 50).astype(int):
+        cls = b.classes(al[i])
+        assert (cls == 1).sum() == al["n_het"][i] and (cls == 2).sum() == al["n_hom"][i]
+    # spot-check rows against the oracle
+    host = bytes(t[:nbytes].cpu().numpy())
+    lines = host.split(b"\n")
+    hdr = bg.header(cfg)
+    pick = [0, 1, rows // 2, rows - 1]
+    rc, out, _, _ = orc.run(hdr + b"".join(lines[i] + b"\n" for i in pick))
+    orows = [r.split(b"\t") for r in out.split(b"\n") if r]
+    for i, r in zip(pick, orows):
+        assert int(r[12]) == al["ac"][i] and int(r[13]) == al["an"][i]
+    ctx.submit_device(t.data_ptr(), nbytes)
+    b2 = ctx.collect()
+    assert (b2.alleles[:rows]["ac"] == al["ac"]).all()
+    ctx.close()
