@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=4, help="distinct resident batches per GPU")
     ap.add_argument("--profile", default="c3", choices=["c2", "c3", "c4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
+    ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
     args = ap.parse_args()
 
     import torch
@@ -81,7 +83,7 @@ def main():
     import benchgen as bg
     import bystro_vcf_amd as bv
 
-    cfg = bg.make_cfg(args.profile)
+    cfg = bg.make_cfg(args.profile, align16=int(args.align16))
     ns = cfg.n_samples
     # ---- synthetic batches, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)
     blocks, sizes = [], []
@@ -94,7 +96,8 @@ def main():
     stride = ((ns + 3) // 4 + 15) & ~15
     n_alt_cap = args.rows * (4 if args.profile == "c4" else 1) + 1024
     ctx = bv.Ctx(bg.n_header_fields(cfg), device=local_rank, max_batch_bytes=max_bytes, n_slots=1,
-                 max_lines=args.rows + 16, max_alleles=n_alt_cap, cmap_bytes=n_alt_cap * stride + 4096)
+                 max_lines=args.rows + 16, max_alleles=n_alt_cap, cmap_bytes=n_alt_cap * stride + 4096,
+                 want_class_maps=not args.no_class_maps)
     ptrs = [t.data_ptr() for t in blocks]
 
     def barrier():

@@ -53,6 +53,7 @@ def make_cfg(profile="c3", seed=SEED, **over):
     c.n_samples = p["n_samples"]
     c.p_multi, c.p_indel, c.p_bad = p["p_multi"], p["p_indel"], p["p_bad"]
     c.pos0 = 10177
+    c.reserved = int(p.get("align16", 0))
     return c
 
 

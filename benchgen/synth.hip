@@ -178,6 +178,10 @@ HD uint32_t fixed_part(const SynthCfg &c, uint64_t r, uint8_t *buf, RowParams *r
   n = put_str(buf, n, ";AA=.|||");
   n = put_str(buf, n, ";VT=");
   n = put_str(buf, n, vt);
+  if (c.reserved & 1u) {  // experiment knob: pad INFO so every sample region starts 16-byte aligned
+    n = put_str(buf, n, ";P=");
+    while ((n + (ns ? 4u : 1u)) % 16u) buf[n++] = 'X';
+  }
   if (ns) n = put_str(buf, n, "\tGT");
   return n;
 }

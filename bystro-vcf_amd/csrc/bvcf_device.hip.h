@@ -592,71 +592,123 @@ __device__ inline void classify_field(const uint8_t *buf, uint32_t p, uint32_t c
   if (alt_count != 0) *cls = alt_count == gt_count ? BVCF_CLS_HOM : BVCF_CLS_HET;
 }
 
-// fast-path test and classification of one dword == one "x|y<TAB>" sample field.
-// returns cls (0..3) in bits 0-1 and sets bit 31 if the dword is not a regular field.
-__device__ __forceinline__ uint32_t fast_field(uint32_t w, uint32_t a_char) {
-  const uint32_t b0 = w & 0xFFu, b2 = (w >> 16) & 0xFFu;
-  const uint32_t frame = w & 0xFF00FF00u;
-  const bool ok_frame = frame == 0x09007C00u || frame == 0x09002F00u;  // '|' or '/', then TAB
-  const bool d0 = b0 == '.', d2 = b2 == '.';
-  const bool ok0 = (b0 - '0') <= 9u || d0;
-  const bool ok2 = (b2 - '0') <= 9u || d2;
-  const uint32_t altc = (uint32_t)(b0 == a_char) + (uint32_t)(b2 == a_char);
-  const uint32_t cls = (d0 || d2) ? 3u : altc;
-  return cls | ((ok_frame && ok0 && ok2) ? 0u : 0x80000000u);
+// ---- regular sample region: exactly 4 bytes per sample, "x<sep>y<TAB>" ----
+//
+// Every dword a lane loads is one sample field.  With t = w ^ "0<sep>0<TAB>":
+//   t == 0                      the field is the reference genotype (the common case)
+//   t & 0xFFE0FFE0 != 0         separator / TAB bytes differ, or an allele byte is outside
+//                               '0'^[0,31]: not a regular field
+//   v = allele byte ^ '0'       0..9 for digits, 0x1E for '.'; valid iff bit v of 0x400003FF
+// Classes come from a 16-entry x 2-bit table indexed by v & 15 (digit d -> 1 iff d == allele,
+// 14 ('.') -> 3): cls = min(code(b0) + code(b2), 3) gives none/het/hom/missing (main.go:1063-1124).
+constexpr int kFastGroup = 5;  // chunks per buffer; two buffers => 10 KiB in flight per wave
+
+__device__ __forceinline__ uint32_t fast_codes(uint32_t t, uint32_t table) {
+  const uint32_t s0 = (t << 1) & 0x1Eu;
+  const uint32_t s2 = (t >> 15) & 0x1Eu;
+  const uint32_t k = ((table >> s0) & 3u) + ((table >> s2) & 3u);
+  return k < 3u ? k : 3u;
 }
 
-// Regular sample region: exactly 4 bytes per sample.  Returns false (stats untouched) if any
-// field is irregular.  cmap may be nullptr.
-__device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint32_t ns, uint32_t allele, uint8_t *cmap,
-                                    GtStats *st) {
+struct FastAcc {
+  uint32_t bad, ok, het, hom, miss;
+};
+
+constexpr uint32_t kStageChunks = 64;                 // class-map bytes staged in LDS per wave:
+constexpr uint32_t kStageBytes = kStageChunks * 64u;  // 64 chunks x 64 B = 4 KiB = 16 384 samples
+
+// write staged class-map bytes [0, n) of the window starting at chunk c_base to the task's map
+__device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *cmap, uint32_t c_base, uint32_t n,
+                                            uint32_t stride) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t g0 = c_base * 64u;
+  if (g0 >= stride) return;
+  n = min(n, stride - g0);  // the slot is `stride` bytes (a multiple of 16)
+  for (uint32_t i = 16u * lane_id(); i < n; i += 16u * kWave)
+    *reinterpret_cast<u32x4 *>(cmap + g0 + i) = *reinterpret_cast<const u32x4 *>(stage + i);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one 1 KiB chunk (this lane's 4 fields) of a regular region; class bytes go to the LDS stage
+__device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunks, uint32_t ns, uint32_t kref,
+                                           uint32_t table, uint8_t *cmap, uint8_t *stage, uint32_t stride,
+                                           FastAcc &acc) {
   const int lane = lane_id();
-  // alleles >= 10 never match a one-character GT allele: compare against an impossible byte
-  const uint32_t a_char = allele <= 9 ? ('0' + allele) : 0x100u;
-  const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;
-  uint32_t bad = 0;
-  uint32_t acc = 0;  // packed byte counters: [none, het, hom, miss]
-  uint32_t het = 0, hom = 0, miss = 0;
-  u32x4 v = load16(a.buf, s_begin + 16u * lane, a.cap);
-  for (uint32_t c = 0; c < n_chunks; c++) {
-    u32x4 nxt = {0u, 0u, 0u, 0u};
-    if (c + 1 < n_chunks) nxt = load16(a.buf, s_begin + (c + 1) * kChunk + 16u * lane, a.cap);
-    const uint32_t f0 = c * 256u + 4u * lane;  // sample index of v.x
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    if (c + 1 == n_chunks) {
-      // tail: slots past the last sample become "0|0\t"; the last sample's terminator byte
-      // (eol or '\r') stands in for its TAB
+  const uint32_t f0 = c * 256u + 4u * lane;  // sample index of the lane's first dword
+  uint32_t t[4] = {v.x ^ kref, v.y ^ kref, v.z ^ kref, v.w ^ kref};
+  if (c + 1 == n_chunks) {
+    // tail: slots past the last sample count as reference; the last sample's terminator byte
+    // (eol or '\r') stands in for its TAB
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (f0 + j >= ns) w[j] = 0x09307C30u;
-        if (f0 + j == ns - 1) w[j] = (w[j] & 0x00FFFFFFu) | 0x09000000u;
-      }
+    for (int q = 0; q < 4; q++) {
+      if (f0 + q >= ns) t[q] = 0;
+      if (f0 + q == ns - 1) t[q] &= 0x00FFFFFFu;
     }
-    uint32_t byte = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      uint32_t r = fast_field(w[j], a_char);
-      bad |= r;
-      uint32_t cls = r & 3u;
-      byte |= cls << (2 * j);
-      acc += 1u << (8 * cls);
-    }
-    if (cmap && f0 < ns) cmap[c * 64u + lane] = (uint8_t)byte;
-    if ((c & 31u) == 31u) {  // byte counters hold <= 128 before spilling
-      het += (acc >> 8) & 0xFFu;
-      hom += (acc >> 16) & 0xFFu;
-      miss += acc >> 24;
-      acc = 0;
-    }
-    v = nxt;
   }
-  het += (acc >> 8) & 0xFFu;
-  hom += (acc >> 16) & 0xFFu;
-  miss += acc >> 24;
-  if (__any((int)(bad >> 31))) return false;
-  st->n_het = wave_sum(het);
-  st->n_hom = wave_sum(hom);
-  st->n_miss = wave_sum(miss);
+  uint32_t byte = 0;
+  if (__any((t[0] | t[1] | t[2] | t[3]) != 0)) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      acc.bad |= t[q] & 0xFFE0FFE0u;
+      acc.ok &= (0x400003FFu >> (t[q] & 31u)) & (0x400003FFu >> ((t[q] >> 16) & 31u));
+      byte |= fast_codes(t[q], table) << (2 * q);
+    }
+    const uint32_t lo = byte & 0x55u, hi = (byte >> 1) & 0x55u;
+    acc.het += __popc(lo & ~hi);
+    acc.hom += __popc(hi & ~lo);
+    acc.miss += __popc(lo & hi);
+  }
+  if (cmap) {
+    stage[(c % kStageChunks) * 64u + lane] = (uint8_t)byte;
+    if ((c % kStageChunks) == kStageChunks - 1u || c + 1 == n_chunks)
+      flush_stage(stage, cmap, c - (c % kStageChunks), ((c % kStageChunks) + 1u) * 64u, stride);
+  }
+}
+
+// Returns false (outputs meaningless) if any field is irregular.  cmap may be nullptr.
+__device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint32_t ns, uint32_t allele, uint8_t *cmap,
+                                    uint8_t *stage, GtStats *st) {
+  const int lane = lane_id();
+  const uint32_t table = (allele <= 9 ? (1u << (2u * allele)) : 0u) | (3u << 28);
+  const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;
+  const uint32_t last_off = a.cap - 16u;
+  const uint8_t *base = a.buf;
+  auto fetch = [&](uint32_t c) -> u32x4 {
+    const uint32_t off = min(s_begin + c * kChunk + 16u * lane, last_off);
+    return *reinterpret_cast<const u32x4_u *>(base + off);
+  };
+  FastAcc acc = {0, 1, 0, 0, 0};
+  u32x4 va[kFastGroup], vb[kFastGroup];
+#pragma unroll
+  for (int g = 0; g < kFastGroup; g++)
+    if ((uint32_t)g < n_chunks) va[g] = fetch(g);
+#pragma unroll
+  for (int g = 0; g < kFastGroup; g++)
+    if ((uint32_t)(kFastGroup + g) < n_chunks) vb[g] = fetch(kFastGroup + g);
+  // the separator of the first field is the line's separator; mixed lines fail the frame test
+  const uint32_t sep = (__builtin_amdgcn_readfirstlane(va[0].x) >> 8) & 0xFFu;
+  if (sep != '|' && sep != '/') return false;
+  const uint32_t kref = 0x09300030u | (sep << 8);
+
+  for (uint32_t c0 = 0; c0 < n_chunks; c0 += 2 * kFastGroup) {
+#pragma unroll
+    for (int g = 0; g < kFastGroup; g++)
+      if (c0 + g < n_chunks) fast_chunk(va[g], c0 + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, acc);
+#pragma unroll
+    for (int g = 0; g < kFastGroup; g++)
+      if (c0 + 2 * kFastGroup + g < n_chunks) va[g] = fetch(c0 + 2 * kFastGroup + g);
+#pragma unroll
+    for (int g = 0; g < kFastGroup; g++)
+      if (c0 + kFastGroup + g < n_chunks) fast_chunk(vb[g], c0 + kFastGroup + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, acc);
+#pragma unroll
+    for (int g = 0; g < kFastGroup; g++)
+      if (c0 + 3 * kFastGroup + g < n_chunks) vb[g] = fetch(c0 + 3 * kFastGroup + g);
+  }
+  if (__any(acc.bad != 0 || !(acc.ok & 1u))) return false;
+  st->n_het = wave_sum(acc.het);
+  st->n_hom = wave_sum(acc.hom);
+  st->n_miss = wave_sum(acc.miss);
   st->ac = st->n_het + 2u * st->n_hom;
   st->an = 2u * (ns - st->n_miss);
   return true;
@@ -725,18 +777,24 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
 // ------------------------------------------------------------------ k_gt: one wave per task
 
 __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
+  uint8_t *stage = s_stage[threadIdx.x >> 6];
   const int lane = lane_id();
   const uint32_t n_tasks = min(min(a.counters->n_lines, a.max_lines) + a.counters->n_tasks, a.max_tasks);
   const uint32_t stride = gridDim.x * kWavesPerWg;
   const uint32_t ns = a.n_samples;
-  for (uint32_t ti = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); ti < n_tasks; ti += stride) {
-    const GtTask t = a.tasks[ti];
+  uint32_t ti = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  GtTask nxt = GtTask{};
+  if (ti < n_tasks) nxt = a.tasks[ti];
+  for (; ti < n_tasks; ti += stride) {
+    const GtTask t = nxt;
+    if (ti + stride < n_tasks) nxt = a.tasks[ti + stride];  // in flight while this task is scanned
     if (t.allele == 0) continue;  // line rejected before getAlleles: nothing to scan
     uint8_t *cm = t.cmap_off != BVCF_NO_CMAP ? a.cmap + t.cmap_off : nullptr;
     GtStats st = {0, 0, 0, 0, 0};
     uint32_t n_fields;
     // regular region: 4 bytes per sample, every dword of a lane is one "x|y<TAB>" field
-    if (t.cend + 1u - t.s_begin == 4u * ns && gt_scan_fast(a, t.s_begin, ns, t.allele, cm, &st)) {
+    if (t.cend + 1u - t.s_begin == 4u * ns && gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, &st)) {
       n_fields = ns;
     } else {
       uint32_t tabs;
