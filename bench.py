@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(profile, rows_total=100_000, chunk=25_000):
+def cpu_baseline(profile, rows_total=400_000, chunk=25_000):
     """the oracle (oracle/bvcf_oracle.c), all host cores, on a bounded sample of the same rows"""
     import benchgen as bg
     import oracle_lib as orc
@@ -52,6 +52,24 @@ def cpu_baseline(profile, rows_total=100_000, chunk=25_000):
         "sample": "%d rows of the same synthetic %s stream (%d-row chunks), oracle/bvcf_oracle.c with %d worker "
                   "threads over 64-line batches, output discarded; %.1f s wall" % (rows, profile, chunk, cores, elapsed),
     }
+
+
+def rank_blocks(rank, n_blocks, rows):
+    """first row of each resident batch of `rank`: rank r owns rows [r*B*R, (r+1)*B*R) — disjoint
+    shards, no data-path collective (records are independent, main.go:534-698)"""
+    return [(rank * n_blocks + b) * rows for b in range(n_blocks)]
+
+
+def reduce_over_ranks(elapsed, n_variants, device, world):
+    """slowest rank's time and the job's total variant count (the only collective: RCCL on GPUs)"""
+    import torch
+    import torch.distributed as dist
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    n_var = torch.tensor([float(n_variants)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n_var, op=dist.ReduceOp.SUM)
+    return float(t_el.item()), float(n_var.item())
 
 
 def main():
@@ -87,8 +105,7 @@ def main():
     ns = cfg.n_samples
     # ---- synthetic batches, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)
     blocks, sizes = [], []
-    for b in range(args.blocks):
-        first = (rank * args.blocks + b) * args.rows
+    for first in rank_blocks(rank, args.blocks, args.rows):
         t, nbytes = bg.rows_device(cfg, first, args.rows, pad=bv.DEVICE_PAD)
         blocks.append(t)
         sizes.append(nbytes)
@@ -117,13 +134,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     assert counts[0] == args.rows, counts
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    n_var = torch.tensor([float(args.rows * args.steps)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)   # slowest rank
-        dist.all_reduce(n_var, op=dist.ReduceOp.SUM)  # the final count gather over RCCL/xGMI
-    elapsed = float(t_el.item())
-    total_variants = float(n_var.item())
+    # the final count gather over RCCL/xGMI (and the slowest rank's clock)
+    elapsed, total_variants = reduce_over_ranks(elapsed, args.rows * args.steps, "cuda", world)
 
     if rank == 0:
         mean_bytes = sum(sizes[i % args.blocks] for i in range(args.steps)) / args.steps
