@@ -269,8 +269,20 @@ struct Span {
   uint32_t off, len;
 };
 
+// Byte access for the leader lane's serial work: the first windows of the line are staged in LDS
+// (k_head), everything else falls through to HBM.
+struct Bytes {
+  const uint8_t *g;          // the block
+  const uint8_t *lds;        // copy of block bytes [lo, lo + n)
+  uint32_t lo, n;
+  __device__ __forceinline__ uint8_t operator[](uint32_t off) const {
+    const uint32_t d = off - lo;
+    return d < n ? lds[d] : g[off];
+  }
+};
+
 // strconv.Atoi on buf[s.off .. +len): optional sign, digits, must fit int64 (main.go:752,824)
-__device__ inline bool go_atoi(const uint8_t *buf, Span s, long long *out) {
+__device__ inline bool go_atoi(const Bytes &buf, Span s, long long *out) {
   if (s.len == 0) return false;
   uint32_t i = 0;
   bool neg = false;
@@ -310,7 +322,7 @@ struct GtStats {
 
 // lane-0 state of one line's getAlleles evaluation
 struct AlleleCtx {
-  const uint8_t *buf;
+  Bytes buf;
   Span chrom, pos, ref, alt;
   long long int_pos;   // intPos, main.go:767
   bool pos_bad;        // Atoi failed: the ALT loop is over (main.go:826-829)
@@ -332,7 +344,7 @@ struct AlleleEval {
 
 // The single-ALT-byte path, main.go:735-765.  t is the whole ALT field (1 byte).
 __device__ inline void eval_single(AlleleCtx &c, AlleleEval &e) {
-  const uint8_t *b = c.buf;
+  const Bytes &b = c.buf;
   e = AlleleEval{};
   const uint8_t a0 = b[c.alt.off];
   if (a0 != 'A' && a0 != 'C' && a0 != 'G' && a0 != 'T') {
@@ -370,7 +382,7 @@ __device__ inline void eval_single(AlleleCtx &c, AlleleEval &e) {
 
 // One token of strings.Split(alt, ","), main.go:774-999.  t = token span.
 __device__ inline void eval_token(AlleleCtx &c, Span t, AlleleEval &e) {
-  const uint8_t *b = c.buf;
+  const Bytes &b = c.buf;
   e = AlleleEval{};
   // altIsValid, main.go:456-474 (empty token: Go would panic; invalid here)
   bool valid = t.len > 0;
@@ -820,6 +832,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
 constexpr int kGroup = 16;                       // lanes per line in k_head
 constexpr int kGroupsPerWg = kWgThreads / kGroup;
 constexpr uint32_t kWindow = kGroup * 16;        // bytes per group step
+constexpr uint32_t kHeadStage = 192;             // line-head bytes kept in LDS for the serial phase
 
 __device__ __forceinline__ int glane() { return threadIdx.x & (kGroup - 1); }
 
@@ -843,7 +856,7 @@ __device__ __forceinline__ uint32_t group_sum(uint32_t v) {
 
 __device__ __forceinline__ uint32_t gbcast0(uint32_t v) { return __shfl(v, 0, kGroup); }
 
-__device__ inline bool filter_in(const uint8_t *buf, Span f, const uint16_t *off, const uint16_t *len, uint32_t n,
+__device__ inline bool filter_in(const Bytes &buf, Span f, const uint16_t *off, const uint16_t *len, uint32_t n,
                                  const uint8_t *text) {
 #pragma nounroll
   for (uint32_t i = 0; i < n; i++) {
@@ -905,89 +918,147 @@ __device__ inline uint32_t put_task(const KernelArgs &a, uint32_t ti, uint32_t l
   return cm;
 }
 
+// k_head handles 256 lines per workgroup step in two phases:
+//   T  tokenise: 16 lanes per line find the TABs of the fixed columns (per-lane masks, 16-lane
+//      prefix sum) and stage the first kHeadStage bytes of the line in LDS; 16 rounds x 16 lines
+//   S  serial:   ONE LANE PER LINE runs the gate + getAlleles on the staged bytes, so a wave
+//      instruction serves 64 lines (with 16 lanes per line it served 4 and the kernel was
+//      issue-bound on this code)
+constexpr uint32_t kLinesPerStep = kWgThreads;
+constexpr uint32_t kHeadRow = kHeadStage / 4 + 1;  // dwords per staged line; odd => conflict-free columns
+constexpr uint32_t kTabRow = 11;                   // 9 TAB offsets + pad, odd stride
+
 __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
-  __shared__ uint32_t s_tab[kGroupsPerWg][12];
+  __shared__ uint32_t s_head[kLinesPerStep * kHeadRow];
+  __shared__ uint32_t s_tab[kLinesPerStep * kTabRow];
+  __shared__ uint32_t s_ls[kLinesPerStep], s_len[kLinesPerStep], s_found[kLinesPerStep], s_staged[kLinesPerStep],
+      s_extra[kLinesPerStep];
+  __shared__ uint32_t s_wave[kWavesPerWg][2];
+  __shared__ uint32_t s_base[2];
+  __shared__ FilterTable s_ft;  // FILTER sets
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.filters);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ft);
+    for (uint32_t i = threadIdx.x; i < sizeof(FilterTable) / 4; i += kWgThreads) dst[i] = src[i];
+  }
   const int gl = glane();
   const int g = threadIdx.x / kGroup;
-  volatile uint32_t *tab = s_tab[g];
+  const int lane = lane_id();
+  const int w = threadIdx.x >> 6;
   const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
-  const uint32_t stride = gridDim.x * kGroupsPerWg;
+  const uint32_t stride = gridDim.x * kLinesPerStep;
   const uint32_t need = min(9u, a.n_header - 1u);  // TABs that bound the fixed columns we read
   const uint32_t ns = a.n_samples;
   const bool maps = a.want_cmap && ns > 0;
 
-  for (uint32_t line = blockIdx.x * kGroupsPerWg + g; line < n_lines; line += stride) {
-    const uint32_t ls = a.line_off[line];
-    const uint32_t le = a.line_off[line + 1];
-    const uint32_t len = le - ls >= a.eol_chars ? le - ls - a.eol_chars : 0u;  // chomp, main.go:535
-    const uint32_t cend = ls + len;
+  for (uint32_t line0 = blockIdx.x * kLinesPerStep; line0 < n_lines; line0 += stride) {
+    __syncthreads();  // LDS of the previous step is free (also covers the s_ft copy)
 
-    // ---- tokenise the fixed columns: strings.Split(row, "\t"), main.go:535
-    uint32_t found = 0;
-    uint32_t base = ls;
-    for (; base < cend && found < need; base += kWindow) {
-      const uint32_t off = base + 16u * gl;
-      u32x4 v = load16(a.buf, off, a.cap);
-      uint32_t m = eq_mask16(v, '\t') & low_bits16((int)cend - (int)off);
-      uint32_t tot;
-      uint32_t r = found + group_excl_scan(__popc(m), &tot);
-      while (m && r < need) {
-        tab[r] = off + __ffs(m) - 1;
-        m &= m - 1;
-        r++;
+    // ================= phase T: 16 lanes per line =================
+    for (uint32_t r = 0; r < kLinesPerStep / kGroupsPerWg; r++) {
+      const uint32_t ll = r * kGroupsPerWg + g;
+      const uint32_t line = line0 + ll;
+      if (line >= n_lines) continue;
+      const uint32_t ls = a.line_off[line];
+      const uint32_t le = a.line_off[line + 1];
+      const uint32_t len = le - ls >= a.eol_chars ? le - ls - a.eol_chars : 0u;  // chomp, main.go:535
+      const uint32_t cend = ls + len;
+      uint32_t found = 0, base = ls;
+      // strings.Split(row, "\t") for the fixed columns, main.go:535
+      for (; base < cend && found < need; base += kWindow) {
+        const uint32_t off = base + 16u * gl;
+        u32x4 v = load16(a.buf, off, a.cap);
+        const uint32_t rel = off - ls;
+        if (rel < kHeadStage) {
+          uint32_t *row = &s_head[ll * kHeadRow + rel / 4];
+          row[0] = v.x;
+          row[1] = v.y;
+          row[2] = v.z;
+          row[3] = v.w;
+        }
+        uint32_t m = eq_mask16(v, '\t') & low_bits16((int)cend - (int)off);
+        uint32_t tot;
+        uint32_t rk = found + group_excl_scan(__popc(m), &tot);
+        while (m && rk < need) {
+          s_tab[ll * kTabRow + rk] = off + __ffs(m) - 1;
+          m &= m - 1;
+          rk++;
+        }
+        found += tot;
       }
-      found += tot;
+      const uint32_t staged = min(base - ls, kHeadStage);
+      uint32_t extra = 0;
+      if (ns == 0 && found >= need) {
+        // no samples: every TAB after the last fixed column is an extra field; `found` already
+        // counts the TABs of the windows read so far
+        for (; base < cend; base += kWindow) {
+          const uint32_t off = base + 16u * gl;
+          u32x4 v = load16(a.buf, off, a.cap);
+          extra += __popc(eq_mask16(v, '\t') & low_bits16((int)cend - (int)off));
+        }
+        extra = group_sum(extra);
+      }
+      if (gl == 0) {
+        s_ls[ll] = ls;
+        s_len[ll] = len;
+        s_found[ll] = found;
+        s_staged[ll] = staged;
+        s_extra[ll] = extra;
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
+
+    // ================= phase S: one lane per line =================
+    const uint32_t ll = threadIdx.x;
+    const uint32_t line = line0 + ll;
+    const bool active = line < n_lines;
+    const uint32_t ls = active ? s_ls[ll] : 0u, len = active ? s_len[ll] : 0u, found = active ? s_found[ll] : 0u;
+    const uint32_t cend = ls + len;
+    const uint32_t *tab = &s_tab[ll * kTabRow];
+    Bytes hb;
+    hb.g = a.buf;
+    hb.lds = reinterpret_cast<const uint8_t *>(&s_head[ll * kHeadRow]);
+    hb.lo = ls;
+    hb.n = active ? s_staged[ll] : 0u;
 
     uint32_t status = BVCF_LINE_OK;
     uint32_t n_fields = 0;
-    if (found < need) {
+    if (active && found < need) {
       status = BVCF_LINE_FIELDS;
       n_fields = found + 1;
-    } else if (ns == 0) {
-      // no samples: every TAB after the last fixed column is an extra field.  `found` already
-      // counts the TABs of the windows read so far; count the rest of the line.
-      uint32_t extra = 0;
-      for (; base < cend; base += kWindow) {
-        const uint32_t off = base + 16u * gl;
-        u32x4 v = load16(a.buf, off, a.cap);
-        extra += __popc(eq_mask16(v, '\t') & low_bits16((int)cend - (int)off));
-      }
-      n_fields = found + group_sum(extra) + 1;
+    } else if (active && ns == 0) {
+      n_fields = found + s_extra[ll] + 1;
       if (n_fields != a.n_header) status = BVCF_LINE_FIELDS;
     }
 
     // field i = [fstart(i), tab[i]) ; fields beyond the line: empty at cend
     auto fspan = [&](uint32_t i) -> Span {
-      Span s;
-      s.off = i == 0 ? ls : tab[i - 1] + 1;
+      Span sp;
+      sp.off = i == 0 ? ls : tab[i - 1] + 1;
       const uint32_t e = i < need ? tab[i] : cend;
-      s.len = e - s.off;
-      return s;
+      sp.len = e - sp.off;
+      return sp;
     };
 
     uint32_t rec_first = 0, n_rec = 0, site_type = 0;
     bool task_written = false, primary_written = false;
 
-    // ---- everything below is the group leader's serial work
-    if (gl == 0 && status == BVCF_LINE_OK) {
+    // ---- part 1: gate and what the line will need
+    AlleleCtx c;
+    uint32_t mode = 0, n_commas = 0, bound = 0, s_begin = cend;
+    if (active && status == BVCF_LINE_OK && a.n_header > 6) {
       // FILTER gate, main.go:447-454
-      if (a.n_header > 6) {
-        const FilterTable *ft = a.filters;
-        Span f = fspan(6);
-        if (!ft->allow_nil && !filter_in(a.buf, f, ft->allow_off, ft->allow_len, ft->allow_n, ft->text))
-          status = BVCF_LINE_FILTER;
-        else if (!ft->deny_nil && filter_in(a.buf, f, ft->deny_off, ft->deny_len, ft->deny_n, ft->text))
-          status = BVCF_LINE_FILTER;
-      }
+      const FilterTable *ft = &s_ft;
+      Span f = fspan(6);
+      if (!ft->allow_nil && !filter_in(hb, f, ft->allow_off, ft->allow_len, ft->allow_n, ft->text))
+        status = BVCF_LINE_FILTER;
+      else if (!ft->deny_nil && filter_in(hb, f, ft->deny_off, ft->deny_len, ft->deny_n, ft->text))
+        status = BVCF_LINE_FILTER;
     }
-    if (gl == 0 && status == BVCF_LINE_OK) {
-      // getAlleles, main.go:723-1038
-      AlleleCtx c;
-      c.buf = a.buf;
+    const bool eval = active && status == BVCF_LINE_OK;
+    if (eval) {
+      // getAlleles set-up, main.go:723-735
+      c.buf = hb;
       c.chrom = fspan(0);
       c.pos = fspan(1);
       c.ref = fspan(3);
@@ -995,41 +1066,61 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       c.int_pos = 0;
       c.pos_bad = false;
       c.line = line;
-      const uint32_t s_begin = need == 9 ? tab[8] + 1 : cend;
-
+      s_begin = need == 9 ? tab[8] + 1 : cend;
       // mode 0: REF == ALT; 1: single-byte ALT path; 2: ALT token loop; 3: empty REF (Go panics)
-      uint32_t n_commas = 0;
+      // bound: a token yields one record, or one per differing base when it is as long as a
+      // multi-base REF (main.go:855-873)
       bool same = c.alt.len == c.ref.len;
+      uint32_t tl = 0, b2 = 0;
 #pragma nounroll
-      for (uint32_t i = 0; i < c.alt.len; i++) {
-        const uint8_t ch = a.buf[c.alt.off + i];
-        n_commas += ch == ',';
-        if (same) same = ch == a.buf[c.ref.off + i];
-      }
-      const uint32_t mode = same ? 0u : (c.alt.len == 1 ? 1u : (c.ref.len == 0 ? 3u : 2u));
-      if (mode == 0) log_err(a, line, 0, BVCF_ERR_SAME);
-      if (mode == 3) log_err(a, line, 0, BVCF_ERR_EMPTY_REF);
-
-      // Record slots are deterministic for the first record (index == line) and reserved by upper
-      // bound for the rest: a token yields one record, or one per differing base when it is as
-      // long as a multi-base REF (main.go:855-873).  Biallelic lines therefore need no atomics.
-      uint32_t bound = 0;
-      if (mode == 1) bound = 1;
-      if (mode == 2) {
-        uint32_t tl = 0;
-#pragma nounroll
-        for (uint32_t i = 0; i <= c.alt.len; i++) {
-          if (i == c.alt.len || a.buf[c.alt.off + i] == ',') {
-            bound += (tl == c.ref.len && c.ref.len > 1) ? c.ref.len : 1u;
-            tl = 0;
-          } else {
-            tl++;
-          }
+      for (uint32_t i = 0; i <= c.alt.len; i++) {
+        const uint8_t ch = i < c.alt.len ? hb[c.alt.off + i] : (uint8_t)',';
+        if (i < c.alt.len && same) same = ch == hb[c.ref.off + i];
+        if (ch == ',') {
+          n_commas += i < c.alt.len;
+          b2 += (tl == c.ref.len && c.ref.len > 1) ? c.ref.len : 1u;
+          tl = 0;
+        } else {
+          tl++;
         }
       }
-      uint32_t extra_base = 0;
-      if (bound > 1) extra_base = n_lines + atomicAdd(&a.counters->n_alleles, bound - 1);
-      const bool fits = bound <= 1 || (unsigned long long)extra_base + (bound - 1) <= a.max_alleles;
+      mode = same ? 0u : (c.alt.len == 1 ? 1u : (c.ref.len == 0 ? 3u : 2u));
+      bound = mode == 1 ? 1u : (mode == 2 ? b2 : 0u);
+    }
+
+    // ---- slot reservation, once per workgroup step: record slot `line` and task slot `line` are
+    // the line's own; only further records / ALT indices draw from the batch counters.  Biallelic
+    // lines — all of a 1KG-shaped file — never touch an atomic.
+    const uint32_t want_rec = bound > 1 ? bound - 1 : 0u;
+    const uint32_t want_task = (eval && ns > 0 && mode == 2) ? n_commas : 0u;
+    uint32_t wt_rec, wt_task;
+    uint32_t extra_base = wave_excl_scan(want_rec, &wt_rec);
+    uint32_t task_base = wave_excl_scan(want_task, &wt_task);
+    if (lane == 0) {
+      s_wave[w][0] = wt_rec;
+      s_wave[w][1] = wt_task;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      uint32_t sum = 0;
+      for (int k = 0; k < kWavesPerWg; k++) sum += s_wave[k][threadIdx.x];
+      uint32_t got = 0;
+      if (sum) got = atomicAdd(threadIdx.x == 0 ? &a.counters->n_alleles : &a.counters->n_tasks, sum);
+      s_base[threadIdx.x] = got;
+    }
+    __syncthreads();
+    extra_base += n_lines + s_base[0];
+    task_base += n_lines + s_base[1];
+    for (int k = 0; k < w; k++) {
+      extra_base += s_wave[k][0];
+      task_base += s_wave[k][1];
+    }
+
+    // ---- part 2: evaluate the ALT tokens, write records and scan tasks
+    if (eval) {
+      if (mode == 0) log_err(a, line, 0, BVCF_ERR_SAME);
+      if (mode == 3) log_err(a, line, 0, BVCF_ERR_EMPTY_REF);
+      const bool fits = (unsigned long long)extra_base + want_rec <= a.max_alleles;
       // slot of this line's j-th record
       auto slot = [&](uint32_t j) -> uint32_t { return j == 0 ? line : extra_base + j - 1; };
 
@@ -1040,7 +1131,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
         task_written = true;
       }
 
-      uint32_t cur = 0, emitted = 0;
+      uint32_t cur = 0, emitted = 0, tasks_used = 0;
       if (mode == 1 || mode == 2) {
 #pragma nounroll
         for (uint32_t k = 0;; k++) {
@@ -1059,7 +1150,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
           if (!e.n) continue;
           uint32_t task = line, cm_off = cm0;
           if (ns > 0 && k > 0) {
-            task = n_lines + atomicAdd(&a.counters->n_tasks, 1u);
+            task = task_base + tasks_used++;
             cm_off = put_task(a, task, line, k + 1, s_begin, cend, maps);
           }
           if (ns == 0) task = kNoTask;
@@ -1079,7 +1170,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
               uint32_t j = 0;
 #pragma nounroll
               for (uint32_t i = 0; i < c.ref.len; i++) {
-                const uint8_t rb = a.buf[c.ref.off + i], ab = a.buf[t.off + i];
+                const uint8_t rb = hb[c.ref.off + i], ab = hb[t.off + i];
                 if (rb == ab) continue;
                 write_allele(a, slot(emitted + j), line, k, e, c.int_pos + (long long)i, rb, ab, stype, task, cm_off);
                 j++;
@@ -1091,10 +1182,12 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
           emitted += e.n;
         }
       }
-      // reserved but unused slots must not look like records to k_finish
+      // reserved but unused slots must not look like records / tasks to the later kernels
       if (fits)
 #pragma nounroll
         for (uint32_t j = emitted > 1 ? emitted : 1; j < bound; j++) a.alleles[slot(j)].gt_task = kNoTask;
+#pragma nounroll
+      for (uint32_t j = tasks_used; j < want_task; j++) put_task(a, task_base + j, line, 0, cend, cend, false);
       if (emitted) primary_written = true;
       if (fits) rec_first = extra_base;
       if (emitted == 0)
@@ -1106,7 +1199,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
     }
 
     // ---- line record
-    if (gl == 0) {
+    if (active) {
       bvcf_line L;
       L.off = ls;
       L.len = len;
@@ -1124,7 +1217,6 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       if (ns > 0 && !task_written) put_task(a, line, line, 0, cend, cend, false);
       if (!primary_written && line < a.max_alleles) a.alleles[line].gt_task = kNoTask;
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 

@@ -11,6 +11,11 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -332,7 +337,8 @@ int open_ctx(Run &R, std::string *msg) {
     R.name_ptr.push_back(R.pre.header[i].data());
     R.name_len.push_back((uint32_t)R.pre.header[i].size());
   }
-  R.n_threads = R.cfg->n_format_threads ? R.cfg->n_format_threads : std::max(1u, std::thread::hardware_concurrency());
+  R.n_threads = R.cfg->n_format_threads ? R.cfg->n_format_threads
+                                         : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   return BVCF_OK;
 }
 
@@ -362,6 +368,46 @@ int process_block(Run &R, const uint8_t *block, size_t n, uint64_t seq, bvcf_res
 }
 
 }  // namespace
+
+namespace {
+
+// a bounded FIFO between pipeline stages
+template <class T>
+class Channel {
+ public:
+  explicit Channel(size_t cap) : cap_(cap) {}
+  void push(T v) {
+    std::unique_lock<std::mutex> lk(mu_);
+    not_full_.wait(lk, [&] { return q_.size() < cap_; });
+    q_.push_back(std::move(v));
+    not_empty_.notify_one();
+  }
+  T pop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    not_empty_.wait(lk, [&] { return !q_.empty(); });
+    T v = std::move(q_.front());
+    q_.pop_front();
+    not_full_.notify_one();
+    return v;
+  }
+
+ private:
+  size_t cap_;
+  std::deque<T> q_;
+  std::mutex mu_;
+  std::condition_variable not_full_, not_empty_;
+};
+
+// one block of whole lines in a pinned buffer
+struct Block {
+  uint8_t *buf = nullptr;
+  size_t start = 0, nb = 0;  // lines live in buf[start, start + nb)
+  size_t fill = 0;           // bytes read into buf (preamble parsing needs this on the first block)
+  bool first = false, last = false, too_long = false, read_error = false;
+};
+
+}  // namespace
+
 
 extern "C" {
 
@@ -395,7 +441,8 @@ int bvcf_format_tsv(const bvcf_config *c, const bvcf_result *r, const uint8_t *b
   if (r->n_samples && (!sample_names || !sample_name_lens)) return BVCF_E_ARG;
   std::string o, l;
   Names nm{sample_names, sample_name_lens};
-  const unsigned nt = c->n_format_threads ? c->n_format_threads : std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nt =
+      c->n_format_threads ? c->n_format_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   format_batch(c, r, block, nm, nt, o, l);
   *out = dup_out(o, n_out);
   if (log && n_log) *log = dup_out(l, n_log);
@@ -467,123 +514,264 @@ static int write_all(int fd, const char *p, size_t n) {
   return 0;
 }
 
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// The reference's main() + readVcf (main.go:134-217, 241-396) as a four-stage pipeline:
+//   reader thread  fd -> pinned buffers, cut at the last terminator         (main.go:349-380)
+//   this thread    bvcf_submit one block ahead, bvcf_collect the oldest     (processLines' input side)
+//   format pool    TSV assembly of a collected batch                        (main.go:566-695)
+//   writer thread  ordered write to fd_out                                  (main.go:524-532,705-711)
 int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_t *n_lines_in) {
   if (!c) return BVCF_E_ARG;
+  const bool timing = getenv("BVCF_TIMING") != nullptr;
+  const double t_start = now_s();
+  double t_wait_read = 0, t_gpu = 0, t_fmt = 0, t_init = 0;
   std::string msg;
   Run R;
   R.cfg = c;
   R.max_batch = c->max_batch_bytes ? c->max_batch_bytes : (64ull << 20);
   uint64_t lines_in = 0;
-  auto fatal = [&](const std::string &m, int rc) {
-    std::string t = m + "\n";
-    write_all(fd_err, t.data(), t.size());
-    if (R.ctx) bvcf_destroy(R.ctx);
-    return rc;
-  };
 
   // fmt.Fprintln(writer, stringHeader(config)), main.go:199
   {
     char h[512];
     size_t hn = bvcf_string_header(c, h, sizeof h);
     h[hn] = '\n';
-    if (write_all(fd_out, h, hn + 1)) return fatal("write failed", BVCF_E_FATAL);
+    if (write_all(fd_out, h, hn + 1)) {
+      dprintf(fd_err, "write failed\n");
+      return BVCF_E_FATAL;
+    }
   }
 
-  // two pinned read buffers: the GPU works on one while the other fills (main.go:192, 349-380)
   const size_t cap = R.max_batch;
-  uint8_t *bufs[2] = {(uint8_t *)bvcf_alloc_pinned(cap), (uint8_t *)bvcf_alloc_pinned(cap)};
-  if (!bufs[0] || !bufs[1]) {
-    // no device => no pinned memory either; fail loudly, there is no CPU path
-    bvcf_free_pinned(bufs[0]);
-    bvcf_free_pinned(bufs[1]);
-    return fatal("cannot allocate pinned host memory (no usable HIP device?)", BVCF_E_NODEV);
-  }
-  int cur = 0;
-  size_t fill = 0;
-  bool eof = false, have_pre = false;
-  std::string out, log;
+  constexpr int kBufs = 4;
+  uint8_t *bufs[kBufs];
+  for (int i = 0; i < kBufs; i++) bufs[i] = (uint8_t *)bvcf_alloc_pinned(cap);
+  auto free_bufs = [&]() {
+    for (int i = 0; i < kBufs; i++) bvcf_free_pinned(bufs[i]);
+  };
+  for (int i = 0; i < kBufs; i++)
+    if (!bufs[i]) {
+      // no device => no pinned memory either; fail loudly, there is no CPU path
+      free_bufs();
+      dprintf(fd_err, "cannot allocate pinned host memory (no usable HIP device?)\n");
+      return BVCF_E_NODEV;
+    }
+
+  Channel<uint8_t *> free_q(64);
+  Channel<Block> ready_q(kBufs);
+  Channel<std::string *> write_q(4);
+  for (int i = 0; i < kBufs; i++) free_q.push(bufs[i]);
+  std::atomic<bool> stop{false};
+  std::atomic<uint8_t> eol_byte{'\n'};
+  std::atomic<bool> eol_known{false};
+
+  // ---- reader: whole lines per block; the partial last line is carried into the next buffer
+  std::thread reader([&]() {
+    std::vector<uint8_t> carry;
+    bool first = true, eof = false;
+    while (!eof && !stop.load()) {
+      Block b;
+      b.buf = free_q.pop();
+      if (!b.buf) break;
+      b.first = first;
+      size_t fill = carry.size();
+      if (fill) memcpy(b.buf, carry.data(), fill);
+      carry.clear();
+      while (!eof && fill < cap) {
+        ssize_t got = read(fd_in, b.buf + fill, cap - fill);
+        if (got < 0) {
+          if (errno == EINTR) continue;
+          b.read_error = true;
+          eof = true;
+          break;
+        }
+        if (got == 0) {
+          eof = true;
+          break;
+        }
+        fill += (size_t)got;
+      }
+      b.fill = fill;
+      b.last = eof;
+      if (first) {
+        // the terminator is learnt from line 1 (parse.FindEndOfLine, main.go:250)
+        uint8_t e = '\n';
+        for (size_t i = 0; i < fill; i++) {
+          if (b.buf[i] == '\n') break;
+          if (b.buf[i] == '\r') {
+            if (i + 1 < fill && b.buf[i + 1] != '\n') e = '\r';
+            break;
+          }
+        }
+        eol_byte.store(e);
+        eol_known.store(true);
+        first = false;
+      }
+      const uint8_t *lastp = fill ? (const uint8_t *)memrchr(b.buf, eol_byte.load(), fill) : nullptr;
+      if (!lastp) {
+        if (!eof && fill == cap) b.too_long = true;
+        b.nb = 0;  // at EOF an unterminated tail is dropped (main.go:354-358)
+      } else {
+        b.nb = (size_t)(lastp - b.buf) + 1;
+        if (!eof) carry.assign(b.buf + b.nb, b.buf + fill);
+      }
+      const bool fatal_block = b.too_long || b.read_error;
+      ready_q.push(b);
+      if (fatal_block) break;
+    }
+    if (!eof || stop.load()) {
+      Block end;
+      end.last = true;
+      ready_q.push(end);
+    }
+  });
+
+  // ---- writer
+  std::atomic<bool> write_failed{false};
+  std::thread writer([&]() {
+    for (;;) {
+      std::string *s = write_q.pop();
+      if (!s) break;
+      if (!write_failed.load() && write_all(fd_out, s->data(), s->size())) write_failed.store(true);
+      delete s;
+    }
+  });
+
   int rc = BVCF_OK;
+  bool have_pre = false, done = false;
+  std::string log;
+  std::deque<Block> in_flight;  // submitted, not yet collected (oldest first)
   uint64_t seq = 0;
-  auto cleanup = [&]() {
-    bvcf_free_pinned(bufs[0]);
-    bvcf_free_pinned(bufs[1]);
+
+  auto fail = [&](const std::string &m, int code) {
+    if (rc == BVCF_OK) {
+      rc = code;
+      log.append(m + "\n");
+    }
+    done = true;
   };
 
-  while (!(eof && fill == 0)) {
-    while (!eof && fill < cap) {
-      ssize_t got = read(fd_in, bufs[cur] + fill, cap - fill);
-      if (got < 0) {
-        if (errno == EINTR) continue;
-        cleanup();
-        return fatal(std::string("read: ") + strerror(errno), BVCF_E_FATAL);
-      }
-      if (got == 0) {
-        eof = true;
-        break;
-      }
-      fill += (size_t)got;
-    }
-    size_t start = 0;
-    if (!have_pre) {
-      int pr = parse_preamble(bufs[cur], fill, eof || fill == cap, c->normalize_header, &R.pre, &msg);
-      if (pr != 0) {
-        cleanup();
-        return fatal(pr > 0 ? "VCF preamble larger than max_batch_bytes" : msg, BVCF_E_FATAL);
-      }
-      have_pre = true;
-      rc = open_ctx(R, &msg);
-      if (rc) {
-        cleanup();
-        return fatal(msg, rc);
-      }
-      if (R.pre.header.size() == 9)
-        log.append("Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n");
-      start = R.pre.data_off;
-    }
-    const uint8_t *last = fill > start ? (const uint8_t *)memrchr(bufs[cur] + start, R.pre.eol_byte, fill - start) : nullptr;
-    if (!last) {
-      if (eof) break;  // unterminated tail: dropped (main.go:354-358)
-      if (fill == cap) {
-        cleanup();
-        return fatal("a line is longer than max_batch_bytes", BVCF_E_TOO_BIG);
-      }
-      continue;
-    }
-    const size_t nb = (size_t)(last - (bufs[cur] + start)) + 1;
+  // collect the oldest in-flight block, format it, queue its rows; grows the reservation on demand
+  auto finish_oldest = [&]() {
+    Block b = in_flight.front();
     bvcf_result res;
-    rc = process_block(R, bufs[cur] + start, nb, seq++, &res, &msg);
-    if (rc) {
-      cleanup();
-      return fatal(msg, rc);
+    double t0 = now_s();
+    int r = bvcf_collect(R.ctx, &res);
+    if (r == BVCF_E_CAPACITY) {
+      // drop what is in flight, grow, resubmit everything still queued on the device side
+      for (size_t k = 1; k < in_flight.size(); k++) {
+        bvcf_result tmp;
+        bvcf_collect(R.ctx, &tmp);
+      }
+      r = bvcf_reserve(R.ctx, res.need_lines + res.need_lines / 4 + 64, res.need_alleles + res.need_alleles / 4 + 64,
+                       res.need_cmap_bytes + res.need_cmap_bytes / 4 + 4096);
+      for (size_t k = 0; k < in_flight.size() && r == BVCF_OK; k++)
+        r = bvcf_submit(R.ctx, in_flight[k].buf + in_flight[k].start, in_flight[k].nb, seq++);
+      if (r == BVCF_OK) r = bvcf_collect(R.ctx, &res);
     }
+    t_gpu += now_s() - t0;
+    if (r != BVCF_OK) {
+      fail(std::string("bvcf: ") + bvcf_last_error(R.ctx), r);
+      return;
+    }
+    in_flight.pop_front();
     lines_in += res.n_lines;
-    out.clear();
+    t0 = now_s();
+    std::string *out = new std::string();
     Names nm{R.name_ptr.data(), R.name_len.data()};
-    format_batch(c, &res, bufs[cur] + start, nm, R.n_threads, out, log);
-    if (write_all(fd_out, out.data(), out.size())) {
-      cleanup();
-      return fatal("write failed", BVCF_E_FATAL);
-    }
+    format_batch(c, &res, b.buf + b.start, nm, R.n_threads, *out, log);
+    t_fmt += now_s() - t0;
+    write_q.push(out);
     if (!log.empty()) {
       write_all(fd_err, log.data(), log.size());
       log.clear();
     }
-    // carry the partial line into the other buffer
-    const size_t tail = fill - (start + nb);
-    memcpy(bufs[cur ^ 1], bufs[cur] + start + nb, tail);
-    cur ^= 1;
-    fill = tail;
-    if (eof && tail && !memchr(bufs[cur], R.pre.eol_byte, tail)) break;
+    free_q.push(b.buf);
+    if (write_failed.load()) fail("write failed", BVCF_E_FATAL);
+  };
+
+  t_init = now_s() - t_start;
+  while (!done) {
+    double t0 = now_s();
+    Block b = ready_q.pop();
+    t_wait_read += now_s() - t0;
+    if (b.read_error) fail(std::string("read: ") + strerror(errno), BVCF_E_FATAL);
+    if (b.too_long) fail("a line is longer than max_batch_bytes", BVCF_E_TOO_BIG);
+    if (!done && b.buf && !have_pre) {
+      t0 = now_s();
+      int pr = parse_preamble(b.buf, b.fill, true, c->normalize_header, &R.pre, &msg);
+      if (pr != 0) {
+        fail(msg, BVCF_E_FATAL);
+      } else {
+        have_pre = true;
+        int r = open_ctx(R, &msg);
+        if (r) fail(msg, r);
+        if (!done && R.pre.header.size() == 9)
+          log.append("Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n");
+        b.start = R.pre.data_off;
+        b.nb = b.nb > b.start ? b.nb - b.start : 0;
+      }
+      t_init += now_s() - t0;
+    }
+    if (!done && b.buf && b.nb) {
+      // keep one block ahead of the one being formatted
+      if (in_flight.size() >= 2) finish_oldest();
+      if (!done) {
+        int r = bvcf_submit(R.ctx, b.buf + b.start, b.nb, seq++);
+        if (r)
+          fail(std::string("bvcf_submit: ") + bvcf_last_error(R.ctx), r);
+        else
+          in_flight.push_back(b);
+      }
+    } else if (b.buf) {
+      free_q.push(b.buf);
+    }
+    if (b.last) {
+      while (!done && !in_flight.empty()) finish_oldest();
+      if (!have_pre && rc == BVCF_OK) fail("EOF", BVCF_E_FATAL);
+      done = true;
+    }
   }
-  if (!have_pre) {
-    cleanup();
-    return fatal("EOF", BVCF_E_FATAL);
+
+  // ---- shut down
+  stop.store(true);
+  for (int i = 0; i < kBufs; i++) free_q.push(nullptr);  // unblock a reader waiting for a buffer
+  // drain blocks the reader may still push so that it can exit
+  std::thread drain([&]() {
+    for (;;) {
+      Block b = ready_q.pop();
+      if (b.last && !b.buf) break;
+      if (b.last) break;
+    }
+  });
+  reader.join();
+  {
+    Block end;
+    end.last = true;
+    ready_q.push(end);
   }
+  drain.join();
+  write_q.push(nullptr);
+  writer.join();
   if (!log.empty()) write_all(fd_err, log.data(), log.size());
-  cleanup();
-  if (R.ctx) bvcf_destroy(R.ctx);
+  const double t_end0 = now_s();
+  if (R.ctx) {
+    // collect anything left after a failure so the ctx can be destroyed
+    bvcf_result tmp;
+    while (bvcf_collect(R.ctx, &tmp) != BVCF_E_EMPTY) {
+    }
+    bvcf_destroy(R.ctx);
+  }
+  free_bufs();
+  if (timing)
+    dprintf(fd_err,
+            "[bvcf timing] init %.3f wait-for-reader %.3f gpu(wait) %.3f format %.3f teardown %.3f total %.3f s\n",
+            t_init, t_wait_read, t_gpu, t_fmt, now_s() - t_end0, now_s() - t_start);
   if (n_lines_in) *n_lines_in = lines_in;
-  return BVCF_OK;
+  return rc;
 }
 
 }  // extern "C"

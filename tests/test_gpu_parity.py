@@ -174,3 +174,44 @@ def test_device_resident_submit_matches_host_submit(bv):
         ra, rb = a.records(i), b.records(i)
         for f in ("pos", "alt_idx", "ac", "an", "n_het", "n_hom", "n_miss", "ref", "kind", "trtv"):
             assert (ra[f] == rb[f]).all()
+
+
+def _run_cli(args, data):
+    import subprocess
+    exe = os.path.join(ROOT, "bystro-vcf_amd", "bystro-vcf")
+    return subprocess.run([exe] + args, input=data, capture_output=True, timeout=300)
+
+
+def test_cli_matches_oracle(bv, tmp_path):
+    """the process surface: stdin -> stdout with header line, log lines on stderr, exit status"""
+    vcf = vcfgen.gen_vcf(51, 3000, 120, weird=0.02)
+    cfg = {"keepId": True, "keepInfo": True, "emptyField": "NA"}
+    rc_o, out_o, log_o, _ = orc.run(vcf, cfg)
+    p = _run_cli(["--keepId", "--keepInfo", "--emptyField", "NA", "--batchMB", "1"], vcf)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert p.stdout == (bv.string_header(cfg) + "\n").encode() + out_o
+    assert p.stderr.decode() == log_o
+    # --in / --out / -flag=value forms, default flags
+    src, dst = tmp_path / "in.vcf", tmp_path / "out.tsv"
+    src.write_bytes(vcf)
+    p = _run_cli(["-in=%s" % src, "--out", str(dst)], b"")
+    assert p.returncode == 0
+    assert dst.read_bytes() == (bv.string_header() + "\n").encode() + orc.run(vcf)[1]
+    # fatal paths: message on stderr, exit status 1 (log.Fatal)
+    p = _run_cli([], b"not a vcf\n")
+    assert p.returncode == 1 and b"Not a VCF file" in p.stderr
+    p = _run_cli([], b"##fileformat=VCFv4.2\n")
+    assert p.returncode == 1 and b"No header found" in p.stderr
+    p = _run_cli([], b"")
+    assert p.returncode == 1
+
+
+def test_cli_large_stream(bv, golden_1kg):
+    """the 200 MB 1KG regression input through the pipelined driver with small blocks"""
+    vcf, want_sorted, hdr = golden_1kg
+    p = _run_cli(["--batchMB", "16"], vcf)
+    assert p.returncode == 0
+    rows = p.stdout.split(b"\n")
+    assert rows[0] == hdr and rows[-1] == b""
+    assert sorted(rows[1:-1]) == want_sorted
+    assert rows[1:-1] == orc.run(vcf)[1].split(b"\n")[:-1]
