@@ -150,17 +150,32 @@ __device__ __forceinline__ uint32_t low_bits16(int n) {
 
 // ------------------------------------------------------------------ line index
 
-// newline census: one wave per 1 KiB chunk
+// newline census: a wave takes 4 consecutive 1 KiB chunks per step so that 4 KiB are in flight
 __global__ __launch_bounds__(kWgThreads) void k_count_eol(KernelArgs a, uint32_t n_chunks) {
   const int lane = lane_id();
   const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
-  const uint32_t stride = gridDim.x * kWavesPerWg;
-  for (uint32_t c = wave; c < n_chunks; c += stride) {
-    const uint32_t off = c * kChunk + 16u * lane;
-    u32x4 v = load16(a.buf, off, a.cap);
-    uint32_t m = eq_mask16(v, a.eol_byte) & low_bits16((int)a.nbytes - (int)off);
-    uint32_t tot = wave_sum(__popc(m));
-    if (lane == 0) a.census[c] = tot;
+  const uint32_t stride = gridDim.x * kWavesPerWg * 4u;
+  const uint32_t last_off = a.cap - 16u;
+  for (uint32_t c0 = wave * 4u; c0 < n_chunks; c0 += stride) {
+    u32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t off = min((c0 + q) * kChunk + 16u * lane, last_off);
+      v[q] = *reinterpret_cast<const u32x4_u *>(a.buf + off);
+    }
+    uint32_t cnt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t off = (c0 + q) * kChunk + 16u * lane;
+      cnt[q] = __popc(eq_mask16(v[q], a.eol_byte) & low_bits16((int)a.nbytes - (int)off));
+    }
+    // two 16-bit sums per register: a chunk holds at most 1024 terminators
+    const uint32_t s01 = wave_sum(cnt[0] | (cnt[1] << 16));
+    const uint32_t s23 = wave_sum(cnt[2] | (cnt[3] << 16));
+    if (lane < 4 && c0 + lane < n_chunks) {
+      const uint32_t s = lane < 2 ? s01 : s23;
+      a.census[c0 + lane] = (lane & 1) ? (s >> 16) : (s & 0xFFFFu);
+    }
   }
 }
 
