@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
     ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
+    ap.add_argument("--path", type=int, default=0, help="0 choose, 1 census path, 2 streaming path")
     args = ap.parse_args()
 
     import torch
@@ -113,7 +114,9 @@ def main():
     stride = ((ns + 3) // 4 + 15) & ~15
     n_alt_cap = args.rows * (4 if args.profile == "c4" else 1) + 1024
     ctx = bv.Ctx(bg.n_header_fields(cfg), device=local_rank, max_batch_bytes=max_bytes, n_slots=1,
-                 max_lines=args.rows + 16, max_alleles=n_alt_cap, cmap_bytes=n_alt_cap * stride + 4096,
+                 max_lines=args.rows + 16, max_alleles=n_alt_cap,
+                 cmap_bytes=(n_alt_cap + 16 * 8192) * stride + 4096,  # + the streaming path's per-wave map blocks
+                 path=args.path,
                  want_class_maps=not args.no_class_maps)
     ptrs = [t.data_ptr() for t in blocks]
 
@@ -141,13 +144,17 @@ def main():
         mean_bytes = sum(sizes[i % args.blocks] for i in range(args.steps)) / args.steps
         gt_mean_ms = sum(gt_ms) / len(gt_ms)
         chain_mean_ms = sum(chain_ms) / len(chain_ms)
-        # algorithmic bytes of one k_gt launch: the GT text of every row, 4 bytes per sample
-        gt_bytes = args.rows * 4 * ns
+        # algorithmic bytes of one launch of the dominant kernel.  Census path, k_gt: the GT text of
+        # every row (4 bytes per sample).  Streaming path, k_stream: every byte of every row (it is
+        # also the pass that finds the lines).
+        streaming = ctx.path() == 2
+        kernel = "k_stream" if streaming else "k_gt"
+        gt_bytes = int(mean_bytes) if streaming else args.rows * 4 * ns
         achieved = gt_bytes / (gt_mean_ms * 1e-3) / 1e9 if ns else None
         pmc = None
         try:
             with open(os.path.join(ROOT, "profiles", "k_gt_hbm_traffic.json")) as f:
-                pmc = json.load(f).get(args.profile, {}).get("traffic_bytes_per_launch_per_row")
+                pmc = json.load(f).get(args.profile, {}).get("k_stream_traffic_bytes_per_launch_per_row" if ctx.path() == 2 else "traffic_bytes_per_launch_per_row")
         except OSError:
             pass
         line = {
@@ -172,7 +179,7 @@ def main():
                 "flags": "default (--allowFilter PASS,.), class maps on", "input": "resident in HBM",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_gt", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": (pmc * args.rows) if pmc else None,
                 "algorithmic_bytes_per_launch": gt_bytes, "mean_launch_ms": gt_mean_ms,

@@ -41,7 +41,7 @@ CLS_NONE, CLS_HET, CLS_HOM, CLS_MISSING = 0, 1, 2, 3
 EXPORTS = [
     "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_alloc_pinned",
     "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_bench_device", "bvcf_counters",
-    "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_free",
+    "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_free",
 ]
 
 
@@ -51,7 +51,7 @@ class Params(C.Structure):
         ("eol_chars", C.c_uint32), ("eol_byte", C.c_uint8), ("want_class_maps", C.c_uint8),
         ("reserved0", C.c_uint8 * 2), ("allow_filter", C.c_char_p), ("exclude_filter", C.c_char_p),
         ("max_batch_bytes", C.c_uint64), ("max_lines", C.c_uint32), ("max_alleles", C.c_uint32),
-        ("cmap_bytes", C.c_uint64), ("n_slots", C.c_uint32), ("reserved1", C.c_uint32),
+        ("cmap_bytes", C.c_uint64), ("n_slots", C.c_uint32), ("path", C.c_uint32),
     ]
 
 
@@ -72,6 +72,7 @@ class Result(C.Structure):
         ("n_samples", C.c_uint32), ("lines", C.c_void_p), ("alleles", C.c_void_p), ("errs", C.c_void_p),
         ("cmap", C.c_void_p), ("need_lines", C.c_uint64), ("need_alleles", C.c_uint64),
         ("need_cmap_bytes", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32),
+        ("n_lines_seen", C.c_uint64),
     ]
 
 
@@ -103,6 +104,7 @@ lib.bvcf_collect.argtypes = [C.c_void_p, C.POINTER(Result)]
 lib.bvcf_bench_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
                                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
 lib.bvcf_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+lib.bvcf_path.argtypes = [C.c_void_p]
 lib.bvcf_config_defaults.argtypes = [C.POINTER(Config)]
 lib.bvcf_config_defaults.restype = None
 lib.bvcf_string_header.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t]
@@ -174,6 +176,7 @@ class Batch:
         self.n_samples = r.n_samples
         self.cmap_stride = r.cmap_stride
         self.kernel_ms = r.kernel_ms
+        self.n_lines_seen = r.n_lines_seen
 
         def arr(ptr, n, dt):
             if not n:
@@ -206,7 +209,8 @@ class Ctx:
     """one bvcf_ctx (one GPU)"""
 
     def __init__(self, n_header_fields, allow="PASS,.", exclude="", device=0, eol_chars=1, eol_byte=b"\n",
-                 max_batch_bytes=0, max_lines=0, max_alleles=0, cmap_bytes=0, n_slots=0, want_class_maps=True):
+                 max_batch_bytes=0, max_lines=0, max_alleles=0, cmap_bytes=0, n_slots=0, want_class_maps=True,
+                 path=0):
         p = Params()
         p.abi_version = ABI_VERSION
         p.device = device
@@ -221,6 +225,7 @@ class Ctx:
         p.max_alleles = max_alleles
         p.cmap_bytes = cmap_bytes
         p.n_slots = n_slots
+        p.path = path
         self.h = C.c_void_p()
         rc = lib.bvcf_create(C.byref(self.h), C.byref(p))
         if rc:
@@ -274,6 +279,10 @@ class Ctx:
         counts = (C.c_uint64 * 5)()
         self._check(lib.bvcf_bench_device(self.h, ptrs, sizes, n, iters, chain, scan, counts))
         return list(chain), list(scan), list(counts)
+
+    def path(self):
+        """1 = census path, 2 = streaming path"""
+        return lib.bvcf_path(self.h)
 
     def counters(self):
         out = (C.c_uint64 * 8)()

@@ -29,6 +29,8 @@ struct Slot {
   uint8_t *d_cmap = nullptr;
   GtTask *d_tasks = nullptr;
   GtResult *d_results = nullptr;
+  StreamEntry *d_entries = nullptr;
+  uint32_t *d_line_len = nullptr, *d_line_cmap = nullptr;
   BatchCounters *d_counters = nullptr;
   // pinned host
   BatchCounters *h_counters = nullptr;
@@ -50,7 +52,9 @@ struct bvcf_ctx {
   bvcf_params p{};
   int device = 0;
   int n_cu = 0;
-  int gt_grid = 0;
+  int gt_grid = 0, stream_grid = 0;
+  bool fused = false;
+  uint32_t tile_bytes = 0, tile_quota = 0;
   uint32_t n_samples = 0;
   uint32_t cmap_stride = 0;
   uint64_t max_lines = 0, max_alleles = 0, max_cmap = 0;
@@ -113,6 +117,9 @@ void free_slot(Slot &s) {
   hipFree(s.d_cmap);
   hipFree(s.d_tasks);
   hipFree(s.d_results);
+  hipFree(s.d_entries);
+  hipFree(s.d_line_len);
+  hipFree(s.d_line_cmap);
   hipFree(s.d_counters);
   hipHostFree(s.h_counters);
   hipHostFree(s.h_lines);
@@ -136,6 +143,8 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   hipFree(s.d_cmap);
   hipFree(s.d_tasks);
   hipFree(s.d_results);
+  hipFree(s.d_line_len);
+  hipFree(s.d_line_cmap);
   hipHostFree(s.h_lines);
   hipHostFree(s.h_alleles);
   hipHostFree(s.h_errs);
@@ -147,6 +156,8 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   s.d_cmap = nullptr;
   s.d_tasks = nullptr;
   s.d_results = nullptr;
+  s.d_line_len = nullptr;
+  s.d_line_cmap = nullptr;
   s.h_lines = nullptr;
   s.h_alleles = nullptr;
   s.h_errs = nullptr;
@@ -159,6 +170,8 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   HIP_TRY(c, hipMalloc(&s.d_cmap, c->max_cmap + 64));
   HIP_TRY(c, hipMalloc(&s.d_tasks, c->max_alleles * sizeof(GtTask)));
   HIP_TRY(c, hipMalloc(&s.d_results, c->max_alleles * sizeof(GtResult)));
+  HIP_TRY(c, hipMalloc(&s.d_line_len, c->max_lines * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&s.d_line_cmap, c->max_lines * sizeof(uint32_t)));
   HIP_TRY(c, hipHostMalloc(&s.h_lines, c->max_lines * sizeof(bvcf_line), hipHostMallocDefault));
   HIP_TRY(c, hipHostMalloc(&s.h_alleles, c->max_alleles * sizeof(bvcf_allele), hipHostMallocDefault));
   HIP_TRY(c, hipHostMalloc(&s.h_errs, c->max_alleles * sizeof(bvcf_err), hipHostMallocDefault));
@@ -181,6 +194,10 @@ int alloc_slot(bvcf_ctx *c, Slot &s) {
   HIP_TRY(c, hipMalloc(&s.d_group, (s.cap_census / kScanGroup + 2) * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&s.d_counters, sizeof(BatchCounters)));
   HIP_TRY(c, hipHostMalloc(&s.h_counters, sizeof(BatchCounters), hipHostMallocDefault));
+  if (c->fused) {
+    const uint64_t max_tiles = (c->p.max_batch_bytes + c->tile_bytes - 1) / c->tile_bytes + 1;
+    HIP_TRY(c, hipMalloc(&s.d_entries, max_tiles * c->tile_quota * sizeof(StreamEntry)));
+  }
   return alloc_results(c, s);
 }
 
@@ -211,11 +228,33 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.tasks = s.d_tasks;
   a.results = s.d_results;
   a.counters = s.d_counters;
+  a.fused = c->fused ? 1u : 0u;
+  a.tile_bytes = c->tile_bytes;
+  a.tile_quota = c->tile_quota;
+  a.n_tiles = c->fused ? (uint32_t)((nbytes + c->tile_bytes - 1) / c->tile_bytes) : 0u;
+  a.entries = s.d_entries;
+  a.line_len = s.d_line_len;
+  a.line_cmap = s.d_line_cmap;
   return a;
 }
 
-// the kernel chain for one resident block; ev_gt0 / ev_gt1 (optional) bracket the genotype scan
+// the kernel chain for one resident block; ev_gt0 / ev_gt1 (optional) bracket the dominant kernel
+// (k_gt on the census path, k_stream on the streaming path)
 void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t ev_gt0, hipEvent_t ev_gt1) {
+  if (a.fused) {
+    const uint32_t n_groups = (a.n_tiles + kScanGroup - 1) / kScanGroup;
+    hipMemsetAsync(a.counters, 0, sizeof(BatchCounters), st);
+    if (ev_gt0) hipEventRecord(ev_gt0, st);
+    hipLaunchKernelGGL(k_stream, dim3(c->stream_grid), dim3(kWgThreads), 0, st, a);
+    if (ev_gt1) hipEventRecord(ev_gt1, st);
+    hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, a.n_tiles);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
+    hipLaunchKernelGGL(k_order, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
+    hipLaunchKernelGGL(k_head, dim3(c->n_cu * 2), dim3(kWgThreads), 0, st, a);
+    hipLaunchKernelGGL(k_gt, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
+    hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
+    return;
+  }
   const uint32_t n_chunks = (a.nbytes + kChunk - 1) / kChunk;
   const uint32_t n_groups = (n_chunks + kScanGroup - 1) / kScanGroup;
   const uint32_t stream_grid = (uint32_t)std::min<uint64_t>((n_chunks + kWavesPerWg - 1) / kWavesPerWg,
@@ -224,7 +263,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
   hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, n_chunks);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
   hipLaunchKernelGGL(k_scatter_eol, dim3(stream_grid ? stream_grid : 1), dim3(kWgThreads), 0, st, a, n_chunks);
-  hipLaunchKernelGGL(k_head, dim3(c->n_cu * 8), dim3(kWgThreads), 0, st, a);
+  hipLaunchKernelGGL(k_head, dim3(c->n_cu * 2), dim3(kWgThreads), 0, st, a);
   if (a.n_samples) {
     if (ev_gt0) hipEventRecord(ev_gt0, st);
     hipLaunchKernelGGL(k_gt, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
@@ -326,6 +365,19 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   c->max_cmap = p->cmap_bytes ? p->cmap_bytes : (c->max_lines + c->max_lines / 2) * (uint64_t)c->cmap_stride + (1ull << 20);
   if (c->max_cmap > 0xFFFFFF00ull) c->max_cmap = 0xFFFFFF00ull;  // cmap_off is 32-bit
   c->max_cmap = (c->max_cmap + 63) & ~63ull;
+  // streaming path: lines are found by the genotype scan itself.  Its tile-local entry quota is
+  // bounded because a line that passes the field count is at least n_header - 1 bytes long; for
+  // narrow files the quota would dwarf the text, so they stay on the census path unless asked.
+  c->tile_bytes = 64u << 10;
+  if (const char *e = getenv("BVCF_TILE_KB")) {
+    const unsigned kb = (unsigned)atoi(e);
+    if (kb >= 4 && kb <= (1u << 20)) c->tile_bytes = kb << 10;
+  }
+  uint32_t path = p->path;
+  if (path == 0)
+    if (const char *e = getenv("BVCF_PATH")) path = (uint32_t)atoi(e);  // test / tuning override
+  c->fused = c->n_samples > 0 && (path == 2 || (path == 0 && p->n_header_fields >= 256));
+  c->tile_quota = c->tile_bytes / (p->n_header_fields - 1 + p->eol_chars) + 2;
   auto fail = [&](int rc) {
     g_create_err = c->err;
     bvcf_destroy(c);
@@ -345,6 +397,10 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gt, kWgThreads, 0) != hipSuccess || per_cu < 1)
     per_cu = 4;
   c->gt_grid = c->n_cu * per_cu;
+  per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream, kWgThreads, 0) != hipSuccess || per_cu < 1)
+    per_cu = 3;
+  c->stream_grid = c->n_cu * per_cu;
 
   FilterTable ft;
   memset(&ft, 0, sizeof ft);
@@ -429,7 +485,12 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   const uint64_t n_tasks = (uint64_t)ctr.n_lines + ctr.n_tasks;
   const uint64_t need_alleles = std::max<uint64_t>(std::max<uint64_t>(n_alleles, ctr.n_errs), n_tasks);
   const bool maps = c->p.want_class_maps && c->n_samples;
-  const uint64_t cmap_bytes = maps ? n_tasks * c->cmap_stride : 0;
+  const uint64_t cmap_bytes = !maps ? 0 : (c->fused ? (uint64_t)ctr.cmap_maps : n_tasks) * c->cmap_stride;
+  if (ctr.pad[0]) {
+    c->err = "internal error: streaming tile quota exceeded";
+    release();
+    return BVCF_E_HIP;
+  }
   if (ctr.n_lines > s.cap_lines || need_alleles > s.cap_alleles || cmap_bytes > s.cap_cmap) {
     r->status = BVCF_E_CAPACITY;
     r->need_lines = ctr.n_lines;
@@ -466,6 +527,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   r->n_alleles = (uint32_t)n_alleles;
   r->n_errs = n_errs;
   r->n_cmap_bytes = cmap_bytes;
+  r->n_lines_seen = ctr.lines_seen;
   r->lines = s.h_lines;
   r->alleles = s.h_alleles;
   r->errs = s.h_errs;
@@ -480,7 +542,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     if (c->n_samples)
       for (uint32_t j = 0; j < L.n_rec; j++) ac0 += s.h_alleles[j ? L.rec_first + j - 1 : i].ac == 0;
   }
-  c->totals[0] += ctr.n_lines;
+  c->totals[0] += ctr.lines_seen;
   c->totals[1] += ok;
   c->totals[2] += recs;
   c->totals[3] += ac0;
@@ -491,6 +553,8 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   release();
   return BVCF_OK;
 }
+
+int bvcf_path(const bvcf_ctx *c) { return c ? (c->fused ? 2 : 1) : BVCF_E_ARG; }
 
 int bvcf_counters(bvcf_ctx *c, uint64_t out[8]) {
   if (!c || !out) return BVCF_E_ARG;
@@ -535,13 +599,14 @@ int bvcf_bench_device(bvcf_ctx *c, const void *const *dblocks, const size_t *nby
     counts[0] = ctr.n_lines;
     counts[1] = (uint64_t)ctr.n_lines + ctr.n_alleles;
     counts[2] = ctr.n_errs;
-    counts[3] = ((uint64_t)ctr.n_lines + ctr.n_tasks) * c->cmap_stride;
+    counts[3] = (c->fused ? (uint64_t)ctr.cmap_maps : (uint64_t)ctr.n_lines + ctr.n_tasks) * c->cmap_stride;
     counts[4] = (uint64_t)ctr.n_lines + ctr.n_tasks;
   }
   const uint64_t b_need = std::max<uint64_t>(std::max<uint64_t>((uint64_t)ctr.n_lines + ctr.n_alleles, ctr.n_errs),
                                              (uint64_t)ctr.n_lines + ctr.n_tasks);
   if (ctr.n_lines > s.cap_lines || b_need > s.cap_alleles ||
-      (c->p.want_class_maps && c->n_samples && ((uint64_t)ctr.n_lines + ctr.n_tasks) * c->cmap_stride > s.cap_cmap)) {
+      (c->p.want_class_maps && c->n_samples &&
+       (c->fused ? (uint64_t)ctr.cmap_maps : (uint64_t)ctr.n_lines + ctr.n_tasks) * c->cmap_stride > s.cap_cmap)) {
     c->err = "bench block exceeds reserved result capacity";
     return BVCF_E_CAPACITY;
   }

@@ -12,6 +12,15 @@
 //                  and the 2-bit class map.  THE HBM-bound kernel.   (main.go:1042-1194)
 //   k_finish       field-count verdict per line, scan results into the allele records
 //
+// Streaming variant for files with samples (KernelArgs.fused): the census, its scans, the scatter
+// and the ALT #1 genotype scan are replaced by ONE pass over the text,
+//   k_stream       one wave walks a 64 KiB tile: finds the lines that start in it, tokenises their
+//                  fixed columns and scans ALT #1 straight away (the scan's loads ARE the newline
+//                  search: a regular line ends where 4*ns bytes of "x|y<TAB>" end)
+//   k_scan_*       exclusive scan of the per-tile line counts
+//   k_order        tile-local line entries -> input-ordered line_off / line_len / results
+// after which k_head, k_gt (further ALT indices only) and k_finish run as above.
+//
 // Everything is byte/integer work bounded by the HBM read of the line bytes; no MFMA.
 // Loads are 16 B per lane, 1 KiB per wave-instruction, starting exactly at the byte the
 // record window starts at (unaligned dwordx4), so that in a regular sample region
@@ -45,11 +54,20 @@ struct FilterTable {
 
 // device-resident batch state
 struct BatchCounters {
-  uint32_t n_lines;      // lines found by the census (may exceed max_lines)
-  uint32_t n_alleles;    // bvcf_allele slots requested
+  uint32_t n_lines;      // lines listed in lines[] (may exceed max_lines)
+  uint32_t n_alleles;    // bvcf_allele slots requested past the first n_lines
   uint32_t n_errs;
-  uint32_t n_tasks;      // genotype-scan tasks requested
-  unsigned long long cmap_bytes;  // class-map bytes requested
+  uint32_t n_tasks;      // genotype-scan tasks requested past the first n_lines
+  uint32_t lines_seen;   // terminated lines in the block (== n_lines on the census path)
+  uint32_t cmap_maps;    // streaming path: class maps handed out
+  uint32_t pad[2];
+};
+
+// streaming path: what k_stream knows about a line when it has scanned it
+struct StreamEntry {
+  uint32_t ls, len;                       // start offset, content length (terminator chomped)
+  uint32_t ac, an, n_het, n_hom, n_miss;  // ALT #1
+  uint32_t cmap_off;
 };
 
 // one genotype scan: all samples of one line against one ALT index
@@ -92,6 +110,15 @@ struct KernelArgs {
   GtTask *tasks;
   GtResult *results;
   BatchCounters *counters;
+  // streaming path
+  uint32_t fused;        // 1: k_stream found the lines and scanned ALT #1
+  uint32_t tile_bytes;   // bytes of text a wave owns (lines belong to the tile they start in)
+  uint32_t tile_quota;   // entries reserved per tile: a line that passes the field count is at
+                         // least n_header - 1 + eol_chars bytes long
+  uint32_t n_tiles;
+  StreamEntry *entries;  // [n_tiles * tile_quota]
+  uint32_t *line_len;    // [max_lines]
+  uint32_t *line_cmap;   // [max_lines] class map of ALT #1
 };
 
 // ------------------------------------------------------------------ wave helpers
@@ -232,11 +259,15 @@ __global__ __launch_bounds__(1024) void k_scan_top(KernelArgs a, uint32_t n_grou
   }
   if (threadIdx.x == 1023) {
     a.counters->n_lines = s_part[1023];
-    a.counters->n_alleles = 0;
-    a.counters->n_errs = 0;
-    a.counters->n_tasks = 0;
-    a.counters->cmap_bytes = 0ull;
-    a.line_off[0] = 0u;
+    if (!a.fused) {  // the streaming path zeroes the counters before k_stream uses them
+      a.counters->n_alleles = 0;
+      a.counters->n_errs = 0;
+      a.counters->n_tasks = 0;
+      a.counters->lines_seen = s_part[1023];
+      a.counters->cmap_maps = 0;
+      a.counters->pad[0] = a.counters->pad[1] = 0;
+      a.line_off[0] = 0u;
+    }
   }
 }
 
@@ -644,6 +675,16 @@ struct FastAcc {
 constexpr uint32_t kStageChunks = 64;                 // class-map bytes staged in LDS per wave:
 constexpr uint32_t kStageBytes = kStageChunks * 64u;  // 64 chunks x 64 B = 4 KiB = 16 384 samples
 
+// all-reference chunks never touch the stage: it is zeroed once per window instead
+__device__ __forceinline__ void zero_stage(uint8_t *stage) {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (uint32_t i = 0; i < kStageBytes / (16u * kWave); i++)
+    *reinterpret_cast<u32x4 *>(stage + 16u * (lane_id() + i * kWave)) = z;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // write staged class-map bytes [0, n) of the window starting at chunk c_base to the task's map
 __device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *cmap, uint32_t c_base, uint32_t n,
                                             uint32_t stride) {
@@ -660,7 +701,7 @@ __device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *cmap,
 // one 1 KiB chunk (this lane's 4 fields) of a regular region; class bytes go to the LDS stage
 __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunks, uint32_t ns, uint32_t kref,
                                            uint32_t table, uint8_t *cmap, uint8_t *stage, uint32_t stride,
-                                           FastAcc &acc) {
+                                           uint32_t term_xor, FastAcc &acc) {
   const int lane = lane_id();
   const uint32_t f0 = c * 256u + 4u * lane;  // sample index of the lane's first dword
   uint32_t t[4] = {v.x ^ kref, v.y ^ kref, v.z ^ kref, v.w ^ kref};
@@ -670,11 +711,15 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       if (f0 + q >= ns) t[q] = 0;
-      if (f0 + q == ns - 1) t[q] &= 0x00FFFFFFu;
+      if (f0 + q == ns - 1) {
+        // term_xor = (expected terminator ^ TAB) << 24; anything above 0xFF000000 = no check
+        if (term_xor <= 0xFF000000u) acc.bad |= (t[q] ^ term_xor) & 0xFF000000u;
+        t[q] &= 0x00FFFFFFu;
+      }
     }
   }
-  uint32_t byte = 0;
   if (__any((t[0] | t[1] | t[2] | t[3]) != 0)) {
+    uint32_t byte = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       acc.bad |= t[q] & 0xFFE0FFE0u;
@@ -685,27 +730,33 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
     acc.het += __popc(lo & ~hi);
     acc.hom += __popc(hi & ~lo);
     acc.miss += __popc(lo & hi);
+    if (cmap) stage[(c % kStageChunks) * 64u + lane] = (uint8_t)byte;  // the stage starts zeroed
   }
-  if (cmap) {
-    stage[(c % kStageChunks) * 64u + lane] = (uint8_t)byte;
-    if ((c % kStageChunks) == kStageChunks - 1u || c + 1 == n_chunks)
-      flush_stage(stage, cmap, c - (c % kStageChunks), ((c % kStageChunks) + 1u) * 64u, stride);
+  if (cmap && ((c % kStageChunks) == kStageChunks - 1u || c + 1 == n_chunks)) {
+    flush_stage(stage, cmap, c - (c % kStageChunks), ((c % kStageChunks) + 1u) * 64u, stride);
+    if (c + 1 != n_chunks) zero_stage(stage);
   }
 }
 
-// Returns false (outputs meaningless) if any field is irregular.  cmap may be nullptr.
+// check_term: also require the byte after the last sample to be the line terminator (the caller
+// predicted the end of the line from the region's regular length)
 __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint32_t ns, uint32_t allele, uint8_t *cmap,
-                                    uint8_t *stage, GtStats *st) {
+                                    uint8_t *stage, bool check_term, GtStats *st) {
   const int lane = lane_id();
   const uint32_t table = (allele <= 9 ? (1u << (2u * allele)) : 0u) | (3u << 28);
   const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;
   const uint32_t last_off = a.cap - 16u;
   const uint8_t *base = a.buf;
+  // every chunk of the region ends before the buffer does (the common case): no per-load clamp
+  const bool inside = (unsigned long long)s_begin + (unsigned long long)n_chunks * kChunk <= a.cap;
+  const uint8_t *lane_base = base + s_begin + 16u * lane;
   auto fetch = [&](uint32_t c) -> u32x4 {
+    if (inside) return *reinterpret_cast<const u32x4_u *>(lane_base + c * kChunk);
     const uint32_t off = min(s_begin + c * kChunk + 16u * lane, last_off);
     return *reinterpret_cast<const u32x4_u *>(base + off);
   };
   FastAcc acc = {0, 1, 0, 0, 0};
+  if (cmap) zero_stage(stage);
   u32x4 va[kFastGroup], vb[kFastGroup];
 #pragma unroll
   for (int g = 0; g < kFastGroup; g++)
@@ -717,17 +768,20 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
   const uint32_t sep = (__builtin_amdgcn_readfirstlane(va[0].x) >> 8) & 0xFFu;
   if (sep != '|' && sep != '/') return false;
   const uint32_t kref = 0x09300030u | (sep << 8);
+  // the 32-bit compare below cannot be expressed with a 0 sentinel (0 is a valid xor), so "no check"
+  // is any value above 0xFF000000
+  const uint32_t term_xor = check_term ? ((a.eol_byte ^ 0x09u) << 24) : 0xFFFFFFFFu;
 
   for (uint32_t c0 = 0; c0 < n_chunks; c0 += 2 * kFastGroup) {
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
-      if (c0 + g < n_chunks) fast_chunk(va[g], c0 + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, acc);
+      if (c0 + g < n_chunks) fast_chunk(va[g], c0 + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
       if (c0 + 2 * kFastGroup + g < n_chunks) va[g] = fetch(c0 + 2 * kFastGroup + g);
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
-      if (c0 + kFastGroup + g < n_chunks) fast_chunk(vb[g], c0 + kFastGroup + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, acc);
+      if (c0 + kFastGroup + g < n_chunks) fast_chunk(vb[g], c0 + kFastGroup + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
       if (c0 + 3 * kFastGroup + g < n_chunks) vb[g] = fetch(c0 + 3 * kFastGroup + g);
@@ -821,7 +875,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
     GtStats st = {0, 0, 0, 0, 0};
     uint32_t n_fields;
     // regular region: 4 bytes per sample, every dword of a lane is one "x|y<TAB>" field
-    if (t.cend + 1u - t.s_begin == 4u * ns && gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, &st)) {
+    if (t.cend + 1u - t.s_begin == 4u * ns && gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, false, &st)) {
       n_fields = ns;
     } else {
       uint32_t tabs;
@@ -913,24 +967,248 @@ __device__ inline void write_allele(const KernelArgs &a, uint32_t idx, uint32_t 
 
 constexpr uint32_t kNoTask = 0xFFFFFFFFu;
 
-// Write genotype-scan task `ti`.  Slots are deterministic: task i < n_lines is "line i, ALT #1",
-// tasks past n_lines are the further ALT indices of multiallelic lines; the class map of task ti
-// lives at ti * cmap_stride.  allele == 0 marks a line that needs no scan.
-__device__ inline uint32_t put_task(const KernelArgs &a, uint32_t ti, uint32_t line, uint32_t allele, uint32_t s_begin,
-                                    uint32_t cend, bool want_map) {
-  uint32_t cm = BVCF_NO_CMAP;
-  if (want_map && ((unsigned long long)ti + 1ull) * a.cmap_stride <= a.max_cmap) cm = ti * a.cmap_stride;
+// Write genotype-scan task `ti` (allele == 0 marks a slot without a scan).  Task i < n_lines is
+// "line i, ALT #1"; tasks past n_lines are the further ALT indices of multiallelic lines.
+__device__ inline void put_task(const KernelArgs &a, uint32_t ti, uint32_t line, uint32_t allele, uint32_t s_begin,
+                                uint32_t cend, uint32_t cmap_off) {
   if (ti < a.max_tasks) {
     GtTask t;
     t.line = line;
     t.allele = allele;
     t.s_begin = s_begin;
     t.cend = cend;
-    t.cmap_off = cm;
+    t.cmap_off = cmap_off;
     t.pad[0] = t.pad[1] = t.pad[2] = 0;
     a.tasks[ti] = t;
   }
-  return cm;
+}
+
+// class map of map slot `mi` (census path: slot == task index), or BVCF_NO_CMAP past the arena
+__device__ __forceinline__ uint32_t cmap_of(const KernelArgs &a, uint32_t mi, bool want) {
+  return (want && ((unsigned long long)mi + 1ull) * a.cmap_stride <= a.max_cmap) ? mi * a.cmap_stride : BVCF_NO_CMAP;
+}
+
+// ------------------------------------------------------------------ k_stream: one wave per tile
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+// first terminator byte at a position in [from, limit), or kNone; 4 KiB in flight per step
+__device__ inline uint32_t find_eol(const KernelArgs &a, uint32_t from, uint32_t limit) {
+  const int lane = lane_id();
+  const uint32_t last_off = a.cap - 16u;
+  for (uint32_t base = from; base < limit; base += 4u * kChunk) {
+    u32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const u32x4_u *>(a.buf + min(base + q * kChunk + 16u * lane, last_off));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t off = base + q * kChunk + 16u * lane;
+      const uint32_t m = eq_mask16(v[q], a.eol_byte) & low_bits16((int)limit - (int)off);
+      const unsigned long long b = __ballot(m != 0);
+      if (b) {
+        const int src = __ffsll((long long)b) - 1;
+        return __builtin_amdgcn_readfirstlane(__shfl(off + __ffs(m) - 1, src, kWave));
+      }
+    }
+  }
+  return kNone;
+}
+
+// position of the k-th (0-based) set bit of m; m has more than k bits set
+__device__ __forceinline__ uint32_t nth_bit(uint32_t m, uint32_t k) {
+  for (uint32_t i = 0; i < k; i++) m &= m - 1;
+  return __ffs(m) - 1;
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
+  uint8_t *stage = s_stage[threadIdx.x >> 6];
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * kWavesPerWg;
+  const uint32_t ns = a.n_samples;
+  const uint32_t nb = a.nbytes;
+  const uint32_t T = a.tile_bytes;
+  const uint32_t need = 9;  // the streaming path is only used with samples
+  const bool maps = a.want_cmap != 0;
+  uint32_t cm_next = 0, cm_end = 0;  // this wave's private block of class-map slots
+  uint32_t seen = 0;                 // terminated lines this wave walked over
+
+  // A wave owns a contiguous run of tiles and walks it front to back, so only the first tile needs
+  // a search for its first line start (those bytes are the previous wave's last line).  Entries
+  // stay per tile: the quota argument is about bytes, not about who scans them.
+  const uint32_t per_wave = (a.n_tiles + n_waves - 1) / n_waves;
+  const uint32_t tile_lo = min(wave * per_wave, a.n_tiles), tile_hi = min(tile_lo + per_wave, a.n_tiles);
+  const uint32_t r0 = tile_lo * T;
+  const uint32_t r1 = (uint32_t)min((unsigned long long)tile_hi * T, (unsigned long long)nb);
+  uint32_t tile = tile_lo, n_local = 0;
+  uint32_t p = kNone;
+  if (tile_lo < tile_hi) {
+    p = 0;
+    if (r0 > 0) {
+      const uint32_t q = find_eol(a, r0 - 1, r1);  // a terminator at r1 - 1 starts a line of the next run
+      p = q == kNone ? kNone : q + 1;
+    }
+  }
+  u32x4 hv = {0u, 0u, 0u, 0u};  // first 256 B of the next line, requested with the current line's scan
+  uint32_t hv_pos = kNone;
+  while (p != kNone && p < r1) {
+    while (p >= (tile + 1) * T) {  // p moved into a later tile of the run
+      if (lane == 0) a.census[tile] = n_local;
+      tile++;
+      n_local = 0;
+    }
+    // ---- fixed columns: the 9th TAB, or the terminator if it comes first (main.go:535)
+    uint32_t found = 0, tab9 = kNone, eolp = kNone;
+    for (uint32_t base = p; base < nb;) {
+      const bool pre = base == hv_pos;  // 16 lanes were fetched ahead: a 256 B window
+      const uint32_t span = pre ? 256u : kChunk;
+      const uint32_t off = base + 16u * lane;
+      u32x4 v = pre ? hv : load16(a.buf, off, a.cap);
+      uint32_t valid = low_bits16((int)nb - (int)off);
+      if (pre && lane >= 16) valid = 0;
+      const uint32_t me = eq_mask16(v, a.eol_byte) & valid;
+      uint32_t mt = eq_mask16(v, '\t') & valid;
+      const unsigned long long be = __ballot(me != 0);
+      uint32_t eol_here = kNone;
+      if (be) {
+        const int src = __ffsll((long long)be) - 1;
+        eol_here = __builtin_amdgcn_readfirstlane(__shfl(off + __ffs(me) - 1, src, kWave));
+        mt &= low_bits16((int)eol_here - (int)off);  // TABs of this line only
+      }
+      uint32_t tot;
+      const uint32_t cnt = __popc(mt);
+      const uint32_t prefix = wave_excl_scan(cnt, &tot);
+      if (found + tot >= need) {
+        const uint32_t target = need - 1 - found;
+        const bool mine = prefix <= target && target < prefix + cnt;
+        const unsigned long long bm = __ballot(mine);
+        const int src = __ffsll((long long)bm) - 1;
+        const uint32_t pos = mine ? off + nth_bit(mt, target - prefix) : 0u;
+        tab9 = __builtin_amdgcn_readfirstlane(__shfl(pos, src, kWave));
+        break;
+      }
+      found += tot;
+      if (eol_here != kNone) {
+        eolp = eol_here;
+        break;
+      }
+      base += span;
+    }
+    if (tab9 == kNone) {
+      if (eolp == kNone) break;  // unterminated tail of the block: dropped (main.go:354-358)
+      seen++;                    // fewer than 10 fields: cannot pass linePasses
+      p = eolp + 1;
+      continue;
+    }
+    const uint32_t s_begin = tab9 + 1;
+
+    // ---- a class-map slot for this line (kept only if the line is listed)
+    uint8_t *cm = nullptr;
+    uint32_t cm_off = BVCF_NO_CMAP;
+    if (maps) {
+      if (cm_next == cm_end) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&a.counters->cmap_maps, 16u);
+        cm_next = __builtin_amdgcn_readfirstlane(b);
+        cm_end = cm_next + 16u;
+      }
+      cm_off = cmap_of(a, cm_next, true);
+      if (cm_off != BVCF_NO_CMAP) cm = a.cmap + cm_off;
+    }
+
+    // ---- ALT #1 scan; a regular region also tells where the line ends
+    GtStats st = {0, 0, 0, 0, 0};
+    uint32_t cend = kNone, n_fields = 0;
+    const unsigned long long pred = (unsigned long long)s_begin + 4ull * ns - 1ull;  // predicted content end
+    hv_pos = kNone;
+    if (pred + a.eol_chars <= nb) {
+      const uint32_t pe = (uint32_t)pred;
+      // "\n": the terminator is the byte after the last sample and is checked by the scan itself;
+      // "\r\n": it is one byte further, look at it here
+      bool term = true;
+      if (a.eol_chars == 2) term = a.buf[pe + 1] == a.eol_byte && a.buf[pe] != a.eol_byte;
+      if (term) {
+        // the next line's head travels with this line's scan loads
+        hv_pos = pe + a.eol_chars;
+        if (lane < 16) hv = load16(a.buf, hv_pos + 16u * lane, a.cap);
+        if (gt_scan_fast(a, s_begin, ns, 1, cm, stage, a.eol_chars == 1, &st)) {
+          cend = pe;
+          n_fields = ns;
+        } else {
+          hv_pos = kNone;
+        }
+      }
+    }
+    if (cend == kNone) {
+      const uint32_t e = find_eol(a, s_begin, nb);
+      if (e == kNone) break;  // unterminated tail
+      if (e + 1 < s_begin + a.eol_chars) {
+        // chomping numChars bytes (main.go:535) eats the 9th TAB: at most 9 fields remain
+        seen++;
+        p = e + 1;
+        continue;
+      }
+      cend = e + 1 - a.eol_chars;
+      uint32_t tabs;
+      gt_scan_general(a, s_begin, cend, ns, 1, cm, &st, &tabs);
+      n_fields = tabs + 1;
+    }
+    seen++;
+    if (9u + n_fields == a.n_header && n_local >= a.tile_quota && lane == 0) a.counters->pad[0] = 1;  // cannot happen
+    if (9u + n_fields == a.n_header && n_local < a.tile_quota) {
+      if (lane == 0) {
+        StreamEntry en;
+        en.ls = p;
+        en.len = cend - p;
+        en.ac = st.ac;
+        en.an = st.an;
+        en.n_het = st.n_het;
+        en.n_hom = st.n_hom;
+        en.n_miss = st.n_miss;
+        en.cmap_off = cm_off;
+        a.entries[(size_t)tile * a.tile_quota + n_local] = en;
+      }
+      n_local++;
+      if (maps) cm_next++;
+    }
+    p = cend + a.eol_chars;
+  }
+  for (; tile < tile_hi; tile++) {  // the rest of the run has no line starts
+    if (lane == 0) a.census[tile] = n_local;
+    n_local = 0;
+  }
+  if (lane == 0 && seen) atomicAdd(&a.counters->lines_seen, seen);
+}
+
+// tile-local entries -> input order (the exclusive scan of the tile counts is in census/group_base)
+__global__ __launch_bounds__(kWgThreads) void k_order(KernelArgs a) {
+  const uint32_t total = a.n_tiles * a.tile_quota;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t tile = i / a.tile_quota, k = i % a.tile_quota;
+    const uint32_t first = a.census[tile] + a.group_base[tile / kScanGroup];
+    const uint32_t next = (tile + 1 < a.n_tiles)
+                              ? a.census[tile + 1] + a.group_base[(tile + 1) / kScanGroup]
+                              : a.counters->n_lines;
+    if (k >= next - first) continue;
+    const uint32_t g = first + k;
+    if (g >= a.max_lines) continue;
+    const StreamEntry en = a.entries[i];
+    a.line_off[g] = en.ls;
+    a.line_len[g] = en.len;
+    a.line_cmap[g] = en.cmap_off;
+    if (g < a.max_tasks) {
+      GtResult r;
+      r.ac = en.ac;
+      r.an = en.an;
+      r.n_het = en.n_het;
+      r.n_hom = en.n_hom;
+      r.n_miss = en.n_miss;
+      r.n_fields = a.n_header - 9u;
+      r.pad[0] = r.pad[1] = 0;
+      a.results[g] = r;
+    }
+  }
 }
 
 // k_head handles 256 lines per workgroup step in two phases:
@@ -949,7 +1227,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
   __shared__ uint32_t s_ls[kLinesPerStep], s_len[kLinesPerStep], s_found[kLinesPerStep], s_staged[kLinesPerStep],
       s_extra[kLinesPerStep];
   __shared__ uint32_t s_wave[kWavesPerWg][2];
-  __shared__ uint32_t s_base[2];
+  __shared__ uint32_t s_base[3];
   __shared__ FilterTable s_ft;  // FILTER sets
   {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(a.filters);
@@ -975,8 +1253,13 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       const uint32_t line = line0 + ll;
       if (line >= n_lines) continue;
       const uint32_t ls = a.line_off[line];
-      const uint32_t le = a.line_off[line + 1];
-      const uint32_t len = le - ls >= a.eol_chars ? le - ls - a.eol_chars : 0u;  // chomp, main.go:535
+      uint32_t len;
+      if (a.fused) {
+        len = a.line_len[line];
+      } else {
+        const uint32_t le = a.line_off[line + 1];
+        len = le - ls >= a.eol_chars ? le - ls - a.eol_chars : 0u;  // chomp, main.go:535
+      }
       const uint32_t cend = ls + len;
       uint32_t found = 0, base = ls;
       // strings.Split(row, "\t") for the fixed columns, main.go:535
@@ -1122,14 +1405,18 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       uint32_t got = 0;
       if (sum) got = atomicAdd(threadIdx.x == 0 ? &a.counters->n_alleles : &a.counters->n_tasks, sum);
       s_base[threadIdx.x] = got;
+      // streaming path: the class maps of the extra tasks come from the same cursor k_stream used
+      if (threadIdx.x == 1) s_base[2] = (sum && a.fused && maps) ? atomicAdd(&a.counters->cmap_maps, sum) : 0u;
     }
     __syncthreads();
-    extra_base += n_lines + s_base[0];
-    task_base += n_lines + s_base[1];
+    uint32_t task_rank = task_base;  // this line's first extra task, counted inside the workgroup
     for (int k = 0; k < w; k++) {
       extra_base += s_wave[k][0];
-      task_base += s_wave[k][1];
+      task_rank += s_wave[k][1];
     }
+    extra_base += n_lines + s_base[0];
+    task_base = n_lines + s_base[1] + task_rank;
+    const uint32_t map_base = a.fused ? s_base[2] + task_rank : task_base;
 
     // ---- part 2: evaluate the ALT tokens, write records and scan tasks
     if (eval) {
@@ -1140,11 +1427,14 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       auto slot = [&](uint32_t j) -> uint32_t { return j == 0 ? line : extra_base + j - 1; };
 
       // With samples, the scan for ALT #1 always runs: it also settles len(record) == len(header).
+      // On the streaming path k_stream has already done it (results[line], line_cmap[line]).
       uint32_t cm0 = BVCF_NO_CMAP;
-      if (ns > 0) {
-        cm0 = put_task(a, line, line, 1, s_begin, cend, maps && (mode == 1 || mode == 2));
+      if (ns > 0 && !a.fused) {
+        cm0 = cmap_of(a, line, maps && (mode == 1 || mode == 2));
+        put_task(a, line, line, 1, s_begin, cend, cm0);
         task_written = true;
       }
+      if (ns > 0 && a.fused && maps) cm0 = a.line_cmap[line];
 
       uint32_t cur = 0, emitted = 0, tasks_used = 0;
       if (mode == 1 || mode == 2) {
@@ -1165,8 +1455,10 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
           if (!e.n) continue;
           uint32_t task = line, cm_off = cm0;
           if (ns > 0 && k > 0) {
-            task = task_base + tasks_used++;
-            cm_off = put_task(a, task, line, k + 1, s_begin, cend, maps);
+            task = task_base + tasks_used;
+            cm_off = cmap_of(a, map_base + tasks_used, maps);
+            put_task(a, task, line, k + 1, s_begin, cend, cm_off);
+            tasks_used++;
           }
           if (ns == 0) task = kNoTask;
           if (fits) {
@@ -1202,7 +1494,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
 #pragma nounroll
         for (uint32_t j = emitted > 1 ? emitted : 1; j < bound; j++) a.alleles[slot(j)].gt_task = kNoTask;
 #pragma nounroll
-      for (uint32_t j = tasks_used; j < want_task; j++) put_task(a, task_base + j, line, 0, cend, cend, false);
+      for (uint32_t j = tasks_used; j < want_task; j++) put_task(a, task_base + j, line, 0, cend, cend, BVCF_NO_CMAP);
       if (emitted) primary_written = true;
       if (fits) rec_first = extra_base;
       if (emitted == 0)
@@ -1229,7 +1521,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       L.pad[0] = L.pad[1] = 0;
       a.lines[line] = L;
       // every line owns task slot `line` and record slot `line`: mark the ones it did not fill
-      if (ns > 0 && !task_written) put_task(a, line, line, 0, cend, cend, false);
+      if (ns > 0 && !task_written) put_task(a, line, line, 0, cend, cend, BVCF_NO_CMAP);
       if (!primary_written && line < a.max_alleles) a.alleles[line].gt_task = kNoTask;
     }
   }

@@ -489,7 +489,7 @@ int bvcf_run_buffer(const bvcf_config *c, const uint8_t *vcf, size_t n, char **o
         l.append(msg + "\n");
         break;
       }
-      lines_in += res.n_lines;
+      lines_in += res.n_lines_seen;
       format_batch(c, &res, vcf + pos, nm, R.n_threads, o, l);
       pos += nb;
     }
@@ -678,7 +678,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       return;
     }
     in_flight.pop_front();
-    lines_in += res.n_lines;
+    lines_in += res.n_lines_seen;
     t0 = now_s();
     std::string *out = new std::string();
     Names nm{R.name_ptr.data(), R.name_len.data()};

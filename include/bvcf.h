@@ -102,7 +102,9 @@ typedef struct {
   uint32_t max_alleles;       /* slots of alleles[] (>= max_lines); 0 = 2 * max_lines + 1024 */
   uint64_t cmap_bytes;        /* class-map arena, one map per (line, ALT index); 0 = 1.5 maps per line */
   uint32_t n_slots;           /* batches in flight (0 = 2) */
-  uint32_t reserved1;
+  uint32_t path;              /* 0 = choose; 1 = census path (separate newline census, every line listed);
+                                 2 = streaming path when there are samples (lines found and ALT #1 scanned
+                                 in one pass; only lines with the right field count are listed) */
 } bvcf_params;
 
 /* one input line; 64 bytes */
@@ -175,6 +177,8 @@ typedef struct {
   uint64_t need_lines, need_alleles, need_cmap_bytes;
   float kernel_ms;           /* device time of the kernel chain for this batch (HIP events) */
   uint32_t reserved;
+  uint64_t n_lines_seen;     /* terminated lines in the block (>= n_lines: the streaming path does not list
+                                lines that fail len(record) == len(header), main.go:449) */
 } bvcf_result;
 
 /* ---- lifecycle ---- */
@@ -199,9 +203,13 @@ int bvcf_collect(bvcf_ctx *ctx, bvcf_result *r);
 /* device-resident variant used by benchmarks: runs the kernel chain `iters` times back to back, step i
  * on resident block i % n_blocks (each owning BVCF_DEVICE_PAD bytes past its nbytes), leaving the
  * results in device memory.  HIP events on the launch stream give, per step, the time of the whole
- * chain (chain_ms[i]) and of its dominant kernel, the genotype scan (gt_ms[i]).  counts receives
+ * chain (chain_ms[i]) and of its dominant kernel (gt_ms[i]): k_gt on the census path, k_stream on the
+ * streaming path.  counts receives
  * {lines, alleles, errs, class-map bytes, tasks} of the last step.  Returns after the last step
  * has finished. */
+/* 1 = census path, 2 = streaming path (see bvcf_params.path) */
+int bvcf_path(const bvcf_ctx *ctx);
+
 int bvcf_bench_device(bvcf_ctx *ctx, const void *const *dblocks, const size_t *nbytes, int n_blocks, int iters,
                       float *chain_ms, float *gt_ms, uint64_t counts[5]);
 

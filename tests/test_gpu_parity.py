@@ -11,6 +11,13 @@ import vcfgen
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["census", "streaming"])
+def bvcf_path(request, monkeypatch):
+    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`)"""
+    monkeypatch.setenv("BVCF_PATH", "1" if request.param == "census" else "2")
+    return request.param
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H8 = ["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO"]
 

@@ -8,6 +8,13 @@ import oracle_lib as orc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["census", "streaming"])
+def bvcf_path(request, monkeypatch):
+    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`)"""
+    monkeypatch.setenv("BVCF_PATH", "1" if request.param == "census" else "2")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def mods():
     import benchgen as bg
@@ -54,7 +61,7 @@ def test_full_size_properties_c3(mods):
     t, nbytes = bg.rows_device(cfg, 777_000_000, rows, pad=bv.DEVICE_PAD)
     stride = ((cfg.n_samples + 3) // 4 + 15) & ~15
     ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=1, max_lines=rows + 16,
-                 max_alleles=rows + 1024, cmap_bytes=(rows + 1024) * stride)
+                 max_alleles=rows + 1024, cmap_bytes=(rows + 1024 + 16 * 8192) * stride)
     ctx.submit_device(t.data_ptr(), nbytes)
     b = ctx.collect()
     assert len(b.lines) == rows and (b.lines["status"] == bv.LINE_OK).all()
