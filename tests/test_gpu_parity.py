@@ -222,3 +222,26 @@ def test_cli_large_stream(bv, golden_1kg):
     assert rows[0] == hdr and rows[-1] == b""
     assert sorted(rows[1:-1]) == want_sorted
     assert rows[1:-1] == orc.run(vcf)[1].split(b"\n")[:-1]
+
+
+@pytest.mark.parametrize("tile_kb", [4, 8])
+def test_streaming_tile_boundaries(bv, monkeypatch, tile_kb, bvcf_path, golden_1kg):
+    """tiny tiles: almost every line straddles a tile (and wave-run) boundary, many tiles hold no
+    line start at all, and 10 KB lines span several tiles"""
+    if bvcf_path != "streaming":
+        pytest.skip("tile logic only exists on the streaming path")
+    monkeypatch.setenv("BVCF_TILE_KB", str(tile_kb))
+    for seed, n_lines, n_samples, fmt_extra, weird in [(61, 500, 3, False, 0.05), (62, 400, 40, True, 0.05),
+                                                       (63, 300, 300, False, 0.01), (64, 120, 2504, False, 0.002),
+                                                       (65, 300, 1100, False, 0.0)]:
+        vcf = vcfgen.gen_vcf(seed, n_lines, n_samples, fmt_extra, weird)
+        both(bv, vcf, {"allow": ""})
+        both(bv, vcf, {"allow": ""}, max_batch_bytes=1 << 20)
+    vcf = golden_1kg[0]
+    both(bv, vcf[: vcf.index(b"\n", 30_000_000) + 1])
+    # line starts exactly on tile boundaries: rows padded to a power of two
+    h = vcfgen.header(2).encode()
+    row = b"1\t5\t.\tA\tG\t.\tPASS\t" + b"X" * (tile_kb * 1024 - 29) + b"\tGT\t0|1\t1|1\n"
+    assert len(row) == tile_kb * 1024
+    both(bv, h + row * 9, {"allow": ""})
+    both(bv, h + (row[:-1] + b"\t\n") * 3 + row * 2, {"allow": ""})
