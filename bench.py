@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=131072, help="rows per step per GPU")
     ap.add_argument("--blocks", type=int, default=4, help="distinct resident batches per GPU")
-    ap.add_argument("--profile", default="c3", choices=["c2", "c3", "c4"])
+    ap.add_argument("--profile", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
     ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
@@ -173,7 +173,8 @@ def main():
             "config": {
                 "workload": {"c2": "BASELINE configs[1]: sites-only, 1M biallelic SNPs, 0 samples",
                              "c3": "BASELINE configs[2]: 1KG-Phase3 chr1-shaped, 2504 samples, biallelic SNPs",
-                             "c4": "BASELINE configs[3]: 2504 samples, 20% multiallelic + 15% indels"}[args.profile],
+                             "c4": "BASELINE configs[3]: 2504 samples, 20% multiallelic + 15% indels",
+                             "c5": "not a BASELINE config: 2504 samples with GT:DP:GQ fields (general scan path)"}[args.profile],
                 "rows_per_step_per_gpu": args.rows, "resident_batches_per_gpu": args.blocks,
                 "bytes_per_row": mean_bytes / args.rows, "n_samples": ns,
                 "flags": "default (--allowFilter PASS,.), class maps on", "input": "resident in HBM",

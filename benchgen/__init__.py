@@ -11,6 +11,9 @@ PROFILES = {
     "c2": dict(n_samples=0, p_multi=0, p_indel=0, p_bad=0),
     "c3": dict(n_samples=2504, p_multi=0, p_indel=0, p_bad=0),
     "c4": dict(n_samples=2504, p_multi=2000, p_indel=1500, p_bad=100),
+    # not a BASELINE config: GATK-style sample fields "x|y:DP:GQ" (9-10 B, no fixed stride) — the
+    # general (ballot / prefix-sum) scan path
+    "c5": dict(n_samples=2504, p_multi=0, p_indel=0, p_bad=0, fmt_extra=1),
 }
 SEED = 20130502
 
@@ -53,7 +56,7 @@ def make_cfg(profile="c3", seed=SEED, **over):
     c.n_samples = p["n_samples"]
     c.p_multi, c.p_indel, c.p_bad = p["p_multi"], p["p_indel"], p["p_bad"]
     c.pos0 = 10177
-    c.reserved = int(p.get("align16", 0))
+    c.reserved = int(p.get("align16", 0)) | (2 if p.get("fmt_extra", 0) else 0)
     return c
 
 

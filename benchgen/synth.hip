@@ -182,14 +182,28 @@ HD uint32_t fixed_part(const SynthCfg &c, uint64_t r, uint8_t *buf, RowParams *r
     n = put_str(buf, n, ";P=");
     while ((n + (ns ? 4u : 1u)) % 16u) buf[n++] = 'X';
   }
-  if (ns) n = put_str(buf, n, "\tGT");
+  if (ns) n = put_str(buf, n, (c.reserved & 2u) ? "\tGT:DP:GQ" : "\tGT");
   return n;
 }
+
+// Extended FORMAT (reserved bit 1): "\tx|y:DP:GQ" with a 1- or 2-digit DP, so fields are 9 or 10
+// bytes and not on a fixed stride.  Sample s of row r is short iff (s + r) % 3 == 0.
+HD uint32_t ext_short_before(uint64_t r, uint32_t s) {
+  const uint32_t c0 = (uint32_t)((3u - (uint32_t)(r % 3u)) % 3u);  // first short sample
+  return s > c0 ? (s - c0 + 2u) / 3u : 0u;
+}
+HD uint32_t ext_offset(uint64_t r, uint32_t s) { return 10u * s - ext_short_before(r, s); }
+
+HD uint32_t samples_bytes(const SynthCfg &c, uint64_t r) {
+  return (c.reserved & 2u) ? ext_offset(r, c.n_samples) : 4u * c.n_samples;
+}
+
+HD void put_sample(const SynthCfg &c, uint64_t r, const RowParams &rp, uint32_t s, uint8_t *row_samples);
 
 HD uint32_t row_length(const SynthCfg &c, uint64_t r) {
   uint8_t buf[320];
   RowParams rp;
-  return fixed_part(c, r, buf, &rp) + 4u * c.n_samples + 1u;
+  return fixed_part(c, r, buf, &rp) + samples_bytes(c, r) + 1u;
 }
 
 // allele digit carried by haplotype hap of row r
@@ -198,6 +212,35 @@ HD uint8_t hap_allele(const SynthCfg &c, uint64_t r, const RowParams &rp, uint32
   const bool carrier = (uint32_t)x < rp.thr || hap == rp.h0;
   if (!carrier) return '0';
   return (uint8_t)('1' + (uint32_t)(x >> 40) % rp.n_alts);
+}
+
+HD void put_sample(const SynthCfg &c, uint64_t r, const RowParams &rp, uint32_t s, uint8_t *row_samples) {
+  if (!(c.reserved & 2u)) {
+    uint8_t *p = row_samples + 4u * s;
+    p[0] = '\t';
+    p[1] = hap_allele(c, r, rp, 2 * s);
+    p[2] = '|';
+    p[3] = hap_allele(c, r, rp, 2 * s + 1);
+    return;
+  }
+  uint8_t *p = row_samples + ext_offset(r, s);
+  const bool is_short = (s + r) % 3u == 0;
+  const uint64_t x = splitmix64(c.seed ^ (r * 0x2545F4914F6CDD1Dull) ^ s);
+  uint32_t n = 0;
+  p[n++] = '\t';
+  p[n++] = hap_allele(c, r, rp, 2 * s);
+  p[n++] = '|';
+  p[n++] = hap_allele(c, r, rp, 2 * s + 1);
+  p[n++] = ':';
+  if (is_short) {
+    p[n++] = (uint8_t)('0' + x % 10);
+  } else {
+    p[n++] = (uint8_t)('1' + x % 9);
+    p[n++] = (uint8_t)('0' + (x >> 8) % 10);
+  }
+  p[n++] = ':';
+  p[n++] = (uint8_t)('0' + (x >> 16) % 10);
+  p[n++] = (uint8_t)('0' + (x >> 24) % 10);
 }
 
 __global__ void k_lengths(SynthCfg c, uint64_t first, uint32_t n, int64_t *len) {
@@ -222,14 +265,8 @@ __global__ __launch_bounds__(256) void k_fill(SynthCfg c, uint64_t first, uint32
     const uint32_t fl = s_len;
     const RowParams rp = s_rp;
     for (uint32_t k = threadIdx.x; k < fl; k += blockDim.x) row[k] = s_fixed[k];
-    for (uint32_t s = threadIdx.x; s < c.n_samples; s += blockDim.x) {
-      uint8_t *p = row + fl + 4u * s;
-      p[0] = '\t';
-      p[1] = hap_allele(c, r, rp, 2 * s);
-      p[2] = '|';
-      p[3] = hap_allele(c, r, rp, 2 * s + 1);
-    }
-    if (threadIdx.x == 0) row[fl + 4u * c.n_samples] = '\n';
+    for (uint32_t s = threadIdx.x; s < c.n_samples; s += blockDim.x) put_sample(c, r, rp, s, row + fl);
+    if (threadIdx.x == 0) row[fl + samples_bytes(c, r)] = '\n';
     __syncthreads();
   }
 }
@@ -271,17 +308,12 @@ uint64_t synth_fill_host(const SynthCfg *c, uint64_t first, uint64_t n, uint8_t 
     RowParams rp;
     uint8_t fx[320];
     const uint32_t fl = fixed_part(*c, r, fx, &rp);
-    const uint64_t need = (uint64_t)fl + 4ull * c->n_samples + 1;
+    const uint32_t sb = samples_bytes(*c, r);
+    const uint64_t need = (uint64_t)fl + sb + 1;
     if (o + need > cap) return 0;
     memcpy(out + o, fx, fl);
-    uint8_t *p = out + o + fl;
-    for (uint32_t s = 0; s < c->n_samples; s++, p += 4) {
-      p[0] = '\t';
-      p[1] = hap_allele(*c, r, rp, 2 * s);
-      p[2] = '|';
-      p[3] = hap_allele(*c, r, rp, 2 * s + 1);
-    }
-    *p = '\n';
+    for (uint32_t s = 0; s < c->n_samples; s++) put_sample(*c, r, rp, s, out + o + fl);
+    out[o + fl + sb] = '\n';
     o += need;
   }
   return o;

@@ -374,8 +374,7 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
     if (kb >= 4 && kb <= (1u << 20)) c->tile_bytes = kb << 10;
   }
   uint32_t path = p->path;
-  if (path == 0)
-    if (const char *e = getenv("BVCF_PATH")) path = (uint32_t)atoi(e);  // test / tuning override
+  if (const char *e = getenv("BVCF_PATH")) path = (uint32_t)atoi(e);  // test / tuning override
   c->fused = c->n_samples > 0 && (path == 2 || (path == 0 && p->n_header_fields >= 256));
   c->tile_quota = c->tile_bytes / (p->n_header_fields - 1 + p->eol_chars) + 2;
   auto fail = [&](int rc) {

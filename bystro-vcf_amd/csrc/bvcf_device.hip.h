@@ -795,24 +795,31 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
   return true;
 }
 
-// Any sample region: delimiter masks per lane, wave prefix-sum for the sample index, byte-serial
-// field classification.  *n_tabs receives the number of TABs in [s_begin, cend).
+// Any sample region: delimiter masks per lane, wave prefix-sum for the sample index.  A field whose
+// first four bytes are "x<sep>y" + (':' | TAB) with x, y in {0-9, .} — the reference's own fast gate,
+// main.go:1063-1124, at any stride — is classified from registers (the lane's 16 bytes and the next
+// lane's first dword); everything else goes through the byte-serial restatement (classify_field).
+// *n_tabs receives the number of TABs in [s_begin, cend).
 __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, uint32_t cend, uint32_t ns,
                                        uint32_t allele, uint8_t *cmap, GtStats *st, uint32_t *n_tabs) {
   const int lane = lane_id();
   uint32_t a_nd = 1;
   for (uint32_t t = allele; t >= 10; t /= 10) a_nd++;
+  const uint32_t table = (allele <= 9 ? (1u << (2u * allele)) : 0u) | (3u << 28);
   if (cmap) {  // zero this allele's map, then OR classes in
     for (uint32_t i = lane * 4u; i < a.cmap_stride; i += kWave * 4u) *reinterpret_cast<uint32_t *>(cmap + i) = 0u;
     __builtin_amdgcn_s_waitcnt(0);  // stores retired before the atomics below touch the same words
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
   uint32_t ac = 0, an = 0, het = 0, hom = 0, miss = 0;
-  uint32_t tabs_before = 0;       // TABs in earlier chunks
-  uint32_t prev_last_tab = 1;     // byte before the region start behaves like a TAB (field start)
+  uint32_t tabs_before = 0;    // TABs in earlier chunks
+  uint32_t prev_last_tab = 1;  // the byte before the region start behaves like a TAB (field start)
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (s_begin < cend) v = load16(a.buf, s_begin + 16u * lane, a.cap);
   for (uint32_t base = s_begin; base < cend; base += kChunk) {
+    u32x4 nxt = {0u, 0u, 0u, 0u};
+    if (base + kChunk < cend) nxt = load16(a.buf, base + kChunk + 16u * lane, a.cap);  // in flight during this chunk
     const uint32_t off = base + 16u * lane;
-    u32x4 v = load16(a.buf, off, a.cap);
     const uint32_t valid = low_bits16((int)cend - (int)off);
     const uint32_t m = eq_mask16(v, '\t') & valid;
     uint32_t tot;
@@ -821,14 +828,36 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
     uint32_t carry = __shfl_up(m >> 15, 1, kWave) & 1u;
     if (lane == 0) carry = prev_last_tab;
     uint32_t starts = ((m << 1) | carry) & valid & 0xFFFFu;
+    // bytes 16..19 of this lane's window: the next lane's first dword (next chunk's for lane 63)
+    uint32_t d4 = __shfl_down(v.x, 1, kWave);
+    const uint32_t nx0 = __shfl(nxt.x, 0, kWave);
+    if (lane == kWave - 1) d4 = nx0;
     while (starts) {
       const uint32_t k = __ffs(starts) - 1;
       starts &= starts - 1;
       // sample index = TABs before this byte
       const uint32_t s = tabs_before + pre + __popc(m & ((1u << k) - 1u));
       if (s < ns) {
-        uint32_t cls, altc, gtc;
-        classify_field(a.buf, off + k, cend, allele, a_nd, &cls, &altc, &gtc);
+        uint32_t cls = 0, altc = 0, gtc = 0;
+        bool done = false;
+        if (off + k + 4u <= cend) {  // four real bytes: c0 c1 c2 c3
+          const uint32_t i = k >> 2;
+          const uint32_t lo = i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+          const uint32_t hi = i == 0 ? v.y : (i == 1 ? v.z : (i == 2 ? v.w : d4));
+          const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, k & 3u);
+          const uint32_t c1 = (w >> 8) & 0xFFu, c3 = w >> 24;
+          const uint32_t v0 = (w & 0xFFu) ^ '0', v2 = ((w >> 16) & 0xFFu) ^ '0';
+          const bool frame = (c1 == '|' || c1 == '/') && (c3 == ':' || c3 == '\t');
+          const bool plain = v0 < 32u && v2 < 32u && ((0x400003FFu >> v0) & (0x400003FFu >> v2) & 1u);
+          if (frame && plain) {
+            const uint32_t code = ((table >> ((v0 & 15u) * 2u)) & 3u) + ((table >> ((v2 & 15u) * 2u)) & 3u);
+            cls = code < 3u ? code : 3u;
+            gtc = cls == 3u ? 0u : 2u;
+            altc = cls == 3u ? 0u : cls;
+            done = true;
+          }
+        }
+        if (!done) classify_field(a.buf, off + k, cend, allele, a_nd, &cls, &altc, &gtc);
         ac += altc;
         an += gtc;
         het += cls == BVCF_CLS_HET;
@@ -837,9 +866,9 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
         if (cmap && cls) atomicOr(reinterpret_cast<uint32_t *>(cmap + (s >> 4) * 4u), cls << (2u * (s & 15u)));
       }
     }
-    // a trailing empty field (line content ends with a TAB) starts at cend: it is sample `tabs` too
     prev_last_tab = __shfl(m >> 15, kWave - 1, kWave) & 1u;
     tabs_before += tot;
+    v = nxt;
   }
   // a field that starts exactly at cend (empty last field) was not visited above
   if (lane == 0) {
@@ -853,7 +882,6 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
   st->n_miss = wave_sum(miss);
   *n_tabs = tabs_before;
 }
-
 
 // ------------------------------------------------------------------ k_gt: one wave per task
 

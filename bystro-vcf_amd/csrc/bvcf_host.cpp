@@ -310,7 +310,23 @@ struct Run {
   uint64_t max_batch = 0;
 };
 
-int open_ctx(Run &R, std::string *msg) {
+// Which device path suits this file: the streaming path shines when sample fields are the bare
+// 4-byte "x|y<TAB>" of a FORMAT == GT file (1000-Genomes style); files whose FORMAT carries more
+// sub-fields are scanned by the general path, for which the census path is the faster frame.
+uint32_t choose_path(const Run &R, const uint8_t *data, size_t n) {
+  if (R.pre.header.size() < 256) return 0;  // the library's own rule (census for narrow files)
+  // FORMAT column (index 8) of the first record
+  size_t pos = 0;
+  for (int tabs = 0; pos < n && tabs < 8; pos++) {
+    if (data[pos] == R.pre.eol_byte) return 0;
+    tabs += data[pos] == '\t';
+  }
+  size_t e = pos;
+  while (e < n && data[e] != '\t' && data[e] != R.pre.eol_byte) e++;
+  return (e - pos == 2 && data[pos] == 'G' && data[pos + 1] == 'T') ? 2u : 1u;
+}
+
+int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_data = 0) {
   if (R.pre.header.size() < 8) {
     // the reference indexes record[6] / record[7] unguarded: out of contract
     *msg = "Malformed header: fewer than 8 fields";
@@ -328,6 +344,7 @@ int open_ctx(Run &R, std::string *msg) {
   p.exclude_filter = R.cfg->exclude_filter;
   p.max_batch_bytes = R.max_batch;
   p.n_slots = 2;
+  p.path = data ? choose_path(R, data, n_data) : 0;
   int rc = bvcf_create(&R.ctx, &p);
   if (rc) {
     *msg = std::string("bvcf_create: ") + bvcf_last_error(nullptr);
@@ -462,7 +479,7 @@ int bvcf_run_buffer(const bvcf_config *c, const uint8_t *vcf, size_t n, char **o
     l = msg + "\n";
     rc = BVCF_E_FATAL;
   } else {
-    rc = open_ctx(R, &msg);
+    rc = open_ctx(R, &msg, vcf + R.pre.data_off, n - R.pre.data_off);
     if (rc) l = msg + "\n";
   }
   if (rc == BVCF_OK) {
@@ -707,7 +724,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
         fail(msg, BVCF_E_FATAL);
       } else {
         have_pre = true;
-        int r = open_ctx(R, &msg);
+        int r = open_ctx(R, &msg, b.buf + R.pre.data_off, b.fill > R.pre.data_off ? b.fill - R.pre.data_off : 0);
         if (r) fail(msg, r);
         if (!done && R.pre.header.size() == 9)
           log.append("Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n");

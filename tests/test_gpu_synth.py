@@ -22,7 +22,7 @@ def mods():
     return bg, bv
 
 
-@pytest.mark.parametrize("profile,first,n", [("c2", 0, 5000), ("c3", 123456, 600), ("c4", 999, 600)])
+@pytest.mark.parametrize("profile,first,n", [("c2", 0, 5000), ("c3", 123456, 600), ("c4", 999, 600), ("c5", 77, 400)])
 def test_device_rows_equal_host_rows(mods, profile, first, n):
     bg, bv = mods
     cfg = bg.make_cfg(profile)
@@ -36,6 +36,7 @@ def test_device_rows_equal_host_rows(mods, profile, first, n):
     ("c2", 20000, {}),
     ("c3", 3000, {}),
     ("c4", 3000, {"keepId": True, "keepInfo": True}),
+    ("c5", 2000, {}),
 ])
 def test_parity_on_bench_shapes(mods, profile, n, cfgd):
     bg, bv = mods
