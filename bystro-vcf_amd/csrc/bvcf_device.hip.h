@@ -1019,6 +1019,7 @@ __device__ __forceinline__ uint32_t cmap_of(const KernelArgs &a, uint32_t mi, bo
 // ------------------------------------------------------------------ k_stream: one wave per tile
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kDeferred = 0xFFFFFFFEu;  // StreamEntry.n_miss / GtResult.n_fields: scan left to k_gt
 
 // first terminator byte at a position in [from, limit), or kNone; 4 KiB in flight per step
 __device__ inline uint32_t find_eol(const KernelArgs &a, uint32_t from, uint32_t limit) {
@@ -1168,7 +1169,10 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
         }
       }
     }
+    bool deferred = false;
     if (cend == kNone) {
+      // not a regular "x|y<TAB>" region: only find where the line ends here; its ALT #1 scan is
+      // left to k_gt (k_head turns the entry into a task), which also settles its field count
       const uint32_t e = find_eol(a, s_begin, nb);
       if (e == kNone) break;  // unterminated tail
       if (e + 1 < s_begin + a.eol_chars) {
@@ -1178,13 +1182,14 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
         continue;
       }
       cend = e + 1 - a.eol_chars;
-      uint32_t tabs;
-      gt_scan_general(a, s_begin, cend, ns, 1, cm, &st, &tabs);
-      n_fields = tabs + 1;
+      deferred = true;
     }
     seen++;
-    if (9u + n_fields == a.n_header && n_local >= a.tile_quota && lane == 0) a.counters->pad[0] = 1;  // cannot happen
-    if (9u + n_fields == a.n_header && n_local < a.tile_quota) {
+    // a line shorter than n_header - 1 bytes cannot have n_header fields: never listed (this is
+    // what bounds the per-tile quota)
+    const bool listed = deferred ? (cend - p + 1u >= a.n_header) : (9u + n_fields == a.n_header);
+    if (listed && n_local >= a.tile_quota && lane == 0) a.counters->pad[0] = 1;  // cannot happen
+    if (listed && n_local < a.tile_quota) {
       if (lane == 0) {
         StreamEntry en;
         en.ls = p;
@@ -1193,7 +1198,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
         en.an = st.an;
         en.n_het = st.n_het;
         en.n_hom = st.n_hom;
-        en.n_miss = st.n_miss;
+        en.n_miss = deferred ? kDeferred : st.n_miss;
         en.cmap_off = cm_off;
         a.entries[(size_t)tile * a.tile_quota + n_local] = en;
       }
@@ -1232,7 +1237,7 @@ __global__ __launch_bounds__(kWgThreads) void k_order(KernelArgs a) {
       r.n_het = en.n_het;
       r.n_hom = en.n_hom;
       r.n_miss = en.n_miss;
-      r.n_fields = a.n_header - 9u;
+      r.n_fields = en.n_miss == kDeferred ? kDeferred : a.n_header - 9u;
       r.pad[0] = r.pad[1] = 0;
       a.results[g] = r;
     }
@@ -1462,7 +1467,13 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
         put_task(a, line, line, 1, s_begin, cend, cm0);
         task_written = true;
       }
-      if (ns > 0 && a.fused && maps) cm0 = a.line_cmap[line];
+      if (ns > 0 && a.fused) {
+        if (maps) cm0 = a.line_cmap[line];
+        if (line < a.max_tasks && a.results[line].n_fields == kDeferred) {  // k_stream left the scan to k_gt
+          put_task(a, line, line, 1, s_begin, cend, cm0);
+          task_written = true;
+        }
+      }
 
       uint32_t cur = 0, emitted = 0, tasks_used = 0;
       if (mode == 1 || mode == 2) {
