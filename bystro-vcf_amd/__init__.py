@@ -18,7 +18,7 @@ except ImportError:  # the library then binds to /opt/rocm's runtime through its
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbvcf.so")
+LIB_PATH = os.environ.get("BVCF_LIB") or os.path.join(_HERE, "libbvcf.so")  # BVCF_LIB: A/B another build
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

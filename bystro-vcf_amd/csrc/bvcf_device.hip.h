@@ -131,6 +131,20 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+// three per-lane counts -> wave totals; two of them share a register while they fit 16 bits
+__device__ __forceinline__ void wave_sum3(uint32_t a, uint32_t b, uint32_t c, uint32_t limit, uint32_t *sa,
+                                          uint32_t *sb, uint32_t *sc) {
+  if (limit < 65536u) {
+    const uint32_t ab = wave_sum(a | (b << 16));
+    *sa = ab & 0xFFFFu;
+    *sb = ab >> 16;
+  } else {
+    *sa = wave_sum(a);
+    *sb = wave_sum(b);
+  }
+  *sc = wave_sum(c);
+}
+
 // exclusive prefix sum over the 64 lanes; *total receives the wave sum
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) {
   uint32_t inc = v;
@@ -661,12 +675,17 @@ __device__ inline void classify_field(const uint8_t *buf, uint32_t p, uint32_t c
 // 14 ('.') -> 3): cls = min(code(b0) + code(b2), 3) gives none/het/hom/missing (main.go:1063-1124).
 constexpr int kFastGroup = 5;  // chunks per buffer; two buffers => 10 KiB in flight per wave
 
+// v_bfe_u32 and the shifts use only the low 5 bits of their offset operand, so (t << 1) selects entry
+// t & 15 of the 2-bit table for byte 0, and (t >> 15) entry (t >> 16) & 15 for byte 2 (bit 0 of that
+// offset is bit 7 of the separator xor, zero whenever the frame test passes).
 __device__ __forceinline__ uint32_t fast_codes(uint32_t t, uint32_t table) {
-  const uint32_t s0 = (t << 1) & 0x1Eu;
-  const uint32_t s2 = (t >> 15) & 0x1Eu;
-  const uint32_t k = ((table >> s0) & 3u) + ((table >> s2) & 3u);
+  const uint32_t k = __builtin_amdgcn_ubfe(table, t << 1, 2u) + __builtin_amdgcn_ubfe(table, t >> 15, 2u);
   return k < 3u ? k : 3u;
 }
+
+// both allele bytes in {0-9, .}: bit (byte ^ '0') of 0x400003FF (the bytes are < 32 when the frame
+// test passes; the hardware shift takes the amount mod 32)
+__device__ __forceinline__ uint32_t fast_valid(uint32_t t) { return (0x400003FFu >> t) & (0x400003FFu >> (t >> 16)); }
 
 struct FastAcc {
   uint32_t bad, ok, het, hom, miss;
@@ -723,7 +742,7 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       acc.bad |= t[q] & 0xFFE0FFE0u;
-      acc.ok &= (0x400003FFu >> (t[q] & 31u)) & (0x400003FFu >> ((t[q] >> 16) & 31u));
+      acc.ok &= fast_valid(t[q]);
       byte |= fast_codes(t[q], table) << (2 * q);
     }
     const uint32_t lo = byte & 0x55u, hi = (byte >> 1) & 0x55u;
@@ -787,9 +806,7 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
       if (c0 + 3 * kFastGroup + g < n_chunks) vb[g] = fetch(c0 + 3 * kFastGroup + g);
   }
   if (__any(acc.bad != 0 || !(acc.ok & 1u))) return false;
-  st->n_het = wave_sum(acc.het);
-  st->n_hom = wave_sum(acc.hom);
-  st->n_miss = wave_sum(acc.miss);
+  wave_sum3(acc.het, acc.hom, acc.miss, ns, &st->n_het, &st->n_hom, &st->n_miss);
   st->ac = st->n_het + 2u * st->n_hom;
   st->an = 2u * (ns - st->n_miss);
   return true;
@@ -1049,6 +1066,72 @@ __device__ __forceinline__ uint32_t nth_bit(uint32_t m, uint32_t k) {
   return __ffs(m) - 1;
 }
 
+// head of a line from one window of bytes: position of the 9th TAB, or kNone with *eolp = first
+// terminator seen (kNone if none).  `v` holds 16 B per lane starting at `base`; lanes >= n_lanes hold
+// nothing.  found_io carries the TAB count across windows.
+__device__ __forceinline__ uint32_t head_window(const KernelArgs &a, u32x4 v, uint32_t base, uint32_t n_lanes,
+                                                uint32_t *found_io, uint32_t *eolp) {
+  const int lane = lane_id();
+  const uint32_t need = 9;
+  const uint32_t off = base + 16u * lane;
+  uint32_t valid = low_bits16((int)a.nbytes - (int)off);
+  if ((uint32_t)lane >= n_lanes) valid = 0;
+  const uint32_t me = eq_mask16(v, a.eol_byte) & valid;
+  uint32_t mt = eq_mask16(v, '\t') & valid;
+  const unsigned long long be = __ballot(me != 0);
+  uint32_t eol_here = kNone;
+  if (be) {
+    const int src = __ffsll((long long)be) - 1;
+    eol_here = __builtin_amdgcn_readfirstlane(__shfl(off + __ffs(me) - 1, src, kWave));
+    mt &= low_bits16((int)eol_here - (int)off);  // TABs of this line only
+  }
+  uint32_t tot;
+  const uint32_t cnt = __popc(mt);
+  const uint32_t prefix = wave_excl_scan(cnt, &tot);
+  if (*found_io + tot >= need) {
+    const uint32_t target = need - 1 - *found_io;
+    const bool mine = prefix <= target && target < prefix + cnt;
+    const unsigned long long bm = __ballot(mine);
+    const int src = __ffsll((long long)bm) - 1;
+    const uint32_t pos = mine ? off + nth_bit(mt, target - prefix) : 0u;
+    return __builtin_amdgcn_readfirstlane(__shfl(pos, src, kWave));
+  }
+  *found_io += tot;
+  *eolp = eol_here;
+  return kNone;
+}
+
+// The same for a 256 B window held by lanes 0..15 (the prefetched head of the next line): a DPP row
+// scan replaces the 64-lane shuffle scan, and a terminator anywhere in the window simply declines
+// (returns kNone: such a line is shorter than 256 B and goes through the general head scan).
+__device__ __forceinline__ uint32_t head_window16(const KernelArgs &a, u32x4 v, uint32_t base) {
+  const int lane = lane_id();
+  const uint32_t need = 9;
+  const uint32_t off = base + 16u * lane;
+  uint32_t valid = low_bits16((int)a.nbytes - (int)off);
+  if (lane >= 16) valid = 0;
+  const uint32_t e4 = a.eol_byte * 0x01010101u;
+  const uint32_t eol_any = (zero_bytes(v.x ^ e4) | zero_bytes(v.y ^ e4) | zero_bytes(v.z ^ e4) | zero_bytes(v.w ^ e4));
+  if (__ballot(eol_any != 0 && lane < 16)) return kNone;
+  const uint32_t mt = eq_mask16(v, '\t') & valid;
+  const uint32_t cnt = __popc(mt);
+  // inclusive scan inside the row of 16 lanes: row_shr:1,2,4,8 with zero fill
+  uint32_t x = cnt;
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+  const uint32_t prefix = x - cnt;
+  const bool mine = lane < 16 && prefix < need && need <= x;  // the 9th TAB is one of this lane's
+  const unsigned long long bm = __ballot(mine);
+  if (!bm) return kNone;
+  const int src = __ffsll((long long)bm) - 1;
+  const uint32_t pos = mine ? off + nth_bit(mt, need - 1 - prefix) : 0u;
+  return __builtin_amdgcn_readfirstlane(__shfl(pos, src, kWave));
+}
+
+constexpr int kPipeChunks = 10;  // chunk registers of the cross-line pipeline: lines of <= 2560 samples
+
 __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
   uint8_t *stage = s_stage[threadIdx.x >> 6];
@@ -1058,8 +1141,11 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   const uint32_t ns = a.n_samples;
   const uint32_t nb = a.nbytes;
   const uint32_t T = a.tile_bytes;
-  const uint32_t need = 9;  // the streaming path is only used with samples
   const bool maps = a.want_cmap != 0;
+  const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;  // of a regular line
+  const uint32_t table1 = (1u << 2) | (3u << 28);              // ALT #1
+  // cross-line pipelining needs the whole line in the chunk registers and the in-scan terminator check
+  const bool pipelined = n_chunks <= (uint32_t)kPipeChunks && a.eol_chars == 1;
   uint32_t cm_next = 0, cm_end = 0;  // this wave's private block of class-map slots
   uint32_t seen = 0;                 // terminated lines this wave walked over
 
@@ -1079,50 +1165,60 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
       p = q == kNone ? kNone : q + 1;
     }
   }
-  u32x4 hv = {0u, 0u, 0u, 0u};  // first 256 B of the next line, requested with the current line's scan
-  uint32_t hv_pos = kNone;
-  while (p != kNone && p < r1) {
-    while (p >= (tile + 1) * T) {  // p moved into a later tile of the run
+
+  // class-map slot for the next listed line
+  auto map_slot = [&]() -> uint32_t {
+    if (!maps) return BVCF_NO_CMAP;
+    if (cm_next == cm_end) {
+      uint32_t b = 0;
+      if (lane == 0) b = atomicAdd(&a.counters->cmap_maps, 16u);
+      cm_next = __builtin_amdgcn_readfirstlane(b);
+      cm_end = cm_next + 16u;
+    }
+    return cmap_of(a, cm_next, true);
+  };
+  // list a line (in input order) in the tile it starts in
+  auto commit = [&](uint32_t ls, uint32_t cend, const GtStats &st, bool deferred, uint32_t cm_off) {
+    while (ls >= (tile + 1) * T) {  // ls moved into a later tile of the run
       if (lane == 0) a.census[tile] = n_local;
       tile++;
       n_local = 0;
     }
+    if (n_local >= a.tile_quota) {
+      if (lane == 0) a.counters->pad[0] = 1;  // cannot happen: see tile_quota
+      return;
+    }
+    if (lane == 0) {
+      StreamEntry en;
+      en.ls = ls;
+      en.len = cend - ls;
+      en.ac = st.ac;
+      en.an = st.an;
+      en.n_het = st.n_het;
+      en.n_hom = st.n_hom;
+      en.n_miss = deferred ? kDeferred : st.n_miss;
+      en.cmap_off = cm_off;
+      a.entries[(size_t)tile * a.tile_quota + n_local] = en;
+    }
+    n_local++;
+    if (maps) cm_next++;
+  };
+  auto chunk_at = [&](uint32_t s_begin, uint32_t c) -> u32x4 {
+    const uint32_t off = min(s_begin + c * kChunk + 16u * lane, a.cap - 16u);
+    return *reinterpret_cast<const u32x4_u *>(a.buf + off);
+  };
+  auto finish_stats = [&](const FastAcc &acc, GtStats *st) {
+    wave_sum3(acc.het, acc.hom, acc.miss, ns, &st->n_het, &st->n_hom, &st->n_miss);
+    st->ac = st->n_het + 2u * st->n_hom;
+    st->an = 2u * (ns - st->n_miss);
+  };
+
+  while (p != kNone && p < r1) {
     // ---- fixed columns: the 9th TAB, or the terminator if it comes first (main.go:535)
     uint32_t found = 0, tab9 = kNone, eolp = kNone;
-    for (uint32_t base = p; base < nb;) {
-      const bool pre = base == hv_pos;  // 16 lanes were fetched ahead: a 256 B window
-      const uint32_t span = pre ? 256u : kChunk;
-      const uint32_t off = base + 16u * lane;
-      u32x4 v = pre ? hv : load16(a.buf, off, a.cap);
-      uint32_t valid = low_bits16((int)nb - (int)off);
-      if (pre && lane >= 16) valid = 0;
-      const uint32_t me = eq_mask16(v, a.eol_byte) & valid;
-      uint32_t mt = eq_mask16(v, '\t') & valid;
-      const unsigned long long be = __ballot(me != 0);
-      uint32_t eol_here = kNone;
-      if (be) {
-        const int src = __ffsll((long long)be) - 1;
-        eol_here = __builtin_amdgcn_readfirstlane(__shfl(off + __ffs(me) - 1, src, kWave));
-        mt &= low_bits16((int)eol_here - (int)off);  // TABs of this line only
-      }
-      uint32_t tot;
-      const uint32_t cnt = __popc(mt);
-      const uint32_t prefix = wave_excl_scan(cnt, &tot);
-      if (found + tot >= need) {
-        const uint32_t target = need - 1 - found;
-        const bool mine = prefix <= target && target < prefix + cnt;
-        const unsigned long long bm = __ballot(mine);
-        const int src = __ffsll((long long)bm) - 1;
-        const uint32_t pos = mine ? off + nth_bit(mt, target - prefix) : 0u;
-        tab9 = __builtin_amdgcn_readfirstlane(__shfl(pos, src, kWave));
-        break;
-      }
-      found += tot;
-      if (eol_here != kNone) {
-        eolp = eol_here;
-        break;
-      }
-      base += span;
+    for (uint32_t base = p; base < nb; base += kChunk) {
+      tab9 = head_window(a, load16(a.buf, base + 16u * lane, a.cap), base, kWave, &found, &eolp);
+      if (tab9 != kNone || eolp != kNone) break;
     }
     if (tab9 == kNone) {
       if (eolp == kNone) break;  // unterminated tail of the block: dropped (main.go:354-358)
@@ -1130,82 +1226,114 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
       p = eolp + 1;
       continue;
     }
-    const uint32_t s_begin = tab9 + 1;
-
-    // ---- a class-map slot for this line (kept only if the line is listed)
-    uint8_t *cm = nullptr;
-    uint32_t cm_off = BVCF_NO_CMAP;
-    if (maps) {
-      if (cm_next == cm_end) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&a.counters->cmap_maps, 16u);
-        cm_next = __builtin_amdgcn_readfirstlane(b);
-        cm_end = cm_next + 16u;
-      }
-      cm_off = cmap_of(a, cm_next, true);
-      if (cm_off != BVCF_NO_CMAP) cm = a.cmap + cm_off;
-    }
-
-    // ---- ALT #1 scan; a regular region also tells where the line ends
+    uint32_t s_begin = tab9 + 1;
     GtStats st = {0, 0, 0, 0, 0};
-    uint32_t cend = kNone, n_fields = 0;
     const unsigned long long pred = (unsigned long long)s_begin + 4ull * ns - 1ull;  // predicted content end
-    hv_pos = kNone;
-    if (pred + a.eol_chars <= nb) {
+    uint32_t cend = kNone;
+
+    if (pred + a.eol_chars <= nb && pipelined) {
+      // ================= cross-line pipeline over consecutive regular lines =================
+      // A = the line being scanned (chunks in va), B = the next one: its head window (hv) is
+      // requested before A's chunks, parsed as soon as A starts, and every chunk register is
+      // re-issued for B right after A's chunk in it has been processed.
+      uint32_t pA = p, sA = s_begin, peA = (uint32_t)pred;
+      u32x4 va[kPipeChunks];
+      u32x4 hv = {0u, 0u, 0u, 0u};
+      bool hv_ok = peA + 1u < r1;  // B starts inside this wave's run
+      if (hv_ok && lane < 16) hv = load16(a.buf, peA + 1u + 16u * lane, a.cap);
+#pragma unroll
+      for (int g = 0; g < kPipeChunks; g++)
+        if ((uint32_t)g < n_chunks) va[g] = chunk_at(sA, g);
+      for (;;) {
+        // ---- B's head from the 256 B window
+        uint32_t sB = 0, peB = 0;
+        bool b_ok = false;
+        if (hv_ok) {
+          const uint32_t t9 = head_window16(a, hv, peA + 1u);
+          if (t9 != kNone) {
+            sB = t9 + 1;
+            const unsigned long long pb = (unsigned long long)sB + 4ull * ns - 1ull;
+            if (pb + 1ull <= nb) {
+              peB = (uint32_t)pb;
+              b_ok = true;
+            }
+          }
+        }
+        const bool hvc_ok = b_ok && peB + 1u < r1;
+        if (hvc_ok && lane < 16) hv = load16(a.buf, peB + 1u + 16u * lane, a.cap);  // C's head, ahead of B's chunks
+        // ---- scan A, re-issuing each register for B
+        const uint32_t cmA = map_slot();
+        uint8_t *cm = cmA != BVCF_NO_CMAP ? a.cmap + cmA : nullptr;
+        if (cm) zero_stage(stage);
+        FastAcc acc = {0, 1, 0, 0, 0};
+        const uint32_t sep = (__builtin_amdgcn_readfirstlane(va[0].x) >> 8) & 0xFFu;
+        if (sep != '|' && sep != '/') acc.bad = 1;
+        const uint32_t kref = 0x09300030u | (sep << 8);
+        const uint32_t term_xor = (a.eol_byte ^ 0x09u) << 24;
+#pragma unroll
+        for (int g = 0; g < kPipeChunks; g++) {
+          if ((uint32_t)g < n_chunks) {
+            fast_chunk(va[g], g, n_chunks, ns, kref, table1, cm, stage, a.cmap_stride, term_xor, acc);
+            if (b_ok) va[g] = chunk_at(sB, g);
+          }
+        }
+        if (__any(acc.bad != 0 || !(acc.ok & 1u))) {
+          // A is not regular after all: B was predicted from a wrong line end.  Leave the
+          // pipeline (the loads in flight are simply dropped) and take A the slow way.
+          s_begin = sA;
+          p = pA;
+          break;
+        }
+        finish_stats(acc, &st);
+        seen++;
+        commit(pA, peA, st, false, cmA);
+        p = peA + 1u;
+        if (!b_ok) {
+          s_begin = kNone;  // nothing pending: rediscover from p
+          break;
+        }
+        pA = peA + 1u;
+        sA = sB;
+        peA = peB;
+        hv_ok = hvc_ok;
+      }
+      if (s_begin == kNone) continue;
+      // fall through with (p, s_begin) of the line that failed the regular scan
+    } else if (pred + a.eol_chars <= nb) {
+      // ---- one line at a time (more than kPipeChunks chunks per line, or "\r\n")
       const uint32_t pe = (uint32_t)pred;
-      // "\n": the terminator is the byte after the last sample and is checked by the scan itself;
-      // "\r\n": it is one byte further, look at it here
       bool term = true;
       if (a.eol_chars == 2) term = a.buf[pe + 1] == a.eol_byte && a.buf[pe] != a.eol_byte;
       if (term) {
-        // the next line's head travels with this line's scan loads
-        hv_pos = pe + a.eol_chars;
-        if (lane < 16) hv = load16(a.buf, hv_pos + 16u * lane, a.cap);
+        const uint32_t cm_off = map_slot();
+        uint8_t *cm = cm_off != BVCF_NO_CMAP ? a.cmap + cm_off : nullptr;
         if (gt_scan_fast(a, s_begin, ns, 1, cm, stage, a.eol_chars == 1, &st)) {
-          cend = pe;
-          n_fields = ns;
-        } else {
-          hv_pos = kNone;
+          seen++;
+          commit(p, pe, st, false, cm_off);
+          p = pe + a.eol_chars;
+          continue;
         }
       }
     }
-    bool deferred = false;
-    if (cend == kNone) {
-      // not a regular "x|y<TAB>" region: only find where the line ends here; its ALT #1 scan is
-      // left to k_gt (k_head turns the entry into a task), which also settles its field count
+
+    // ---- not a regular "x|y<TAB>" region: only find where the line ends here; its ALT #1 scan is
+    // left to k_gt (k_head turns the entry into a task), which also settles its field count
+    {
       const uint32_t e = find_eol(a, s_begin, nb);
       if (e == kNone) break;  // unterminated tail
+      seen++;
       if (e + 1 < s_begin + a.eol_chars) {
         // chomping numChars bytes (main.go:535) eats the 9th TAB: at most 9 fields remain
-        seen++;
         p = e + 1;
         continue;
       }
       cend = e + 1 - a.eol_chars;
-      deferred = true;
+      // a line shorter than n_header - 1 bytes cannot have n_header fields: never listed (this
+      // is what bounds the per-tile quota)
+      const GtStats none = {0, 0, 0, 0, 0};
+      if (cend - p + 1u >= a.n_header) commit(p, cend, none, true, map_slot());
+      p = cend + a.eol_chars;
     }
-    seen++;
-    // a line shorter than n_header - 1 bytes cannot have n_header fields: never listed (this is
-    // what bounds the per-tile quota)
-    const bool listed = deferred ? (cend - p + 1u >= a.n_header) : (9u + n_fields == a.n_header);
-    if (listed && n_local >= a.tile_quota && lane == 0) a.counters->pad[0] = 1;  // cannot happen
-    if (listed && n_local < a.tile_quota) {
-      if (lane == 0) {
-        StreamEntry en;
-        en.ls = p;
-        en.len = cend - p;
-        en.ac = st.ac;
-        en.an = st.an;
-        en.n_het = st.n_het;
-        en.n_hom = st.n_hom;
-        en.n_miss = deferred ? kDeferred : st.n_miss;
-        en.cmap_off = cm_off;
-        a.entries[(size_t)tile * a.tile_quota + n_local] = en;
-      }
-      n_local++;
-      if (maps) cm_next++;
-    }
-    p = cend + a.eol_chars;
   }
   for (; tile < tile_hi; tile++) {  // the rest of the run has no line starts
     if (lane == 0) a.census[tile] = n_local;

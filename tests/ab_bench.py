@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Same-box A/B of two libbvcf builds (not a test): alternates BVCF_LIB between the given .so files
+and prints per-build medians of the dominant kernel and of the chain.
+usage: python tests/ab_bench.py libA.so libB.so [rounds] [-- extra bench.py args]"""
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+args = sys.argv[1:]
+extra = []
+if "--" in args:
+    k = args.index("--")
+    args, extra = args[:k], args[k + 1:]
+libs = args[:2]
+rounds = int(args[2]) if len(args) > 2 else 4
+res = {l: [] for l in libs}
+for r in range(rounds):
+    for l in libs:
+        env = dict(os.environ, BVCF_LIB=os.path.abspath(l))
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2",
+                                       "--no-cpu-baseline"] + extra, env=env, stderr=subprocess.DEVNULL)
+        d = json.loads(out.decode().strip().splitlines()[-1])
+        res[l].append((d["roofline"]["mean_launch_ms"], d["chain"]["mean_ms"]))
+for l in libs:
+    k = [x[0] for x in res[l]]
+    c = [x[1] for x in res[l]]
+    print("%-40s kernel med %.4f ms (min %.4f)  chain med %.4f ms (min %.4f)" % (
+        os.path.basename(l), statistics.median(k), min(k), statistics.median(c), min(c)))
