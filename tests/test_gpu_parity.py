@@ -113,6 +113,9 @@ def test_example_query_vcf(bv):
     (1, 400, 0, False, 0.05), (2, 400, 1, False, 0.1), (3, 300, 7, False, 0.1), (4, 300, 64, False, 0.02),
     (5, 200, 255, False, 0.02), (6, 200, 256, False, 0.0), (7, 200, 257, False, 0.01), (8, 150, 1000, False, 0.002),
     (9, 200, 33, True, 0.05), (10, 100, 300, True, 0.01), (11, 60, 2504, False, 0.001), (12, 300, 5, False, 0.5),
+    # > 2 560 samples: lines no longer fit the streaming kernel's chunk registers (one line at a time);
+    # > 16 384 samples: the class map is staged and flushed in several 4 KiB windows
+    (13, 40, 3000, False, 0.001), (14, 14, 17000, False, 0.0003), (15, 10, 33000, False, 0.0),
 ])
 def test_fuzz_parity(bv, seed, n_lines, n_samples, fmt_extra, weird):
     vcf = vcfgen.gen_vcf(seed, n_lines, n_samples, fmt_extra, weird)
