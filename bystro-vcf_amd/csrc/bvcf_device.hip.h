@@ -1415,24 +1415,36 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
     __syncthreads();  // LDS of the previous step is free (also covers the s_ft copy)
 
     // ================= phase T: 16 lanes per line =================
+    // lane gl of a group fetches the offsets of the group's round-gl line, so the 16 rounds' offsets
+    // are in flight together; the first window of round r + 1 is requested before round r is parsed
+    uint32_t my_ls = 0, my_len = 0;
+    {
+      const uint32_t l = line0 + (uint32_t)gl * kGroupsPerWg + g;
+      if (l < n_lines) {
+        my_ls = a.line_off[l];
+        if (a.fused) {
+          my_len = a.line_len[l];
+        } else {
+          const uint32_t le = a.line_off[l + 1];
+          my_len = le - my_ls >= a.eol_chars ? le - my_ls - a.eol_chars : 0u;  // chomp, main.go:535
+        }
+      }
+    }
+    u32x4 v_next = load16(a.buf, __shfl(my_ls, 0, kGroup) + 16u * gl, a.cap);
     for (uint32_t r = 0; r < kLinesPerStep / kGroupsPerWg; r++) {
       const uint32_t ll = r * kGroupsPerWg + g;
       const uint32_t line = line0 + ll;
+      const uint32_t ls = __shfl(my_ls, r, kGroup);
+      const uint32_t len = __shfl(my_len, r, kGroup);
+      const u32x4 v_first = v_next;
+      if (r + 1 < kLinesPerStep / kGroupsPerWg) v_next = load16(a.buf, __shfl(my_ls, r + 1, kGroup) + 16u * gl, a.cap);
       if (line >= n_lines) continue;
-      const uint32_t ls = a.line_off[line];
-      uint32_t len;
-      if (a.fused) {
-        len = a.line_len[line];
-      } else {
-        const uint32_t le = a.line_off[line + 1];
-        len = le - ls >= a.eol_chars ? le - ls - a.eol_chars : 0u;  // chomp, main.go:535
-      }
       const uint32_t cend = ls + len;
       uint32_t found = 0, base = ls;
       // strings.Split(row, "\t") for the fixed columns, main.go:535
       for (; base < cend && found < need; base += kWindow) {
         const uint32_t off = base + 16u * gl;
-        u32x4 v = load16(a.buf, off, a.cap);
+        u32x4 v = base == ls ? v_first : load16(a.buf, off, a.cap);
         const uint32_t rel = off - ls;
         if (rel < kHeadStage) {
           uint32_t *row = &s_head[ll * kHeadRow + rel / 4];
