@@ -952,7 +952,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
 constexpr int kGroup = 16;                       // lanes per line in k_head
 constexpr int kGroupsPerWg = kWgThreads / kGroup;
 constexpr uint32_t kWindow = kGroup * 16;        // bytes per group step
-constexpr uint32_t kHeadStage = 192;             // line-head bytes kept in LDS for the serial phase
+constexpr uint32_t kHeadStage = 128;             // line-head bytes kept in LDS for the serial phase
 
 __device__ __forceinline__ int glane() { return threadIdx.x & (kGroup - 1); }
 
