@@ -1,0 +1,180 @@
+// bvcf_common.hip.h — shared constants, batch structures, wave/byte helpers
+// Part of the gfx950 device code of libbvcf; see bvcf_device.hip.h for the kernel map.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bvcf.h"
+
+namespace bvcf_dev {
+
+
+constexpr int kWave = 64;
+constexpr int kWavesPerWg = 4;
+constexpr int kWgThreads = kWave * kWavesPerWg;
+constexpr uint32_t kChunk = 1024;      // bytes per wave-iteration (16 B x 64 lanes)
+constexpr uint32_t kScanGroup = 1024;  // census entries per level-1 scan group
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+
+// FILTER allow / deny sets (config.allowedFilters / excludedFilters, main.go:78-79)
+struct FilterTable {
+  uint32_t allow_nil, allow_n;
+  uint32_t deny_nil, deny_n;
+  uint16_t allow_off[32], allow_len[32];
+  uint16_t deny_off[32], deny_len[32];
+  uint8_t text[2048];
+};
+
+// device-resident batch state
+struct BatchCounters {
+  uint32_t n_lines;      // lines listed in lines[] (may exceed max_lines)
+  uint32_t n_alleles;    // bvcf_allele slots requested past the first n_lines
+  uint32_t n_errs;
+  uint32_t n_tasks;      // genotype-scan tasks requested past the first n_lines
+  uint32_t lines_seen;   // terminated lines in the block (== n_lines on the census path)
+  uint32_t cmap_maps;    // streaming path: class maps handed out
+  uint32_t pad[2];
+};
+
+// streaming path: what k_stream knows about a line when it has scanned it
+struct StreamEntry {
+  uint32_t ls, len;                       // start offset, content length (terminator chomped)
+  uint32_t ac, an, n_het, n_hom, n_miss;  // ALT #1
+  uint32_t cmap_off;
+};
+
+// one genotype scan: all samples of one line against one ALT index
+struct GtTask {
+  uint32_t line;
+  uint32_t allele;       // alleleNum = ALT index + 1 (main.go:552)
+  uint32_t s_begin;      // first byte after the FORMAT column's TAB
+  uint32_t cend;         // end of the line content (terminator excluded)
+  uint32_t cmap_off;     // BVCF_NO_CMAP if no class map is wanted
+  uint32_t pad[3];
+};
+
+// makeHetHomozygotes' return values for one task, plus the fields it walked
+struct GtResult {
+  uint32_t ac, an, n_het, n_hom, n_miss;
+  uint32_t n_fields;     // sample fields present on the line
+  uint32_t pad[2];
+};
+
+struct KernelArgs {
+  const uint8_t *buf;
+  uint32_t nbytes;       // bytes of whole lines
+  uint32_t cap;          // bytes that may be read (nbytes + pad)
+  uint32_t n_header;     // len(header)
+  uint32_t n_samples;    // len(header) - 9, or 0
+  uint32_t eol_chars;
+  uint32_t eol_byte;
+  uint32_t want_cmap;
+  uint32_t cmap_stride;
+  uint32_t max_lines, max_alleles, max_errs, max_tasks;
+  unsigned long long max_cmap;
+  const FilterTable *filters;
+  uint32_t *census;      // [n_chunks] newline count per chunk -> exclusive prefix within group
+  uint32_t *group_base;  // [n_groups]
+  uint32_t *line_off;    // [max_lines + 1]
+  bvcf_line *lines;
+  bvcf_allele *alleles;
+  bvcf_err *errs;
+  uint8_t *cmap;
+  GtTask *tasks;
+  GtResult *results;
+  BatchCounters *counters;
+  // streaming path
+  uint32_t fused;        // 1: k_stream found the lines and scanned ALT #1
+  uint32_t tile_bytes;   // bytes of text a wave owns (lines belong to the tile they start in)
+  uint32_t tile_quota;   // entries reserved per tile: a line that passes the field count is at
+                         // least n_header - 1 + eol_chars bytes long
+  uint32_t n_tiles;
+  StreamEntry *entries;  // [n_tiles * tile_quota]
+  uint32_t *line_len;    // [max_lines]
+  uint32_t *line_cmap;   // [max_lines] class map of ALT #1
+};
+
+// ------------------------------------------------------------------ wave helpers
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+  return v;
+}
+
+// three per-lane counts -> wave totals; two of them share a register while they fit 16 bits
+__device__ __forceinline__ void wave_sum3(uint32_t a, uint32_t b, uint32_t c, uint32_t limit, uint32_t *sa,
+                                          uint32_t *sb, uint32_t *sc) {
+  if (limit < 65536u) {
+    const uint32_t ab = wave_sum(a | (b << 16));
+    *sa = ab & 0xFFFFu;
+    *sb = ab >> 16;
+  } else {
+    *sa = wave_sum(a);
+    *sb = wave_sum(b);
+  }
+  *sc = wave_sum(c);
+}
+
+// exclusive prefix sum over the 64 lanes; *total receives the wave sum
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, kWave);
+    if (lane_id() >= d) inc += t;
+  }
+  *total = __shfl(inc, kWave - 1, kWave);
+  return inc - v;
+}
+
+__device__ __forceinline__ uint32_t bcast0(uint32_t v) { return __shfl(v, 0, kWave); }
+
+// 16 bytes at buf+off for this lane (any alignment); zeros if the window leaves [0, cap)
+__device__ __forceinline__ u32x4 load16(const uint8_t *buf, uint32_t off, uint32_t cap) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (off + 16u <= cap) v = *reinterpret_cast<const u32x4_u *>(buf + off);
+  return v;
+}
+
+// 16 bytes of text that this kernel reads exactly once: non-temporal, so the stream does not evict
+// what the caches are asked to keep (measured on k_stream: -3 %)
+__device__ __forceinline__ u32x4 ld_stream(const uint8_t *p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
+}
+
+// 0x80 in every byte of x that is zero, exact (no borrow artefacts)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x) {
+  uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  return ~(t | x | 0x7F7F7F7Fu);
+}
+
+// 4-bit mask: bit k set iff byte k of d equals c
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t d, uint32_t c4) {
+  uint32_t z = zero_bytes(d ^ c4) >> 7;  // bits 0,8,16,24
+  return ((z * 0x00204081u) >> 21) & 0xFu;
+}
+
+// 16-bit mask over the lane's 16 bytes
+__device__ __forceinline__ uint32_t eq_mask16(u32x4 v, uint32_t c) {
+  uint32_t c4 = c * 0x01010101u;
+  return eq_mask4(v.x, c4) | (eq_mask4(v.y, c4) << 4) | (eq_mask4(v.z, c4) << 8) | (eq_mask4(v.w, c4) << 12);
+}
+
+// bits [0, n) of a 16-bit mask, n may be <= 0 or >= 16
+__device__ __forceinline__ uint32_t low_bits16(int n) {
+  return n <= 0 ? 0u : (n >= 16 ? 0xFFFFu : ((1u << n) - 1u));
+}
+
+
+// class map of map slot `mi` (census path: slot == task index), or BVCF_NO_CMAP past the arena
+__device__ __forceinline__ uint32_t cmap_of(const KernelArgs &a, uint32_t mi, bool want) {
+  return (want && ((unsigned long long)mi + 1ull) * a.cmap_stride <= a.max_cmap) ? mi * a.cmap_stride : BVCF_NO_CMAP;
+}
+
+}  // namespace bvcf_dev

@@ -1,0 +1,383 @@
+// bvcf_gtscan.hip.h — makeHetHomozygotes: fast (regular) and general genotype scans, k_gt (main.go:1042-1194)
+// Part of the gfx950 device code of libbvcf; see bvcf_device.hip.h for the kernel map.
+#pragma once
+
+#include "bvcf_common.hip.h"
+#include "bvcf_alleles.hip.h"
+
+namespace bvcf_dev {
+
+// ------------------------------------------------------------------ GT scan (whole wave)
+
+// Exact restatement of one sample field of makeHetHomozygotes (main.go:1057-1190) for the
+// allele whose decimal text is itoa(a): byte-serial, used for irregular lines.
+// p = field start, cend = end of line content; a field ends at '\t' or cend.
+__device__ inline void classify_field(const uint8_t *buf, uint32_t p, uint32_t cend, uint32_t a, uint32_t a_ndigits,
+                                      uint32_t *cls, uint32_t *altc, uint32_t *gtc) {
+  auto getc = [&](uint32_t q) -> uint32_t { return q < cend ? (uint32_t)buf[q] : (uint32_t)'\t'; };
+  *altc = 0;
+  *gtc = 0;
+  *cls = BVCF_CLS_NONE;
+  // fast gate, main.go:1063-1064: (len == 3 || g[3] == ':') && g[1] in {'|','/'}
+  uint32_t c0 = getc(p), c1 = '\t', c2 = '\t', c3 = '\t';
+  if (c0 != '\t') {
+    c1 = getc(p + 1);
+    if (c1 != '\t') {
+      c2 = getc(p + 2);
+      if (c2 != '\t') c3 = getc(p + 3);
+    }
+  }
+  const bool have3 = c0 != '\t' && c1 != '\t' && c2 != '\t';
+  if (have3 && (c3 == '\t' || c3 == ':') && (c1 == '|' || c1 == '/')) {
+    if (c0 == '0' && c2 == '0') {
+      *gtc = 2;
+      return;
+    }
+    if (a_ndigits == 1) {
+      const uint32_t ac = '0' + a;
+      if ((c0 == '0' && c2 == ac) || (c0 == ac && c2 == '0')) {
+        *gtc = 2;
+        *altc = 1;
+        *cls = BVCF_CLS_HET;
+        return;
+      }
+      if (c0 == ac && c2 == ac) {
+        *gtc = 2;
+        *altc = 2;
+        *cls = BVCF_CLS_HOM;
+        return;
+      }
+    }
+    if (c0 == '.' || c2 == '.') {
+      *cls = BVCF_CLS_MISSING;
+      return;
+    }
+  }
+  // general path, main.go:1126-1190.  f = field up to the first ':'
+  uint32_t nf = 0;
+  bool has_bar = false, has_slash = false;
+  #pragma nounroll
+  for (;; nf++) {
+    uint32_t ch = getc(p + nf);
+    if (ch == '\t' || ch == ':') break;
+    has_bar |= ch == '|';
+    has_slash |= ch == '/';
+  }
+  const uint32_t sep = has_bar ? '|' : (has_slash ? '/' : 0xFFFFFFFFu);
+  uint32_t alt_count = 0, gt_count = 0;
+  // token state
+  uint32_t tlen = 0;
+  unsigned long long val = 0;
+  bool digits = true, lead0 = false, dot = false;
+  #pragma nounroll
+  for (uint32_t k = 0; k <= nf; k++) {
+    uint32_t ch = k < nf ? getc(p + k) : sep;
+    if (k == nf || ch == sep) {
+      if (tlen == 1 && dot) {  // allele == "." => whole sample missing, nothing counted
+        *cls = BVCF_CLS_MISSING;
+        return;
+      }
+      if (tlen >= 1 && tlen <= 10 && digits && !lead0 && val == (unsigned long long)a) alt_count++;
+      gt_count++;
+      tlen = 0;
+      val = 0;
+      digits = true;
+      lead0 = false;
+      dot = false;
+      continue;
+    }
+    if (tlen == 0) {
+      dot = ch == '.';
+      lead0 = ch == '0';
+    }
+    uint32_t d = ch - '0';
+    if (d > 9u)
+      digits = false;
+    else if (tlen < 11)
+      val = val * 10ull + d;
+    tlen++;
+  }
+  *gtc = gt_count;
+  *altc = alt_count;
+  if (alt_count != 0) *cls = alt_count == gt_count ? BVCF_CLS_HOM : BVCF_CLS_HET;
+}
+
+// ---- regular sample region: exactly 4 bytes per sample, "x<sep>y<TAB>" ----
+//
+// Every dword a lane loads is one sample field.  With t = w ^ "0<sep>0<TAB>":
+//   t == 0                      the field is the reference genotype (the common case)
+//   t & 0xFFE0FFE0 != 0         separator / TAB bytes differ, or an allele byte is outside
+//                               '0'^[0,31]: not a regular field
+//   v = allele byte ^ '0'       0..9 for digits, 0x1E for '.'; valid iff bit v of 0x400003FF
+// Classes come from a 16-entry x 2-bit table indexed by v & 15 (digit d -> 1 iff d == allele,
+// 14 ('.') -> 3): cls = min(code(b0) + code(b2), 3) gives none/het/hom/missing (main.go:1063-1124).
+constexpr int kFastGroup = 5;  // chunks per buffer; two buffers => 10 KiB in flight per wave
+
+// v_bfe_u32 and the shifts use only the low 5 bits of their offset operand, so (t << 1) selects entry
+// t & 15 of the 2-bit table for byte 0, and (t >> 15) entry (t >> 16) & 15 for byte 2 (bit 0 of that
+// offset is bit 7 of the separator xor, zero whenever the frame test passes).
+__device__ __forceinline__ uint32_t fast_codes(uint32_t t, uint32_t table) {
+  const uint32_t k = __builtin_amdgcn_ubfe(table, t << 1, 2u) + __builtin_amdgcn_ubfe(table, t >> 15, 2u);
+  return k < 3u ? k : 3u;
+}
+
+// both allele bytes in {0-9, .}: bit (byte ^ '0') of 0x400003FF (the bytes are < 32 when the frame
+// test passes; the hardware shift takes the amount mod 32)
+__device__ __forceinline__ uint32_t fast_valid(uint32_t t) { return (0x400003FFu >> t) & (0x400003FFu >> (t >> 16)); }
+
+struct FastAcc {
+  uint32_t bad, ok, het, hom, miss;
+};
+
+constexpr uint32_t kStageChunks = 64;                 // class-map bytes staged in LDS per wave:
+constexpr uint32_t kStageBytes = kStageChunks * 64u;  // 64 chunks x 64 B = 4 KiB = 16 384 samples
+
+// all-reference chunks never touch the stage: it is zeroed once per window instead
+__device__ __forceinline__ void zero_stage(uint8_t *stage) {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (uint32_t i = 0; i < kStageBytes / (16u * kWave); i++)
+    *reinterpret_cast<u32x4 *>(stage + 16u * (lane_id() + i * kWave)) = z;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// write staged class-map bytes [0, n) of the window starting at chunk c_base to the task's map
+__device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *cmap, uint32_t c_base, uint32_t n,
+                                            uint32_t stride) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t g0 = c_base * 64u;
+  if (g0 >= stride) return;
+  n = min(n, stride - g0);  // the slot is `stride` bytes (a multiple of 16)
+  for (uint32_t i = 16u * lane_id(); i < n; i += 16u * kWave)
+    *reinterpret_cast<u32x4 *>(cmap + g0 + i) = *reinterpret_cast<const u32x4 *>(stage + i);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one 1 KiB chunk (this lane's 4 fields) of a regular region; class bytes go to the LDS stage
+__device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunks, uint32_t ns, uint32_t kref,
+                                           uint32_t table, uint8_t *cmap, uint8_t *stage, uint32_t stride,
+                                           uint32_t term_xor, FastAcc &acc) {
+  const int lane = lane_id();
+  const uint32_t f0 = c * 256u + 4u * lane;  // sample index of the lane's first dword
+  uint32_t t[4] = {v.x ^ kref, v.y ^ kref, v.z ^ kref, v.w ^ kref};
+  if (c + 1 == n_chunks) {
+    // tail: slots past the last sample count as reference; the last sample's terminator byte
+    // (eol or '\r') stands in for its TAB
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (f0 + q >= ns) t[q] = 0;
+      if (f0 + q == ns - 1) {
+        // term_xor = (expected terminator ^ TAB) << 24; anything above 0xFF000000 = no check
+        if (term_xor <= 0xFF000000u) acc.bad |= (t[q] ^ term_xor) & 0xFF000000u;
+        t[q] &= 0x00FFFFFFu;
+      }
+    }
+  }
+  if (__any((t[0] | t[1] | t[2] | t[3]) != 0)) {
+    uint32_t byte = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      acc.bad |= t[q] & 0xFFE0FFE0u;
+      acc.ok &= fast_valid(t[q]);
+      byte |= fast_codes(t[q], table) << (2 * q);
+    }
+    const uint32_t lo = byte & 0x55u, hi = (byte >> 1) & 0x55u;
+    acc.het += __popc(lo & ~hi);
+    acc.hom += __popc(hi & ~lo);
+    acc.miss += __popc(lo & hi);
+    if (cmap) stage[(c % kStageChunks) * 64u + lane] = (uint8_t)byte;  // the stage starts zeroed
+  }
+  if (cmap && ((c % kStageChunks) == kStageChunks - 1u || c + 1 == n_chunks)) {
+    flush_stage(stage, cmap, c - (c % kStageChunks), ((c % kStageChunks) + 1u) * 64u, stride);
+    if (c + 1 != n_chunks) zero_stage(stage);
+  }
+}
+
+// check_term: also require the byte after the last sample to be the line terminator (the caller
+// predicted the end of the line from the region's regular length)
+__device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint32_t ns, uint32_t allele, uint8_t *cmap,
+                                    uint8_t *stage, bool check_term, GtStats *st) {
+  const int lane = lane_id();
+  const uint32_t table = (allele <= 9 ? (1u << (2u * allele)) : 0u) | (3u << 28);
+  const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;
+  const uint32_t last_off = a.cap - 16u;
+  const uint8_t *base = a.buf;
+  // every chunk of the region ends before the buffer does (the common case): no per-load clamp
+  const bool inside = (unsigned long long)s_begin + (unsigned long long)n_chunks * kChunk <= a.cap;
+  const uint8_t *lane_base = base + s_begin + 16u * lane;
+  auto fetch = [&](uint32_t c) -> u32x4 {
+    if (inside) return ld_stream(lane_base + c * kChunk);
+    const uint32_t off = min(s_begin + c * kChunk + 16u * lane, last_off);
+    return ld_stream(base + off);
+  };
+  FastAcc acc = {0, 1, 0, 0, 0};
+  if (cmap) zero_stage(stage);
+  u32x4 va[kFastGroup], vb[kFastGroup];
+#pragma unroll
+  for (int g = 0; g < kFastGroup; g++)
+    if ((uint32_t)g < n_chunks) va[g] = fetch(g);
+#pragma unroll
+  for (int g = 0; g < kFastGroup; g++)
+    if ((uint32_t)(kFastGroup + g) < n_chunks) vb[g] = fetch(kFastGroup + g);
+  // the separator of the first field is the line's separator; mixed lines fail the frame test
+  const uint32_t sep = (__builtin_amdgcn_readfirstlane(va[0].x) >> 8) & 0xFFu;
+  if (sep != '|' && sep != '/') return false;
+  const uint32_t kref = 0x09300030u | (sep << 8);
+  // the 32-bit compare below cannot be expressed with a 0 sentinel (0 is a valid xor), so "no check"
+  // is any value above 0xFF000000
+  const uint32_t term_xor = check_term ? ((a.eol_byte ^ 0x09u) << 24) : 0xFFFFFFFFu;
+
+  for (uint32_t c0 = 0; c0 < n_chunks; c0 += 2 * kFastGroup) {
+#pragma unroll
+    for (int g = 0; g < kFastGroup; g++)
+      if (c0 + g < n_chunks) fast_chunk(va[g], c0 + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
+#pragma unroll
+    for (int g = 0; g < kFastGroup; g++)
+      if (c0 + 2 * kFastGroup + g < n_chunks) va[g] = fetch(c0 + 2 * kFastGroup + g);
+#pragma unroll
+    for (int g = 0; g < kFastGroup; g++)
+      if (c0 + kFastGroup + g < n_chunks) fast_chunk(vb[g], c0 + kFastGroup + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
+#pragma unroll
+    for (int g = 0; g < kFastGroup; g++)
+      if (c0 + 3 * kFastGroup + g < n_chunks) vb[g] = fetch(c0 + 3 * kFastGroup + g);
+  }
+  if (__any(acc.bad != 0 || !(acc.ok & 1u))) return false;
+  wave_sum3(acc.het, acc.hom, acc.miss, ns, &st->n_het, &st->n_hom, &st->n_miss);
+  st->ac = st->n_het + 2u * st->n_hom;
+  st->an = 2u * (ns - st->n_miss);
+  return true;
+}
+
+// Any sample region: delimiter masks per lane, wave prefix-sum for the sample index.  A field whose
+// first four bytes are "x<sep>y" + (':' | TAB) with x, y in {0-9, .} — the reference's own fast gate,
+// main.go:1063-1124, at any stride — is classified from registers (the lane's 16 bytes and the next
+// lane's first dword); everything else goes through the byte-serial restatement (classify_field).
+// *n_tabs receives the number of TABs in [s_begin, cend).
+__device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, uint32_t cend, uint32_t ns,
+                                       uint32_t allele, uint8_t *cmap, GtStats *st, uint32_t *n_tabs) {
+  const int lane = lane_id();
+  uint32_t a_nd = 1;
+  for (uint32_t t = allele; t >= 10; t /= 10) a_nd++;
+  const uint32_t table = (allele <= 9 ? (1u << (2u * allele)) : 0u) | (3u << 28);
+  if (cmap) {  // zero this allele's map, then OR classes in
+    for (uint32_t i = lane * 4u; i < a.cmap_stride; i += kWave * 4u) *reinterpret_cast<uint32_t *>(cmap + i) = 0u;
+    __builtin_amdgcn_s_waitcnt(0);  // stores retired before the atomics below touch the same words
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+  uint32_t ac = 0, an = 0, het = 0, hom = 0, miss = 0;
+  uint32_t tabs_before = 0;    // TABs in earlier chunks
+  uint32_t prev_last_tab = 1;  // the byte before the region start behaves like a TAB (field start)
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (s_begin < cend) v = load16(a.buf, s_begin + 16u * lane, a.cap);
+  for (uint32_t base = s_begin; base < cend; base += kChunk) {
+    u32x4 nxt = {0u, 0u, 0u, 0u};
+    if (base + kChunk < cend) nxt = load16(a.buf, base + kChunk + 16u * lane, a.cap);  // in flight during this chunk
+    const uint32_t off = base + 16u * lane;
+    const uint32_t valid = low_bits16((int)cend - (int)off);
+    const uint32_t m = eq_mask16(v, '\t') & valid;
+    uint32_t tot;
+    const uint32_t pre = wave_excl_scan(__popc(m), &tot);
+    // field starts: the byte after each TAB, plus the region start
+    uint32_t carry = __shfl_up(m >> 15, 1, kWave) & 1u;
+    if (lane == 0) carry = prev_last_tab;
+    uint32_t starts = ((m << 1) | carry) & valid & 0xFFFFu;
+    // bytes 16..19 of this lane's window: the next lane's first dword (next chunk's for lane 63)
+    uint32_t d4 = __shfl_down(v.x, 1, kWave);
+    const uint32_t nx0 = __shfl(nxt.x, 0, kWave);
+    if (lane == kWave - 1) d4 = nx0;
+    while (starts) {
+      const uint32_t k = __ffs(starts) - 1;
+      starts &= starts - 1;
+      // sample index = TABs before this byte
+      const uint32_t s = tabs_before + pre + __popc(m & ((1u << k) - 1u));
+      if (s < ns) {
+        uint32_t cls = 0, altc = 0, gtc = 0;
+        bool done = false;
+        if (off + k + 4u <= cend) {  // four real bytes: c0 c1 c2 c3
+          const uint32_t i = k >> 2;
+          const uint32_t lo = i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+          const uint32_t hi = i == 0 ? v.y : (i == 1 ? v.z : (i == 2 ? v.w : d4));
+          const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, k & 3u);
+          const uint32_t c1 = (w >> 8) & 0xFFu, c3 = w >> 24;
+          const uint32_t v0 = (w & 0xFFu) ^ '0', v2 = ((w >> 16) & 0xFFu) ^ '0';
+          const bool frame = (c1 == '|' || c1 == '/') && (c3 == ':' || c3 == '\t');
+          const bool plain = v0 < 32u && v2 < 32u && ((0x400003FFu >> v0) & (0x400003FFu >> v2) & 1u);
+          if (frame && plain) {
+            const uint32_t code = ((table >> ((v0 & 15u) * 2u)) & 3u) + ((table >> ((v2 & 15u) * 2u)) & 3u);
+            cls = code < 3u ? code : 3u;
+            gtc = cls == 3u ? 0u : 2u;
+            altc = cls == 3u ? 0u : cls;
+            done = true;
+          }
+        }
+        if (!done) classify_field(a.buf, off + k, cend, allele, a_nd, &cls, &altc, &gtc);
+        ac += altc;
+        an += gtc;
+        het += cls == BVCF_CLS_HET;
+        hom += cls == BVCF_CLS_HOM;
+        miss += cls == BVCF_CLS_MISSING;
+        if (cmap && cls) atomicOr(reinterpret_cast<uint32_t *>(cmap + (s >> 4) * 4u), cls << (2u * (s & 15u)));
+      }
+    }
+    prev_last_tab = __shfl(m >> 15, kWave - 1, kWave) & 1u;
+    tabs_before += tot;
+    v = nxt;
+  }
+  // a field that starts exactly at cend (empty last field) was not visited above
+  if (lane == 0) {
+    const bool empty_last = (cend == s_begin) || (cend > s_begin && a.buf[cend - 1] == '\t');
+    if (empty_last && tabs_before < ns) an += 1;  // "" is one non-matching allele token
+  }
+  st->ac = wave_sum(ac);
+  st->an = wave_sum(an);
+  st->n_het = wave_sum(het);
+  st->n_hom = wave_sum(hom);
+  st->n_miss = wave_sum(miss);
+  *n_tabs = tabs_before;
+}
+
+// ------------------------------------------------------------------ k_gt: one wave per task
+
+__global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
+  uint8_t *stage = s_stage[threadIdx.x >> 6];
+  const int lane = lane_id();
+  const uint32_t n_tasks = min(min(a.counters->n_lines, a.max_lines) + a.counters->n_tasks, a.max_tasks);
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  const uint32_t ns = a.n_samples;
+  uint32_t ti = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  GtTask nxt = GtTask{};
+  if (ti < n_tasks) nxt = a.tasks[ti];
+  for (; ti < n_tasks; ti += stride) {
+    const GtTask t = nxt;
+    if (ti + stride < n_tasks) nxt = a.tasks[ti + stride];  // in flight while this task is scanned
+    if (t.allele == 0) continue;  // line rejected before getAlleles: nothing to scan
+    uint8_t *cm = t.cmap_off != BVCF_NO_CMAP ? a.cmap + t.cmap_off : nullptr;
+    GtStats st = {0, 0, 0, 0, 0};
+    uint32_t n_fields;
+    // regular region: 4 bytes per sample, every dword of a lane is one "x|y<TAB>" field
+    if (t.cend + 1u - t.s_begin == 4u * ns && gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, false, &st)) {
+      n_fields = ns;
+    } else {
+      uint32_t tabs;
+      gt_scan_general(a, t.s_begin, t.cend, ns, t.allele, cm, &st, &tabs);
+      n_fields = tabs + 1u;
+    }
+    if (lane == 0) {
+      GtResult r;
+      r.ac = st.ac;
+      r.an = st.an;
+      r.n_het = st.n_het;
+      r.n_hom = st.n_hom;
+      r.n_miss = st.n_miss;
+      r.n_fields = n_fields;
+      r.pad[0] = r.pad[1] = 0;
+      a.results[ti] = r;
+    }
+  }
+}
+
+
+}  // namespace bvcf_dev

@@ -1,0 +1,470 @@
+// bvcf_head.hip.h — k_head (fixed columns, FILTER gate, getAlleles, records + scan tasks) and k_finish
+// Part of the gfx950 device code of libbvcf; see bvcf_device.hip.h for the kernel map.
+#pragma once
+
+#include "bvcf_common.hip.h"
+#include "bvcf_alleles.hip.h"
+#include "bvcf_gtscan.hip.h"
+#include "bvcf_stream.hip.h"
+
+namespace bvcf_dev {
+
+// ------------------------------------------------------------------ k_head: 16 lanes per line
+
+constexpr int kGroup = 16;                       // lanes per line in k_head
+constexpr int kGroupsPerWg = kWgThreads / kGroup;
+constexpr uint32_t kWindow = kGroup * 16;        // bytes per group step
+constexpr uint32_t kHeadStage = 128;             // line-head bytes kept in LDS for the serial phase
+
+__device__ __forceinline__ int glane() { return threadIdx.x & (kGroup - 1); }
+
+// exclusive prefix sum inside a 16-lane group; *total = group sum
+__device__ __forceinline__ uint32_t group_excl_scan(uint32_t v, uint32_t *total) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < kGroup; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, kGroup);
+    if (glane() >= d) inc += t;
+  }
+  *total = __shfl(inc, kGroup - 1, kGroup);
+  return inc - v;
+}
+
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+  for (int d = kGroup / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, kGroup);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t gbcast0(uint32_t v) { return __shfl(v, 0, kGroup); }
+
+__device__ inline bool filter_in(const Bytes &buf, Span f, const uint16_t *off, const uint16_t *len, uint32_t n,
+                                 const uint8_t *text) {
+#pragma nounroll
+  for (uint32_t i = 0; i < n; i++) {
+    if (len[i] != f.len) continue;
+    bool eq = true;
+#pragma nounroll
+    for (uint32_t k = 0; k < f.len && eq; k++) eq = buf[f.off + k] == text[off[i] + k];
+    if (eq) return true;
+  }
+  return false;
+}
+
+__device__ inline void write_allele(const KernelArgs &a, uint32_t idx, uint32_t line, uint32_t alt_idx,
+                                    const AlleleEval &e, long long pos, uint8_t ref, uint8_t alt_base,
+                                    uint8_t site_type, uint32_t task, uint32_t cmap_off) {
+  bvcf_allele r;
+  r.pos = pos;
+  r.line = line;
+  r.alt_idx = alt_idx;
+  r.alt_off = e.alt_off;
+  r.alt_len = e.mnp ? 1u : e.alt_len;
+  r.ac = 0;
+  r.an = 0;
+  r.n_het = 0;
+  r.n_hom = 0;
+  r.n_miss = 0;
+  r.cmap_off = cmap_off;
+  r.ref = ref;
+  r.alt_base = alt_base;
+  r.kind = e.mnp ? (uint8_t)BVCF_ALT_BASE : e.kind;
+  r.site_type = site_type;
+  r.trtv = (site_type == BVCF_SITE_MULTI || r.kind != BVCF_ALT_BASE) ? 0 : trtv_of(ref, alt_base);
+  r.flags = (!e.mnp && e.pos_text) ? BVCF_ALLELE_POS_TEXT : 0;
+  r.pad[0] = r.pad[1] = 0;
+  r.gt_task = task;
+  r.pad2 = 0;
+  a.alleles[idx] = r;
+}
+
+constexpr uint32_t kNoTask = 0xFFFFFFFFu;
+
+// Write genotype-scan task `ti` (allele == 0 marks a slot without a scan).  Task i < n_lines is
+// "line i, ALT #1"; tasks past n_lines are the further ALT indices of multiallelic lines.
+__device__ inline void put_task(const KernelArgs &a, uint32_t ti, uint32_t line, uint32_t allele, uint32_t s_begin,
+                                uint32_t cend, uint32_t cmap_off) {
+  if (ti < a.max_tasks) {
+    GtTask t;
+    t.line = line;
+    t.allele = allele;
+    t.s_begin = s_begin;
+    t.cend = cend;
+    t.cmap_off = cmap_off;
+    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    a.tasks[ti] = t;
+  }
+}
+
+
+// k_head handles 256 lines per workgroup step in two phases:
+//   T  tokenise: 16 lanes per line find the TABs of the fixed columns (per-lane masks, 16-lane
+//      prefix sum) and stage the first kHeadStage bytes of the line in LDS; 16 rounds x 16 lines
+//   S  serial:   ONE LANE PER LINE runs the gate + getAlleles on the staged bytes, so a wave
+//      instruction serves 64 lines (with 16 lanes per line it served 4 and the kernel was
+//      issue-bound on this code)
+constexpr uint32_t kLinesPerStep = kWgThreads;
+constexpr uint32_t kHeadRow = kHeadStage / 4 + 1;  // dwords per staged line; odd => conflict-free columns
+constexpr uint32_t kTabRow = 11;                   // 9 TAB offsets + pad, odd stride
+
+__global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
+  __shared__ uint32_t s_head[kLinesPerStep * kHeadRow];
+  __shared__ uint32_t s_tab[kLinesPerStep * kTabRow];
+  __shared__ uint32_t s_ls[kLinesPerStep], s_len[kLinesPerStep], s_found[kLinesPerStep], s_staged[kLinesPerStep],
+      s_extra[kLinesPerStep];
+  __shared__ uint32_t s_wave[kWavesPerWg][2];
+  __shared__ uint32_t s_base[3];
+  __shared__ FilterTable s_ft;  // FILTER sets
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.filters);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ft);
+    for (uint32_t i = threadIdx.x; i < sizeof(FilterTable) / 4; i += kWgThreads) dst[i] = src[i];
+  }
+  const int gl = glane();
+  const int g = threadIdx.x / kGroup;
+  const int lane = lane_id();
+  const int w = threadIdx.x >> 6;
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t stride = gridDim.x * kLinesPerStep;
+  const uint32_t need = min(9u, a.n_header - 1u);  // TABs that bound the fixed columns we read
+  const uint32_t ns = a.n_samples;
+  const bool maps = a.want_cmap && ns > 0;
+
+  for (uint32_t line0 = blockIdx.x * kLinesPerStep; line0 < n_lines; line0 += stride) {
+    __syncthreads();  // LDS of the previous step is free (also covers the s_ft copy)
+
+    // ================= phase T: 16 lanes per line =================
+    // lane gl of a group fetches the offsets of the group's round-gl line, so the 16 rounds' offsets
+    // are in flight together; the first window of round r + 1 is requested before round r is parsed
+    uint32_t my_ls = 0, my_len = 0;
+    {
+      const uint32_t l = line0 + (uint32_t)gl * kGroupsPerWg + g;
+      if (l < n_lines) {
+        my_ls = a.line_off[l];
+        if (a.fused) {
+          my_len = a.line_len[l];
+        } else {
+          const uint32_t le = a.line_off[l + 1];
+          my_len = le - my_ls >= a.eol_chars ? le - my_ls - a.eol_chars : 0u;  // chomp, main.go:535
+        }
+      }
+    }
+    u32x4 v_next = load16(a.buf, __shfl(my_ls, 0, kGroup) + 16u * gl, a.cap);
+    for (uint32_t r = 0; r < kLinesPerStep / kGroupsPerWg; r++) {
+      const uint32_t ll = r * kGroupsPerWg + g;
+      const uint32_t line = line0 + ll;
+      const uint32_t ls = __shfl(my_ls, r, kGroup);
+      const uint32_t len = __shfl(my_len, r, kGroup);
+      const u32x4 v_first = v_next;
+      if (r + 1 < kLinesPerStep / kGroupsPerWg) v_next = load16(a.buf, __shfl(my_ls, r + 1, kGroup) + 16u * gl, a.cap);
+      if (line >= n_lines) continue;
+      const uint32_t cend = ls + len;
+      uint32_t found = 0, base = ls;
+      // strings.Split(row, "\t") for the fixed columns, main.go:535
+      for (; base < cend && found < need; base += kWindow) {
+        const uint32_t off = base + 16u * gl;
+        u32x4 v = base == ls ? v_first : load16(a.buf, off, a.cap);
+        const uint32_t rel = off - ls;
+        if (rel < kHeadStage) {
+          uint32_t *row = &s_head[ll * kHeadRow + rel / 4];
+          row[0] = v.x;
+          row[1] = v.y;
+          row[2] = v.z;
+          row[3] = v.w;
+        }
+        uint32_t m = eq_mask16(v, '\t') & low_bits16((int)cend - (int)off);
+        uint32_t tot;
+        uint32_t rk = found + group_excl_scan(__popc(m), &tot);
+        while (m && rk < need) {
+          s_tab[ll * kTabRow + rk] = off + __ffs(m) - 1;
+          m &= m - 1;
+          rk++;
+        }
+        found += tot;
+      }
+      const uint32_t staged = min(base - ls, kHeadStage);
+      uint32_t extra = 0;
+      if (ns == 0 && found >= need) {
+        // no samples: every TAB after the last fixed column is an extra field; `found` already
+        // counts the TABs of the windows read so far
+        for (; base < cend; base += kWindow) {
+          const uint32_t off = base + 16u * gl;
+          u32x4 v = load16(a.buf, off, a.cap);
+          extra += __popc(eq_mask16(v, '\t') & low_bits16((int)cend - (int)off));
+        }
+        extra = group_sum(extra);
+      }
+      if (gl == 0) {
+        s_ls[ll] = ls;
+        s_len[ll] = len;
+        s_found[ll] = found;
+        s_staged[ll] = staged;
+        s_extra[ll] = extra;
+      }
+    }
+    __syncthreads();
+
+    // ================= phase S: one lane per line =================
+    const uint32_t ll = threadIdx.x;
+    const uint32_t line = line0 + ll;
+    const bool active = line < n_lines;
+    const uint32_t ls = active ? s_ls[ll] : 0u, len = active ? s_len[ll] : 0u, found = active ? s_found[ll] : 0u;
+    const uint32_t cend = ls + len;
+    const uint32_t *tab = &s_tab[ll * kTabRow];
+    Bytes hb;
+    hb.g = a.buf;
+    hb.lds = reinterpret_cast<const uint8_t *>(&s_head[ll * kHeadRow]);
+    hb.lo = ls;
+    hb.n = active ? s_staged[ll] : 0u;
+
+    uint32_t status = BVCF_LINE_OK;
+    uint32_t n_fields = 0;
+    if (active && found < need) {
+      status = BVCF_LINE_FIELDS;
+      n_fields = found + 1;
+    } else if (active && ns == 0) {
+      n_fields = found + s_extra[ll] + 1;
+      if (n_fields != a.n_header) status = BVCF_LINE_FIELDS;
+    }
+
+    // field i = [fstart(i), tab[i]) ; fields beyond the line: empty at cend
+    auto fspan = [&](uint32_t i) -> Span {
+      Span sp;
+      sp.off = i == 0 ? ls : tab[i - 1] + 1;
+      const uint32_t e = i < need ? tab[i] : cend;
+      sp.len = e - sp.off;
+      return sp;
+    };
+
+    uint32_t rec_first = 0, n_rec = 0, site_type = 0;
+    bool task_written = false, primary_written = false;
+
+    // ---- part 1: gate and what the line will need
+    AlleleCtx c;
+    uint32_t mode = 0, n_commas = 0, bound = 0, s_begin = cend;
+    if (active && status == BVCF_LINE_OK && a.n_header > 6) {
+      // FILTER gate, main.go:447-454
+      const FilterTable *ft = &s_ft;
+      Span f = fspan(6);
+      if (!ft->allow_nil && !filter_in(hb, f, ft->allow_off, ft->allow_len, ft->allow_n, ft->text))
+        status = BVCF_LINE_FILTER;
+      else if (!ft->deny_nil && filter_in(hb, f, ft->deny_off, ft->deny_len, ft->deny_n, ft->text))
+        status = BVCF_LINE_FILTER;
+    }
+    const bool eval = active && status == BVCF_LINE_OK;
+    if (eval) {
+      // getAlleles set-up, main.go:723-735
+      c.buf = hb;
+      c.chrom = fspan(0);
+      c.pos = fspan(1);
+      c.ref = fspan(3);
+      c.alt = fspan(4);
+      c.int_pos = 0;
+      c.pos_bad = false;
+      c.line = line;
+      s_begin = need == 9 ? tab[8] + 1 : cend;
+      // mode 0: REF == ALT; 1: single-byte ALT path; 2: ALT token loop; 3: empty REF (Go panics)
+      // bound: a token yields one record, or one per differing base when it is as long as a
+      // multi-base REF (main.go:855-873)
+      bool same = c.alt.len == c.ref.len;
+      uint32_t tl = 0, b2 = 0;
+#pragma nounroll
+      for (uint32_t i = 0; i <= c.alt.len; i++) {
+        const uint8_t ch = i < c.alt.len ? hb[c.alt.off + i] : (uint8_t)',';
+        if (i < c.alt.len && same) same = ch == hb[c.ref.off + i];
+        if (ch == ',') {
+          n_commas += i < c.alt.len;
+          b2 += (tl == c.ref.len && c.ref.len > 1) ? c.ref.len : 1u;
+          tl = 0;
+        } else {
+          tl++;
+        }
+      }
+      mode = same ? 0u : (c.alt.len == 1 ? 1u : (c.ref.len == 0 ? 3u : 2u));
+      bound = mode == 1 ? 1u : (mode == 2 ? b2 : 0u);
+    }
+
+    // ---- slot reservation, once per workgroup step: record slot `line` and task slot `line` are
+    // the line's own; only further records / ALT indices draw from the batch counters.  Biallelic
+    // lines — all of a 1KG-shaped file — never touch an atomic.
+    const uint32_t want_rec = bound > 1 ? bound - 1 : 0u;
+    const uint32_t want_task = (eval && ns > 0 && mode == 2) ? n_commas : 0u;
+    uint32_t wt_rec, wt_task;
+    uint32_t extra_base = wave_excl_scan(want_rec, &wt_rec);
+    uint32_t task_base = wave_excl_scan(want_task, &wt_task);
+    if (lane == 0) {
+      s_wave[w][0] = wt_rec;
+      s_wave[w][1] = wt_task;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      uint32_t sum = 0;
+      for (int k = 0; k < kWavesPerWg; k++) sum += s_wave[k][threadIdx.x];
+      uint32_t got = 0;
+      if (sum) got = atomicAdd(threadIdx.x == 0 ? &a.counters->n_alleles : &a.counters->n_tasks, sum);
+      s_base[threadIdx.x] = got;
+      // streaming path: the class maps of the extra tasks come from the same cursor k_stream used
+      if (threadIdx.x == 1) s_base[2] = (sum && a.fused && maps) ? atomicAdd(&a.counters->cmap_maps, sum) : 0u;
+    }
+    __syncthreads();
+    uint32_t task_rank = task_base;  // this line's first extra task, counted inside the workgroup
+    for (int k = 0; k < w; k++) {
+      extra_base += s_wave[k][0];
+      task_rank += s_wave[k][1];
+    }
+    extra_base += n_lines + s_base[0];
+    task_base = n_lines + s_base[1] + task_rank;
+    const uint32_t map_base = a.fused ? s_base[2] + task_rank : task_base;
+
+    // ---- part 2: evaluate the ALT tokens, write records and scan tasks
+    if (eval) {
+      if (mode == 0) log_err(a, line, 0, BVCF_ERR_SAME);
+      if (mode == 3) log_err(a, line, 0, BVCF_ERR_EMPTY_REF);
+      const bool fits = (unsigned long long)extra_base + want_rec <= a.max_alleles;
+      // slot of this line's j-th record
+      auto slot = [&](uint32_t j) -> uint32_t { return j == 0 ? line : extra_base + j - 1; };
+
+      // With samples, the scan for ALT #1 always runs: it also settles len(record) == len(header).
+      // On the streaming path k_stream has already done it (results[line], line_cmap[line]).
+      uint32_t cm0 = BVCF_NO_CMAP;
+      if (ns > 0 && !a.fused) {
+        cm0 = cmap_of(a, line, maps && (mode == 1 || mode == 2));
+        put_task(a, line, line, 1, s_begin, cend, cm0);
+        task_written = true;
+      }
+      if (ns > 0 && a.fused) {
+        if (maps) cm0 = a.line_cmap[line];
+        if (line < a.max_tasks && a.results[line].n_fields == kDeferred) {  // k_stream left the scan to k_gt
+          put_task(a, line, line, 1, s_begin, cend, cm0);
+          task_written = true;
+        }
+      }
+
+      uint32_t cur = 0, emitted = 0, tasks_used = 0;
+      if (mode == 1 || mode == 2) {
+#pragma nounroll
+        for (uint32_t k = 0;; k++) {
+          AlleleEval e;
+          Span t;
+          if (mode == 1) {
+            if (k > 0) break;
+            eval_single(c, e);
+            t = c.alt;
+          } else {
+            if (!next_token(c, &cur, &t)) break;
+            eval_token(c, t, e);
+          }
+          if (e.err) log_err(a, line, (e.err == BVCF_ERR_POS) ? 0u : k + 1u, e.err);
+          if (e.stop) break;
+          if (!e.n) continue;
+          uint32_t task = line, cm_off = cm0;
+          if (ns > 0 && k > 0) {
+            task = task_base + tasks_used;
+            cm_off = cmap_of(a, map_base + tasks_used, maps);
+            put_task(a, task, line, k + 1, s_begin, cend, cm_off);
+            tasks_used++;
+          }
+          if (ns == 0) task = kNoTask;
+          if (fits) {
+            // type call, main.go:1004-1037 (single-ALT path: main.go:743,764)
+            uint8_t stype;
+            if (n_commas > 0)
+              stype = BVCF_SITE_MULTI;
+            else if (!e.mnp && e.kind == BVCF_ALT_DEL)
+              stype = BVCF_SITE_DEL;
+            else if (!e.mnp && e.kind == BVCF_ALT_INS)
+              stype = BVCF_SITE_INS;
+            else
+              stype = e.n > 1 ? BVCF_SITE_MNP : BVCF_SITE_SNP;
+            site_type = stype;
+            if (e.mnp) {
+              uint32_t j = 0;
+#pragma nounroll
+              for (uint32_t i = 0; i < c.ref.len; i++) {
+                const uint8_t rb = hb[c.ref.off + i], ab = hb[t.off + i];
+                if (rb == ab) continue;
+                write_allele(a, slot(emitted + j), line, k, e, c.int_pos + (long long)i, rb, ab, stype, task, cm_off);
+                j++;
+              }
+            } else {
+              write_allele(a, slot(emitted), line, k, e, e.pos, e.ref, e.alt_base, stype, task, cm_off);
+            }
+          }
+          emitted += e.n;
+        }
+      }
+      // reserved but unused slots must not look like records / tasks to the later kernels
+      if (fits)
+#pragma nounroll
+        for (uint32_t j = emitted > 1 ? emitted : 1; j < bound; j++) a.alleles[slot(j)].gt_task = kNoTask;
+#pragma nounroll
+      for (uint32_t j = tasks_used; j < want_task; j++) put_task(a, task_base + j, line, 0, cend, cend, BVCF_NO_CMAP);
+      if (emitted) primary_written = true;
+      if (fits) rec_first = extra_base;
+      if (emitted == 0)
+        status = BVCF_LINE_NOALLELE;  // k_finish may still turn this into FIELDS
+      else if (fits)
+        n_rec = emitted;
+      n_fields = 0;  // settled by k_finish from the scan when there are samples
+      if (ns == 0) n_fields = a.n_header;
+    }
+
+    // ---- line record
+    if (active) {
+      bvcf_line L;
+      L.off = ls;
+      L.len = len;
+#pragma unroll
+      for (uint32_t i = 0; i < 9; i++) L.fend[i] = (i < need && i < found) ? tab[i] - ls : len;
+      L.rec_first = rec_first;
+      L.n_rec = n_rec;
+      L.n_fields = n_fields;
+      L.gt_task = line;
+      L.status = (uint8_t)status;
+      L.site_type = (uint8_t)site_type;
+      L.pad[0] = L.pad[1] = 0;
+      a.lines[line] = L;
+      // every line owns task slot `line` and record slot `line`: mark the ones it did not fill
+      if (ns > 0 && !task_written) put_task(a, line, line, 0, cend, cend, BVCF_NO_CMAP);
+      if (!primary_written && line < a.max_alleles) a.alleles[line].gt_task = kNoTask;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_finish
+
+// One thread per line and per allele record: the field-count half of linePasses (main.go:449) from
+// the scan of ALT #1, and the scan results copied into the records that reference them.
+__global__ __launch_bounds__(kWgThreads) void k_finish(KernelArgs a) {
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t n_alleles = min(n_lines + a.counters->n_alleles, a.max_alleles);
+  const uint32_t n_tasks = min(n_lines + a.counters->n_tasks, a.max_tasks);
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nthreads = gridDim.x * blockDim.x;
+  if (a.n_samples == 0) return;
+  for (uint32_t i = tid; i < n_lines; i += nthreads) {
+    bvcf_line *L = &a.lines[i];
+    const uint32_t st = L->status;
+    if (st != BVCF_LINE_OK && st != BVCF_LINE_NOALLELE) continue;
+    const uint32_t nf = 9u + a.results[i].n_fields;
+    L->n_fields = nf;
+    if (nf != a.n_header) {
+      L->status = BVCF_LINE_FIELDS;
+      L->n_rec = 0;
+    }
+  }
+  for (uint32_t i = tid; i < n_alleles; i += nthreads) {
+    bvcf_allele *r = &a.alleles[i];
+    const uint32_t t = r->gt_task;
+    if (t >= n_tasks) continue;  // kNoTask: slot without a record
+    const GtResult g = a.results[t];
+    r->ac = g.ac;
+    r->an = g.an;
+    r->n_het = g.n_het;
+    r->n_hom = g.n_hom;
+    r->n_miss = g.n_miss;
+  }
+}
+
+
+}  // namespace bvcf_dev

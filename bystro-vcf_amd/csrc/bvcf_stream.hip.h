@@ -1,0 +1,350 @@
+// bvcf_stream.hip.h — the streaming path: k_stream (lines + ALT #1 scan in one pass) and k_order
+// Part of the gfx950 device code of libbvcf; see bvcf_device.hip.h for the kernel map.
+#pragma once
+
+#include "bvcf_common.hip.h"
+#include "bvcf_gtscan.hip.h"
+
+namespace bvcf_dev {
+
+// ------------------------------------------------------------------ k_stream: one wave per tile
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kDeferred = 0xFFFFFFFEu;  // StreamEntry.n_miss / GtResult.n_fields: scan left to k_gt
+
+// first terminator byte at a position in [from, limit), or kNone; 4 KiB in flight per step
+__device__ inline uint32_t find_eol(const KernelArgs &a, uint32_t from, uint32_t limit) {
+  const int lane = lane_id();
+  const uint32_t last_off = a.cap - 16u;
+  for (uint32_t base = from; base < limit; base += 4u * kChunk) {
+    u32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = ld_stream(a.buf + min(base + q * kChunk + 16u * lane, last_off));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t off = base + q * kChunk + 16u * lane;
+      const uint32_t m = eq_mask16(v[q], a.eol_byte) & low_bits16((int)limit - (int)off);
+      const unsigned long long b = __ballot(m != 0);
+      if (b) {
+        const int src = __ffsll((long long)b) - 1;
+        return __builtin_amdgcn_readfirstlane(__shfl(off + __ffs(m) - 1, src, kWave));
+      }
+    }
+  }
+  return kNone;
+}
+
+// position of the k-th (0-based) set bit of m; m has more than k bits set
+__device__ __forceinline__ uint32_t nth_bit(uint32_t m, uint32_t k) {
+  for (uint32_t i = 0; i < k; i++) m &= m - 1;
+  return __ffs(m) - 1;
+}
+
+// head of a line from one window of bytes: position of the 9th TAB, or kNone with *eolp = first
+// terminator seen (kNone if none).  `v` holds 16 B per lane starting at `base`; lanes >= n_lanes hold
+// nothing.  found_io carries the TAB count across windows.
+__device__ __forceinline__ uint32_t head_window(const KernelArgs &a, u32x4 v, uint32_t base, uint32_t n_lanes,
+                                                uint32_t *found_io, uint32_t *eolp) {
+  const int lane = lane_id();
+  const uint32_t need = 9;
+  const uint32_t off = base + 16u * lane;
+  uint32_t valid = low_bits16((int)a.nbytes - (int)off);
+  if ((uint32_t)lane >= n_lanes) valid = 0;
+  const uint32_t me = eq_mask16(v, a.eol_byte) & valid;
+  uint32_t mt = eq_mask16(v, '\t') & valid;
+  const unsigned long long be = __ballot(me != 0);
+  uint32_t eol_here = kNone;
+  if (be) {
+    const int src = __ffsll((long long)be) - 1;
+    eol_here = __builtin_amdgcn_readfirstlane(__shfl(off + __ffs(me) - 1, src, kWave));
+    mt &= low_bits16((int)eol_here - (int)off);  // TABs of this line only
+  }
+  uint32_t tot;
+  const uint32_t cnt = __popc(mt);
+  const uint32_t prefix = wave_excl_scan(cnt, &tot);
+  if (*found_io + tot >= need) {
+    const uint32_t target = need - 1 - *found_io;
+    const bool mine = prefix <= target && target < prefix + cnt;
+    const unsigned long long bm = __ballot(mine);
+    const int src = __ffsll((long long)bm) - 1;
+    const uint32_t pos = mine ? off + nth_bit(mt, target - prefix) : 0u;
+    return __builtin_amdgcn_readfirstlane(__shfl(pos, src, kWave));
+  }
+  *found_io += tot;
+  *eolp = eol_here;
+  return kNone;
+}
+
+// The same for a 256 B window held by lanes 0..15 (the prefetched head of the next line): a DPP row
+// scan replaces the 64-lane shuffle scan, and a terminator anywhere in the window simply declines
+// (returns kNone: such a line is shorter than 256 B and goes through the general head scan).
+__device__ __forceinline__ uint32_t head_window16(const KernelArgs &a, u32x4 v, uint32_t base) {
+  const int lane = lane_id();
+  const uint32_t need = 9;
+  const uint32_t off = base + 16u * lane;
+  uint32_t valid = low_bits16((int)a.nbytes - (int)off);
+  if (lane >= 16) valid = 0;
+  const uint32_t e4 = a.eol_byte * 0x01010101u;
+  const uint32_t eol_any = (zero_bytes(v.x ^ e4) | zero_bytes(v.y ^ e4) | zero_bytes(v.z ^ e4) | zero_bytes(v.w ^ e4));
+  if (__ballot(eol_any != 0 && lane < 16)) return kNone;
+  const uint32_t mt = eq_mask16(v, '\t') & valid;
+  const uint32_t cnt = __popc(mt);
+  // inclusive scan inside the row of 16 lanes: row_shr:1,2,4,8 with zero fill
+  uint32_t x = cnt;
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+  const uint32_t prefix = x - cnt;
+  const bool mine = lane < 16 && prefix < need && need <= x;  // the 9th TAB is one of this lane's
+  const unsigned long long bm = __ballot(mine);
+  if (!bm) return kNone;
+  const int src = __ffsll((long long)bm) - 1;
+  const uint32_t pos = mine ? off + nth_bit(mt, need - 1 - prefix) : 0u;
+  return __builtin_amdgcn_readfirstlane(__shfl(pos, src, kWave));
+}
+
+constexpr int kPipeChunks = 10;  // chunk registers of the cross-line pipeline: lines of <= 2560 samples
+
+__global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
+  uint8_t *stage = s_stage[threadIdx.x >> 6];
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * kWavesPerWg;
+  const uint32_t ns = a.n_samples;
+  const uint32_t nb = a.nbytes;
+  const uint32_t T = a.tile_bytes;
+  const bool maps = a.want_cmap != 0;
+  const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;  // of a regular line
+  const uint32_t table1 = (1u << 2) | (3u << 28);              // ALT #1
+  // cross-line pipelining needs the whole line in the chunk registers and the in-scan terminator check
+  const bool pipelined = n_chunks <= (uint32_t)kPipeChunks && a.eol_chars == 1;
+  uint32_t cm_next = 0, cm_end = 0;  // this wave's private block of class-map slots
+  uint32_t seen = 0;                 // terminated lines this wave walked over
+
+  // A wave owns a contiguous run of tiles and walks it front to back, so only the first tile needs
+  // a search for its first line start (those bytes are the previous wave's last line).  Entries
+  // stay per tile: the quota argument is about bytes, not about who scans them.
+  const uint32_t per_wave = (a.n_tiles + n_waves - 1) / n_waves;
+  const uint32_t tile_lo = min(wave * per_wave, a.n_tiles), tile_hi = min(tile_lo + per_wave, a.n_tiles);
+  const uint32_t r0 = tile_lo * T;
+  const uint32_t r1 = (uint32_t)min((unsigned long long)tile_hi * T, (unsigned long long)nb);
+  uint32_t tile = tile_lo, n_local = 0;
+  uint32_t p = kNone;
+  if (tile_lo < tile_hi) {
+    p = 0;
+    if (r0 > 0) {
+      const uint32_t q = find_eol(a, r0 - 1, r1);  // a terminator at r1 - 1 starts a line of the next run
+      p = q == kNone ? kNone : q + 1;
+    }
+  }
+
+  // class-map slot for the next listed line
+  auto map_slot = [&]() -> uint32_t {
+    if (!maps) return BVCF_NO_CMAP;
+    if (cm_next == cm_end) {
+      uint32_t b = 0;
+      if (lane == 0) b = atomicAdd(&a.counters->cmap_maps, 16u);
+      cm_next = __builtin_amdgcn_readfirstlane(b);
+      cm_end = cm_next + 16u;
+    }
+    return cmap_of(a, cm_next, true);
+  };
+  // list a line (in input order) in the tile it starts in
+  auto commit = [&](uint32_t ls, uint32_t cend, const GtStats &st, bool deferred, uint32_t cm_off) {
+    while (ls >= (tile + 1) * T) {  // ls moved into a later tile of the run
+      if (lane == 0) a.census[tile] = n_local;
+      tile++;
+      n_local = 0;
+    }
+    if (n_local >= a.tile_quota) {
+      if (lane == 0) a.counters->pad[0] = 1;  // cannot happen: see tile_quota
+      return;
+    }
+    if (lane == 0) {
+      StreamEntry en;
+      en.ls = ls;
+      en.len = cend - ls;
+      en.ac = st.ac;
+      en.an = st.an;
+      en.n_het = st.n_het;
+      en.n_hom = st.n_hom;
+      en.n_miss = deferred ? kDeferred : st.n_miss;
+      en.cmap_off = cm_off;
+      a.entries[(size_t)tile * a.tile_quota + n_local] = en;
+    }
+    n_local++;
+    if (maps) cm_next++;
+  };
+  auto chunk_at = [&](uint32_t s_begin, uint32_t c) -> u32x4 {
+    const uint32_t off = min(s_begin + c * kChunk + 16u * lane, a.cap - 16u);
+    return ld_stream(a.buf + off);
+  };
+  auto finish_stats = [&](const FastAcc &acc, GtStats *st) {
+    wave_sum3(acc.het, acc.hom, acc.miss, ns, &st->n_het, &st->n_hom, &st->n_miss);
+    st->ac = st->n_het + 2u * st->n_hom;
+    st->an = 2u * (ns - st->n_miss);
+  };
+
+  while (p != kNone && p < r1) {
+    // ---- fixed columns: the 9th TAB, or the terminator if it comes first (main.go:535)
+    uint32_t found = 0, tab9 = kNone, eolp = kNone;
+    for (uint32_t base = p; base < nb; base += kChunk) {
+      tab9 = head_window(a, load16(a.buf, base + 16u * lane, a.cap), base, kWave, &found, &eolp);
+      if (tab9 != kNone || eolp != kNone) break;
+    }
+    if (tab9 == kNone) {
+      if (eolp == kNone) break;  // unterminated tail of the block: dropped (main.go:354-358)
+      seen++;                    // fewer than 10 fields: cannot pass linePasses
+      p = eolp + 1;
+      continue;
+    }
+    uint32_t s_begin = tab9 + 1;
+    GtStats st = {0, 0, 0, 0, 0};
+    const unsigned long long pred = (unsigned long long)s_begin + 4ull * ns - 1ull;  // predicted content end
+    uint32_t cend = kNone;
+
+    if (pred + a.eol_chars <= nb && pipelined) {
+      // ================= cross-line pipeline over consecutive regular lines =================
+      // A = the line being scanned (chunks in va), B = the next one: its head window (hv) is
+      // requested before A's chunks, parsed as soon as A starts, and every chunk register is
+      // re-issued for B right after A's chunk in it has been processed.
+      uint32_t pA = p, sA = s_begin, peA = (uint32_t)pred;
+      u32x4 va[kPipeChunks];
+      u32x4 hv = {0u, 0u, 0u, 0u};
+      bool hv_ok = peA + 1u < r1;  // B starts inside this wave's run
+      if (hv_ok && lane < 16) hv = load16(a.buf, peA + 1u + 16u * lane, a.cap);
+#pragma unroll
+      for (int g = 0; g < kPipeChunks; g++)
+        if ((uint32_t)g < n_chunks) va[g] = chunk_at(sA, g);
+      for (;;) {
+        // ---- B's head from the 256 B window
+        uint32_t sB = 0, peB = 0;
+        bool b_ok = false;
+        if (hv_ok) {
+          const uint32_t t9 = head_window16(a, hv, peA + 1u);
+          if (t9 != kNone) {
+            sB = t9 + 1;
+            const unsigned long long pb = (unsigned long long)sB + 4ull * ns - 1ull;
+            if (pb + 1ull <= nb) {
+              peB = (uint32_t)pb;
+              b_ok = true;
+            }
+          }
+        }
+        const bool hvc_ok = b_ok && peB + 1u < r1;
+        if (hvc_ok && lane < 16) hv = load16(a.buf, peB + 1u + 16u * lane, a.cap);  // C's head, ahead of B's chunks
+        // ---- scan A, re-issuing each register for B
+        const uint32_t cmA = map_slot();
+        uint8_t *cm = cmA != BVCF_NO_CMAP ? a.cmap + cmA : nullptr;
+        if (cm) zero_stage(stage);
+        FastAcc acc = {0, 1, 0, 0, 0};
+        const uint32_t sep = (__builtin_amdgcn_readfirstlane(va[0].x) >> 8) & 0xFFu;
+        if (sep != '|' && sep != '/') acc.bad = 1;
+        const uint32_t kref = 0x09300030u | (sep << 8);
+        const uint32_t term_xor = (a.eol_byte ^ 0x09u) << 24;
+#pragma unroll
+        for (int g = 0; g < kPipeChunks; g++) {
+          if ((uint32_t)g < n_chunks) {
+            fast_chunk(va[g], g, n_chunks, ns, kref, table1, cm, stage, a.cmap_stride, term_xor, acc);
+            if (b_ok) va[g] = chunk_at(sB, g);
+          }
+        }
+        if (__any(acc.bad != 0 || !(acc.ok & 1u))) {
+          // A is not regular after all: B was predicted from a wrong line end.  Leave the
+          // pipeline (the loads in flight are simply dropped) and take A the slow way.
+          s_begin = sA;
+          p = pA;
+          break;
+        }
+        finish_stats(acc, &st);
+        seen++;
+        commit(pA, peA, st, false, cmA);
+        p = peA + 1u;
+        if (!b_ok) {
+          s_begin = kNone;  // nothing pending: rediscover from p
+          break;
+        }
+        pA = peA + 1u;
+        sA = sB;
+        peA = peB;
+        hv_ok = hvc_ok;
+      }
+      if (s_begin == kNone) continue;
+      // fall through with (p, s_begin) of the line that failed the regular scan
+    } else if (pred + a.eol_chars <= nb) {
+      // ---- one line at a time (more than kPipeChunks chunks per line, or "\r\n")
+      const uint32_t pe = (uint32_t)pred;
+      bool term = true;
+      if (a.eol_chars == 2) term = a.buf[pe + 1] == a.eol_byte && a.buf[pe] != a.eol_byte;
+      if (term) {
+        const uint32_t cm_off = map_slot();
+        uint8_t *cm = cm_off != BVCF_NO_CMAP ? a.cmap + cm_off : nullptr;
+        if (gt_scan_fast(a, s_begin, ns, 1, cm, stage, a.eol_chars == 1, &st)) {
+          seen++;
+          commit(p, pe, st, false, cm_off);
+          p = pe + a.eol_chars;
+          continue;
+        }
+      }
+    }
+
+    // ---- not a regular "x|y<TAB>" region: only find where the line ends here; its ALT #1 scan is
+    // left to k_gt (k_head turns the entry into a task), which also settles its field count
+    {
+      const uint32_t e = find_eol(a, s_begin, nb);
+      if (e == kNone) break;  // unterminated tail
+      seen++;
+      if (e + 1 < s_begin + a.eol_chars) {
+        // chomping numChars bytes (main.go:535) eats the 9th TAB: at most 9 fields remain
+        p = e + 1;
+        continue;
+      }
+      cend = e + 1 - a.eol_chars;
+      // a line shorter than n_header - 1 bytes cannot have n_header fields: never listed (this
+      // is what bounds the per-tile quota)
+      const GtStats none = {0, 0, 0, 0, 0};
+      if (cend - p + 1u >= a.n_header) commit(p, cend, none, true, map_slot());
+      p = cend + a.eol_chars;
+    }
+  }
+  for (; tile < tile_hi; tile++) {  // the rest of the run has no line starts
+    if (lane == 0) a.census[tile] = n_local;
+    n_local = 0;
+  }
+  if (lane == 0 && seen) atomicAdd(&a.counters->lines_seen, seen);
+}
+
+// tile-local entries -> input order (the exclusive scan of the tile counts is in census/group_base)
+__global__ __launch_bounds__(kWgThreads) void k_order(KernelArgs a) {
+  const uint32_t total = a.n_tiles * a.tile_quota;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t tile = i / a.tile_quota, k = i % a.tile_quota;
+    const uint32_t first = a.census[tile] + a.group_base[tile / kScanGroup];
+    const uint32_t next = (tile + 1 < a.n_tiles)
+                              ? a.census[tile + 1] + a.group_base[(tile + 1) / kScanGroup]
+                              : a.counters->n_lines;
+    if (k >= next - first) continue;
+    const uint32_t g = first + k;
+    if (g >= a.max_lines) continue;
+    const StreamEntry en = a.entries[i];
+    a.line_off[g] = en.ls;
+    a.line_len[g] = en.len;
+    a.line_cmap[g] = en.cmap_off;
+    if (g < a.max_tasks) {
+      GtResult r;
+      r.ac = en.ac;
+      r.an = en.an;
+      r.n_het = en.n_het;
+      r.n_hom = en.n_hom;
+      r.n_miss = en.n_miss;
+      r.n_fields = en.n_miss == kDeferred ? kDeferred : a.n_header - 9u;
+      r.pad[0] = r.pad[1] = 0;
+      a.results[g] = r;
+    }
+  }
+}
+
+
+}  // namespace bvcf_dev
