@@ -61,7 +61,7 @@ class Config(C.Structure):
         ("exclude_filter", C.c_char_p), ("keep_id", C.c_uint8), ("keep_info", C.c_uint8),
         ("keep_pos", C.c_uint8), ("keep_qual", C.c_uint8), ("normalize_header", C.c_uint8),
         ("reserved", C.c_uint8 * 3), ("device", C.c_int32), ("n_format_threads", C.c_uint32),
-        ("max_batch_bytes", C.c_uint64),
+        ("max_batch_bytes", C.c_uint64), ("sample_list_path", C.c_char_p),
     ]
 
 
@@ -142,6 +142,9 @@ def make_config(cfg=None, device=0, max_batch_bytes=0, n_format_threads=0):
     c.device = device
     c.max_batch_bytes = max_batch_bytes
     c.n_format_threads = n_format_threads
+    if cfg.get("sample"):
+        keep.append(cfg["sample"].encode())
+        c.sample_list_path = keep[-1]
     c._keep = keep
     return c
 

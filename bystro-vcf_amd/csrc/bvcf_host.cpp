@@ -5,6 +5,7 @@
 #include "../../include/bvcf.h"
 
 #include <errno.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -326,10 +327,41 @@ uint32_t choose_path(const Run &R, const uint8_t *data, size_t n) {
   return (e - pos == 2 && data[pos] == 'G' && data[pos + 1] == 'T') ? 2u : 1u;
 }
 
+// writeSampleListIfWanted + makeSampleList, main.go:398-445: header fields 9.. one per line; the file is
+// opened O_WRONLY|O_CREATE (no truncation), and stays empty when the header has fewer than 10 fields
+int write_sample_list(const Run &R) {
+  const char *path = R.cfg->sample_list_path;
+  if (!path || !*path) return 0;
+  int fd = open(path, O_WRONLY | O_CREAT, 0644);
+  if (fd < 0) return -1;
+  std::string s;
+  if (R.pre.header.size() >= 10)
+    for (size_t i = 9; i < R.pre.header.size(); i++) {
+      s.append(R.pre.header[i]);
+      s.push_back('\n');
+    }
+  size_t off = 0;
+  while (off < s.size()) {
+    ssize_t w = write(fd, s.data() + off, s.size() - off);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      close(fd);
+      return -1;
+    }
+    off += (size_t)w;
+  }
+  fsync(fd);
+  return close(fd);
+}
+
 int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_data = 0) {
   if (R.pre.header.size() < 8) {
     // the reference indexes record[6] / record[7] unguarded: out of contract
     *msg = "Malformed header: fewer than 8 fields";
+    return BVCF_E_FATAL;
+  }
+  if (write_sample_list(R)) {  // main.go:298-304
+    *msg = "Couldn't write sample list file";
     return BVCF_E_FATAL;
   }
   bvcf_params p;

@@ -162,6 +162,7 @@ int main(int argc, char **argv) {
   cfg.keep_qual = c.keep_qual;
   cfg.device = c.device;
   if (c.batch_mb) cfg.max_batch_bytes = c.batch_mb << 20;
+  cfg.sample_list_path = c.sample.c_str();
   const char *raw = getenv("BVCF_RAW_SAMPLE_NAMES");
   if (raw && *raw == '1') cfg.normalize_header = 0;
 

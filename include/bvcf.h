@@ -231,6 +231,7 @@ typedef struct {
   int32_t device;               /* HIP device ordinal */
   uint32_t n_format_threads;    /* 0 = hardware concurrency */
   uint64_t max_batch_bytes;     /* 0 = 64 MiB */
+  const char *sample_list_path; /* --sample: write the sample names, one per line (main.go:398-445); NULL/"" = no */
 } bvcf_config;
 
 void bvcf_config_defaults(bvcf_config *c); /* setup() defaults, main.go:84-99 */

@@ -1035,6 +1035,10 @@ int main(int argc, char **argv) {
   int rv = orc_read_vcf(&cfg, in.data ? in.data : "", in.len, &out, &err, NULL);
   fwrite(out.data, 1, out.len, stdout);
   if (err.len) fwrite(err.data, 1, err.len, stderr);
+  orc_buf_free(&in);
+  orc_buf_free(&out);
+  orc_buf_free(&err);
+  if (f != stdin) fclose(f);
   return rv;
 }
 #endif

@@ -248,3 +248,17 @@ def test_streaming_tile_boundaries(bv, monkeypatch, tile_kb, bvcf_path, golden_1
     assert len(row) == tile_kb * 1024
     both(bv, h + row * 9, {"allow": ""})
     both(bv, h + (row[:-1] + b"\t\n") * 3 + row * 2, {"allow": ""})
+
+
+def test_sample_list(bv, tmp_path, known_answers):
+    """--sample: main_test.go:171-270 (names one per line; nothing when the header has no samples)"""
+    path = tmp_path / "samples.txt"
+    vcf = vcfgen.gen_vcf(71, 20, 4, weird=0.0)
+    rc, _, log, _ = bv.run_buffer(vcf, {"sample": str(path)})
+    assert rc == 0, log
+    assert path.read_text().split("\n") == ["S00000", "S00001", "S00002", "S00003", ""]
+    path2 = tmp_path / "samples2.txt"
+    rc, _, _, _ = bv.run_buffer(vcfgen.gen_vcf(72, 5, 0), {"sample": str(path2)})
+    assert rc == 0 and path2.read_text() == ""
+    p = _run_cli(["--sample", str(tmp_path / "s3.txt")], vcf)
+    assert p.returncode == 0 and (tmp_path / "s3.txt").read_text().count("\n") == 4
