@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
     ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
     ap.add_argument("--path", type=int, default=0, help="0 choose, 1 census path, 2 streaming path")
+    ap.add_argument("--golden", action="store_true",
+                    help="experiment: real 1000-Genomes lines (tests/golden/1kg_chr1_20klines.vcf.gz, 19 747 rows "
+                         "replicated to --rows) instead of the synthetic model")
     args = ap.parse_args()
 
     import torch
@@ -106,13 +109,31 @@ def main():
     ns = cfg.n_samples
     # ---- synthetic batches, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)
     blocks, sizes = [], []
-    for first in rank_blocks(rank, args.blocks, args.rows):
-        t, nbytes = bg.rows_device(cfg, first, args.rows, pad=bv.DEVICE_PAD)
-        blocks.append(t)
-        sizes.append(nbytes)
+    if args.golden:
+        import gzip
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "1kg_chr1_20klines.vcf.gz"), "rb") as f:
+            raw = f.read()
+        body = raw[raw.index(b"\n", raw.index(b"#CHROM")) + 1:]
+        n_body = body.count(b"\n")
+        reps = max(1, args.rows // n_body)
+        args.rows = reps * n_body
+        host = torch.frombuffer(bytearray(body), dtype=torch.uint8)
+        for b in range(args.blocks):
+            t = torch.full((len(body) * reps + bv.DEVICE_PAD,), 10, dtype=torch.uint8, device="cuda")
+            dev = host.cuda()
+            for r in range(reps):
+                t[r * len(body):(r + 1) * len(body)] = dev
+            blocks.append(t)
+            sizes.append(len(body) * reps)
+        torch.cuda.synchronize()
+    else:
+        for first in rank_blocks(rank, args.blocks, args.rows):
+            t, nbytes = bg.rows_device(cfg, first, args.rows, pad=bv.DEVICE_PAD)
+            blocks.append(t)
+            sizes.append(nbytes)
     max_bytes = max(sizes)
     stride = ((ns + 3) // 4 + 15) & ~15
-    n_alt_cap = args.rows * (4 if args.profile == "c4" else 1) + 1024
+    n_alt_cap = args.rows * (4 if args.profile == "c4" or args.golden else 1) + 1024
     ctx = bv.Ctx(bg.n_header_fields(cfg), device=local_rank, max_batch_bytes=max_bytes, n_slots=1,
                  max_lines=args.rows + 16, max_alleles=n_alt_cap,
                  cmap_bytes=(n_alt_cap + 16 * 8192) * stride + 4096,  # + the streaming path's per-wave map blocks
