@@ -3,6 +3,7 @@
 //
 // Nothing here computes what the kernels compute: rows are assembled from bvcf_result only.
 #include "../../include/bvcf.h"
+#include "bvcf_input.h"
 
 #include <errno.h>
 #include <fcntl.h>
@@ -618,7 +619,9 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   std::atomic<bool> eol_known{false};
 
   // ---- reader: whole lines per block; the partial last line is carried into the next buffer
+  std::string source_err;
   std::thread reader([&]() {
+    bvcf_input::ByteSource src(fd_in, std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
     std::vector<uint8_t> carry;
     bool first = true, eof = false;
     while (!eof && !stop.load()) {
@@ -630,9 +633,10 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       if (fill) memcpy(b.buf, carry.data(), fill);
       carry.clear();
       while (!eof && fill < cap) {
-        ssize_t got = read(fd_in, b.buf + fill, cap - fill);
+        ssize_t got = src.read(b.buf + fill, cap - fill);
+        if (got == bvcf_input::ByteSource::kNoRoom) break;  // this buffer is as full as it gets
         if (got < 0) {
-          if (errno == EINTR) continue;
+          source_err = src.error();
           b.read_error = true;
           eof = true;
           break;
@@ -747,7 +751,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     double t0 = now_s();
     Block b = ready_q.pop();
     t_wait_read += now_s() - t0;
-    if (b.read_error) fail(std::string("read: ") + strerror(errno), BVCF_E_FATAL);
+    if (b.read_error) fail(source_err.empty() ? std::string("read error") : source_err, BVCF_E_FATAL);
     if (b.too_long) fail("a line is longer than max_batch_bytes", BVCF_E_TOO_BIG);
     if (!done && b.buf && !have_pre) {
       t0 = now_s();

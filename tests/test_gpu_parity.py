@@ -262,3 +262,35 @@ def test_sample_list(bv, tmp_path, known_answers):
     assert rc == 0 and path2.read_text() == ""
     p = _run_cli(["--sample", str(tmp_path / "s3.txt")], vcf)
     assert p.returncode == 0 and (tmp_path / "s3.txt").read_text().count("\n") == 4
+
+
+def test_compressed_input(bv, golden_1kg, tmp_path):
+    """the CLI reads gzip and BGZF itself (the reference needs `pigz -d -c` in front)"""
+    import gzip
+    import bgzf
+    vcf = vcfgen.gen_vcf(81, 4000, 150, weird=0.02)
+    want = _run_cli(["--keepId"], vcf)
+    assert want.returncode == 0
+    for name, data in (("gz", gzip.compress(vcf, 1)), ("bgzf", bgzf.bgzf_compress(vcf)),
+                       ("bgzf-small", bgzf.bgzf_compress(vcf, block=777, eof_marker=False)),
+                       ("gz-members", gzip.compress(vcf[:100000]) + gzip.compress(vcf[100000:]))):
+        p = _run_cli(["--keepId", "--batchMB", "2"], data)
+        assert p.returncode == 0, (name, p.stderr[-300:])
+        assert p.stdout == want.stdout and p.stderr == want.stderr, name
+        f = tmp_path / ("in." + name)
+        f.write_bytes(data)
+        p = _run_cli(["--keepId", "--in", str(f)], b"")
+        assert p.returncode == 0 and p.stdout == want.stdout, name
+    # the reference's own regression input, exactly as shipped (.vcf.gz, single-stream gzip)
+    raw = open(os.path.join(ROOT, "tests", "golden", "1kg_chr1_20klines.vcf.gz"), "rb").read()
+    p = _run_cli([], raw)
+    assert p.returncode == 0
+    rows = p.stdout.split(b"\n")
+    assert sorted(rows[1:-1]) == golden_1kg[1]
+    # damaged input: message on stderr, exit status 1
+    p = _run_cli([], bgzf.bgzf_compress(vcf)[:-40])
+    assert p.returncode == 1 and b"bgzf" in p.stderr
+    bad = bytearray(gzip.compress(vcf, 1))
+    bad[len(bad) // 2] ^= 0xFF
+    p = _run_cli([], bytes(bad))
+    assert p.returncode == 1 and b"gzip" in p.stderr
