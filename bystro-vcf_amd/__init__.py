@@ -41,7 +41,7 @@ CLS_NONE, CLS_HET, CLS_HOM, CLS_MISSING = 0, 1, 2, 3
 EXPORTS = [
     "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_alloc_pinned",
     "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_bench_device", "bvcf_counters",
-    "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_free",
+    "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_free",
 ]
 
 
@@ -116,6 +116,7 @@ lib.bvcf_run_buffer.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t, C.POI
                                 C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                 C.POINTER(C.c_uint64)]
 lib.bvcf_run_fd.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+lib.bvcf_decompress_fd.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_char_p]
 lib.bvcf_free.argtypes = [C.c_void_p]
 lib.bvcf_free.restype = None
 
@@ -169,6 +170,19 @@ def run_buffer(vcf_bytes, cfg=None, device=0, max_batch_bytes=0, n_format_thread
     lib.bvcf_free(out)
     lib.bvcf_free(log)
     return rc, o, e, n_lines.value
+
+
+def decompress(data, n_threads=0):
+    """gzip / BGZF / plain bytes -> (rc, bytes, kind) through the driver's byte source (host only)"""
+    import tempfile
+    with tempfile.TemporaryFile() as fi, tempfile.TemporaryFile() as fo:
+        fi.write(data)
+        fi.flush()
+        fi.seek(0)
+        kind = C.create_string_buffer(8)
+        rc = lib.bvcf_decompress_fd(fi.fileno(), fo.fileno(), n_threads, kind)
+        fo.seek(0)
+        return rc, fo.read(), kind.value.decode()
 
 
 class Batch:

@@ -485,6 +485,31 @@ size_t bvcf_string_header(const bvcf_config *c, char *out, size_t cap) {
 
 void bvcf_free(void *p) { free(p); }
 
+int bvcf_decompress_fd(int fd_in, int fd_out, uint32_t n_threads, char *kind_out) {
+  if (!n_threads) n_threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  bvcf_input::ByteSource src(fd_in, n_threads);
+  std::vector<uint8_t> buf(8u << 20);
+  for (;;) {
+    ssize_t got = src.read(buf.data(), buf.size());
+    if (got == 0) break;
+    if (got < 0) {
+      if (kind_out) snprintf(kind_out, 8, "%s", src.kind());
+      return BVCF_E_FATAL;
+    }
+    size_t off = 0;
+    while (off < (size_t)got) {
+      ssize_t w = write(fd_out, buf.data() + off, (size_t)got - off);
+      if (w < 0) {
+        if (errno == EINTR) continue;
+        return BVCF_E_FATAL;
+      }
+      off += (size_t)w;
+    }
+  }
+  if (kind_out) snprintf(kind_out, 8, "%s", src.kind());
+  return BVCF_OK;
+}
+
 int bvcf_format_tsv(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const char *const *sample_names,
                     const uint32_t *sample_name_lens, char **out, size_t *n_out, char **log, size_t *n_log) {
   if (!c || !r || !out || !n_out) return BVCF_E_ARG;

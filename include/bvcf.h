@@ -257,6 +257,10 @@ int bvcf_run_buffer(const bvcf_config *c, const uint8_t *vcf, size_t n, char **o
  * log lines to fd_err */
 int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_t *n_lines_in);
 
+/* the byte source in front of bvcf_run_fd on its own: copies fd_in to fd_out, inflating gzip (streaming)
+ * or BGZF (block-parallel, n_threads workers; 0 = up to 32) on the way.  Host-only: needs no device. */
+int bvcf_decompress_fd(int fd_in, int fd_out, uint32_t n_threads, char *kind_out /* >= 8 bytes or NULL */);
+
 void bvcf_free(void *p);
 
 #ifdef __cplusplus
