@@ -344,10 +344,13 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
   uint8_t *stage = s_stage[threadIdx.x >> 6];
   const int lane = lane_id();
-  const uint32_t n_tasks = min(min(a.counters->n_lines, a.max_lines) + a.counters->n_tasks, a.max_tasks);
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t n_tasks = min(n_lines + a.counters->n_tasks, a.max_tasks);
   const uint32_t stride = gridDim.x * kWavesPerWg;
   const uint32_t ns = a.n_samples;
-  uint32_t ti = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  // streaming path: ALT #1 of every regular line is already scanned; only the slots past n_lines
+  // (further ALT indices, and lines k_stream merely delimited) hold tasks
+  uint32_t ti = (a.fused ? n_lines : 0u) + blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
   GtTask nxt = GtTask{};
   if (ti < n_tasks) nxt = a.tasks[ti];
   for (; ti < n_tasks; ti += stride) {

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       return sp;
     };
 
-    uint32_t rec_first = 0, n_rec = 0, site_type = 0;
+    uint32_t rec_first = 0, n_rec = 0, site_type = 0, first_task = line;
     bool task_written = false, primary_written = false;
 
     // ---- part 1: gate and what the line will need
@@ -288,7 +288,10 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
     // the line's own; only further records / ALT indices draw from the batch counters.  Biallelic
     // lines — all of a 1KG-shaped file — never touch an atomic.
     const uint32_t want_rec = bound > 1 ? bound - 1 : 0u;
-    const uint32_t want_task = (eval && ns > 0 && mode == 2) ? n_commas : 0u;
+    // streaming path: a line whose ALT #1 scan k_stream left to k_gt takes one more task slot, so
+    // that k_gt only has to visit the slots past n_lines there
+    const bool deferred = eval && a.fused && ns > 0 && line < a.max_tasks && a.results[line].n_fields == kDeferred;
+    const uint32_t want_task = ((eval && ns > 0 && mode == 2) ? n_commas : 0u) + (deferred ? 1u : 0u);
     uint32_t wt_rec, wt_task;
     uint32_t extra_base = wave_excl_scan(want_rec, &wt_rec);
     uint32_t task_base = wave_excl_scan(want_task, &wt_task);
@@ -332,15 +335,21 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
         put_task(a, line, line, 1, s_begin, cend, cm0);
         task_written = true;
       }
+      uint32_t task0 = line;  // where ALT #1's counts are (to be) found
+      uint32_t tasks_used = 0;
       if (ns > 0 && a.fused) {
-        if (maps) cm0 = a.line_cmap[line];
-        if (line < a.max_tasks && a.results[line].n_fields == kDeferred) {  // k_stream left the scan to k_gt
-          put_task(a, line, line, 1, s_begin, cend, cm0);
-          task_written = true;
+        if (deferred) {
+          task0 = task_base;
+          cm0 = cmap_of(a, map_base, maps);
+          put_task(a, task0, line, 1, s_begin, cend, cm0);
+          tasks_used = 1;
+        } else if (maps) {
+          cm0 = a.line_cmap[line];
         }
       }
+      first_task = task0;
 
-      uint32_t cur = 0, emitted = 0, tasks_used = 0;
+      uint32_t cur = 0, emitted = 0;
       if (mode == 1 || mode == 2) {
 #pragma nounroll
         for (uint32_t k = 0;; k++) {
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
           if (e.err) log_err(a, line, (e.err == BVCF_ERR_POS) ? 0u : k + 1u, e.err);
           if (e.stop) break;
           if (!e.n) continue;
-          uint32_t task = line, cm_off = cm0;
+          uint32_t task = task0, cm_off = cm0;
           if (ns > 0 && k > 0) {
             task = task_base + tasks_used;
             cm_off = cmap_of(a, map_base + tasks_used, maps);
@@ -419,13 +428,14 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       L.rec_first = rec_first;
       L.n_rec = n_rec;
       L.n_fields = n_fields;
-      L.gt_task = line;
+      L.gt_task = first_task;
       L.status = (uint8_t)status;
       L.site_type = (uint8_t)site_type;
       L.pad[0] = L.pad[1] = 0;
       a.lines[line] = L;
       // every line owns task slot `line` and record slot `line`: mark the ones it did not fill
-      if (ns > 0 && !task_written) put_task(a, line, line, 0, cend, cend, BVCF_NO_CMAP);
+      // (the streaming path's k_gt never looks at the first n_lines task slots)
+      if (ns > 0 && !task_written && !a.fused) put_task(a, line, line, 0, cend, cend, BVCF_NO_CMAP);
       if (!primary_written && line < a.max_alleles) a.alleles[line].gt_task = kNoTask;
     }
   }
@@ -446,7 +456,8 @@ __global__ __launch_bounds__(kWgThreads) void k_finish(KernelArgs a) {
     bvcf_line *L = &a.lines[i];
     const uint32_t st = L->status;
     if (st != BVCF_LINE_OK && st != BVCF_LINE_NOALLELE) continue;
-    const uint32_t nf = 9u + a.results[i].n_fields;
+    if (L->gt_task >= n_tasks) continue;
+    const uint32_t nf = 9u + a.results[L->gt_task].n_fields;
     L->n_fields = nf;
     if (nf != a.n_header) {
       L->status = BVCF_LINE_FIELDS;

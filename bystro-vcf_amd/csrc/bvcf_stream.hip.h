@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   };
   // list a line (in input order) in the tile it starts in
   auto commit = [&](uint32_t ls, uint32_t cend, const GtStats &st, bool deferred, uint32_t cm_off) {
+    // (a deferred line gets its class map with its k_gt task, not here)
     while (ls >= (tile + 1) * T) {  // ls moved into a later tile of the run
       if (lane == 0) a.census[tile] = n_local;
       tile++;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
       a.entries[(size_t)tile * a.tile_quota + n_local] = en;
     }
     n_local++;
-    if (maps) cm_next++;
+    if (maps && !deferred) cm_next++;
   };
   auto chunk_at = [&](uint32_t s_begin, uint32_t c) -> u32x4 {
     const uint32_t off = min(s_begin + c * kChunk + 16u * lane, a.cap - 16u);
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
       // a line shorter than n_header - 1 bytes cannot have n_header fields: never listed (this
       // is what bounds the per-tile quota)
       const GtStats none = {0, 0, 0, 0, 0};
-      if (cend - p + 1u >= a.n_header) commit(p, cend, none, true, map_slot());
+      if (cend - p + 1u >= a.n_header) commit(p, cend, none, true, BVCF_NO_CMAP);
       p = cend + a.eol_chars;
     }
   }
