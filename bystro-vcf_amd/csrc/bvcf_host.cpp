@@ -103,6 +103,7 @@ void append_err(std::string &log, const bvcf_err &e, const bvcf_line &L, const u
     case BVCF_ERR_INS1: log.append(tmp, (size_t)snprintf(tmp, sizeof tmp, " ALT #%u ", e.alt_no)); break;
     case BVCF_ERR_DEL1:
     case BVCF_ERR_MIXED: log.append(tmp, (size_t)snprintf(tmp, sizeof tmp, " ALT#%u ", e.alt_no)); break;
+    case BVCF_ERR_EMPTY_REF: log.append(e.alt_no == 1 ? " ALT #1 " : " "); break;
     default: log.push_back(' '); break;
   }
   log.append(err_text(e.code));

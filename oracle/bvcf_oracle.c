@@ -86,6 +86,22 @@ static void log_printf(orc_buf *log, const char *fmt, ...) {
   if (log->len == 0 || log->data[log->len - 1] != '\n') buf_putc(log, '\n');
 }
 
+/* one getAlleles message: "<chrom>:<pos><rest>\n" with chrom/pos as raw bytes (Go strings may hold NULs) */
+static void log_site(orc_buf *log, const char *chrom, size_t nchrom, const char *pos, size_t npos,
+                     const char *fmt, ...) {
+  if (!log) return;
+  char tmp[256];
+  va_list ap;
+  va_start(ap, fmt);
+  int n = vsnprintf(tmp, sizeof tmp, fmt, ap);
+  va_end(ap);
+  buf_write(log, chrom, nchrom);
+  buf_putc(log, ':');
+  buf_write(log, pos, npos);
+  if (n > 0) buf_write(log, tmp, (size_t)n < sizeof tmp ? (size_t)n : sizeof tmp - 1);
+  buf_putc(log, '\n');
+}
+
 /* strconv.Itoa */
 static void buf_itoa(orc_buf *b, long long v) {
   char tmp[32];
@@ -289,18 +305,17 @@ void orc_get_alleles(const char *chrom, size_t nchrom, const char *pos, size_t n
                      const char *ref, size_t nref, const char *alt, size_t nalt,
                      orc_alleles *out, orc_buf *log) {
   alleles_init(out);
-  const int ic = (int)nchrom, ip = (int)npos;
 
   /* main.go:729-732 */
   if (nalt == nref && memcmp(alt, ref, nalt) == 0) {
-    log_printf(log, "%.*s:%.*s : %s", ic, chrom, ip, pos, "REF == ALT");
+    log_site(log, chrom, nchrom, pos, npos, " : %s", "REF == ALT");
     return;
   }
 
   /* main.go:735-765 */
   if (nalt == 1) {
     if (alt[0] != 'A' && alt[0] != 'C' && alt[0] != 'G' && alt[0] != 'T') {
-      log_printf(log, "%.*s:%.*s ALT #1 %s", ic, chrom, ip, pos, "ALT not ACTG");
+      log_site(log, chrom, nchrom, pos, npos, " ALT #1 %s", "ALT not ACTG");
       return;
     }
     if (nref == 1) {
@@ -310,16 +325,16 @@ void orc_get_alleles(const char *chrom, size_t nchrom, const char *pos, size_t n
     }
     /* nref == 0 would index ref[0] out of range in Go (panic); reject */
     if (nref == 0) {
-      log_printf(log, "%.*s:%.*s ALT #1 %s", ic, chrom, ip, pos, "empty REF");
+      log_site(log, chrom, nchrom, pos, npos, " ALT #1 %s", "empty REF");
       return;
     }
     if (alt[0] != ref[0]) {
-      log_printf(log, "%.*s:%.*s ALT #1 %s", ic, chrom, ip, pos, "1st base REF != ALT");
+      log_site(log, chrom, nchrom, pos, npos, " ALT #1 %s", "1st base REF != ALT");
       return;
     }
     long long int_pos;
     if (!go_atoi(pos, npos, &int_pos)) {
-      log_printf(log, "%.*s:%.*s ALT #1 %s", ic, chrom, ip, pos, "Invalid POS");
+      log_site(log, chrom, nchrom, pos, npos, " ALT #1 %s", "Invalid POS");
       return;
     }
     strcpy(out->site_type, "DEL");
@@ -328,7 +343,7 @@ void orc_get_alleles(const char *chrom, size_t nchrom, const char *pos, size_t n
   }
 
   if (nref == 0) { /* Go would panic on ref[0] below; reject */
-    log_printf(log, "%.*s:%.*s %s", ic, chrom, ip, pos, "empty REF");
+    log_site(log, chrom, nchrom, pos, npos, " %s", "empty REF");
     return;
   }
 
@@ -347,7 +362,7 @@ void orc_get_alleles(const char *chrom, size_t nchrom, const char *pos, size_t n
     if (!multi && alt_idx > 0) multi = 1; /* main.go:777-779 */
 
     if (!orc_alt_is_valid(t, nt)) { /* main.go:781-784 */
-      log_printf(log, "%.*s:%.*s ALT #%d %s", ic, chrom, ip, pos, alt_idx + 1, "ALT not ACTG");
+      log_site(log, chrom, nchrom, pos, npos, " ALT #%d %s", alt_idx + 1, "ALT not ACTG");
       continue;
     }
 
@@ -357,7 +372,7 @@ void orc_get_alleles(const char *chrom, size_t nchrom, const char *pos, size_t n
         continue;
       }
       if (t[0] != ref[0]) {
-        log_printf(log, "%.*s:%.*s ALT #%d %s", ic, chrom, ip, pos, alt_idx + 1,
+        log_site(log, chrom, nchrom, pos, npos, " ALT #%d %s", alt_idx + 1,
                    "1st base ALT != REF");
         continue;
       }
@@ -368,14 +383,14 @@ void orc_get_alleles(const char *chrom, size_t nchrom, const char *pos, size_t n
     /* main.go:822-830 */
     if (int_pos == 0) {
       if (!go_atoi(pos, npos, &int_pos)) {
-        log_printf(log, "%.*s:%.*s %s", ic, chrom, ip, pos, "Invalid POS");
+        log_site(log, chrom, nchrom, pos, npos, " %s", "Invalid POS");
         break;
       }
     }
 
     if (nt == 1) { /* main.go:832-847 */
       if (t[0] != ref[0]) {
-        log_printf(log, "%.*s:%.*s ALT#%d %s", ic, chrom, ip, pos, alt_idx + 1,
+        log_site(log, chrom, nchrom, pos, npos, " ALT#%d %s", alt_idx + 1,
                    "1st base REF != ALT");
         continue;
       }
@@ -396,7 +411,7 @@ void orc_get_alleles(const char *chrom, size_t nchrom, const char *pos, size_t n
       while (lt + r > 0 && lr + r > 1 && t[lt + r - 1] == ref[lr + r - 1]) r--;
       const long long offset = lr + r;
       if (memcmp(ref, t, (size_t)offset) != 0) {
-        log_printf(log, "%.*s:%.*s ALT#%d %s", ic, chrom, ip, pos, alt_idx + 1,
+        log_site(log, chrom, nchrom, pos, npos, " ALT#%d %s", alt_idx + 1,
                    "Mixed indel/snp sites not supported");
         continue;
       }
@@ -411,7 +426,7 @@ void orc_get_alleles(const char *chrom, size_t nchrom, const char *pos, size_t n
       while (lt + r > 1 && lr + r > 0 && t[lt + r - 1] == ref[lr + r - 1]) r--;
       const long long offset = lt + r;
       if (memcmp(ref, t, (size_t)offset) != 0) {
-        log_printf(log, "%.*s:%.*s ALT#%d %s", ic, chrom, ip, pos, alt_idx + 1,
+        log_site(log, chrom, nchrom, pos, npos, " ALT#%d %s", alt_idx + 1,
                    "Mixed indel/snp sites not supported");
         continue;
       }

@@ -294,3 +294,35 @@ def test_compressed_input(bv, golden_1kg, tmp_path):
     bad[len(bad) // 2] ^= 0xFF
     p = _run_cli([], bytes(bad))
     assert p.returncode == 1 and b"gzip" in p.stderr
+
+
+def _garbage_vcf(seed, n_lines, n_samples):
+    """structurally hostile input: random bytes biased towards the characters the parsers care about"""
+    import random
+    rng = random.Random(seed)
+    alphabet = b"\t\t\t\t\t\t,,..||//::00112ACGTN<>*\r\x00\xff-+ 9PASSq;="
+    out = [vcfgen.header(n_samples).encode()]
+    for i in range(n_lines):
+        r = rng.random()
+        if r < 0.5:  # mutate a valid line
+            line = bytearray(vcfgen.gen_line(rng, n_samples, 1000 + i, fmt_extra=rng.random() < 0.3, weird=0.2).encode())
+            for _ in range(rng.randint(0, 6)):
+                k = rng.randrange(len(line) - 1)
+                line[k] = rng.choice(alphabet)
+            line = bytes(line).replace(b"\n", b" ") + b"\n"
+        elif r < 0.8:  # random fields, right count
+            nf = 9 + n_samples if n_samples else 8
+            line = b"\t".join(bytes(rng.choice(alphabet.replace(b"\t", b"")) for _ in range(rng.randint(0, 6)))
+                              for _ in range(nf)) + b"\n"
+        else:  # pure junk of random length
+            line = bytes(rng.choice(alphabet) for _ in range(rng.randint(0, 400))).replace(b"\n", b"") + b"\n"
+        out.append(line)
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("seed,n_lines,n_samples", [(201, 600, 0), (202, 600, 1), (203, 500, 5), (204, 300, 70),
+                                                     (205, 200, 300)])
+def test_garbage_parity(bv, seed, n_lines, n_samples):
+    vcf = _garbage_vcf(seed, n_lines, n_samples)
+    both(bv, vcf, {"allow": ""})
+    both(bv, vcf, {"allow": "PASS,q", "exclude": ".", "keepInfo": True, "keepId": True, "keepPos": True})
