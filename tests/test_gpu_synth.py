@@ -87,3 +87,55 @@ def test_full_size_properties_c3(mods):
     b2 = ctx.collect()
     assert (b2.alleles[:rows]["ac"] == al["ac"]).all()
     ctx.close()
+
+
+def test_full_size_properties_c4(mods):
+    """BASELINE configs[3] at bench size (65 536 rows x 2 504 samples, 20 % multiallelic, 15 % indels,
+    1 % malformed): invariants that hold for every record whatever the data, both device paths agreeing
+    record by record, and oracle spot checks."""
+    import torch
+    bg, bv = mods
+    cfg = bg.make_cfg("c4")
+    rows = 65536
+    ns = cfg.n_samples
+    t, nbytes = bg.rows_device(cfg, 42_000_000, rows, pad=bv.DEVICE_PAD)
+    stride = ((ns + 3) // 4 + 15) & ~15
+    ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=1, max_lines=rows + 16,
+                 max_alleles=4 * rows, cmap_bytes=(4 * rows + 16 * 8192) * stride)
+    ctx.submit_device(t.data_ptr(), nbytes)
+    b = ctx.collect()
+    ctx.close()
+    assert len(b.lines) == rows and b.n_lines_seen == rows
+    ok = b.lines["status"] == bv.LINE_OK
+    assert 0.97 * rows < ok.sum() < rows            # ~1 % malformed rows yield no allele
+    assert (b.lines["status"][~ok] == bv.LINE_NOALLELE).all()
+    n_multi = n_del = n_ins = 0
+    for i in np.flatnonzero(ok)[:: 37]:
+        recs = b.records(int(i))
+        assert len(recs) == b.lines["n_rec"][i] >= 1
+        for r in recs:
+            assert r["an"] == 2 * ns and r["n_miss"] == 0
+            assert r["ac"] == r["n_het"] + 2 * r["n_hom"]
+            cls = b.classes(r)
+            assert (cls == 1).sum() == r["n_het"] and (cls == 2).sum() == r["n_hom"] and (cls == 3).sum() == 0
+        n_multi += recs[0]["site_type"] == 4
+        n_del += recs[0]["site_type"] == 2
+        n_ins += recs[0]["site_type"] == 1
+        if recs[0]["site_type"] == 4:               # alleles of one site partition the carriers
+            assert sum(int(r["ac"]) for r in recs) <= 2 * ns
+    assert n_multi > 100 and n_del > 30 and n_ins > 30
+    # oracle on a sample of whole lines
+    host = bytes(t[:nbytes].cpu().numpy())
+    lines = host.split(b"\n")
+    pick = list(range(0, rows, 1499))
+    rc, out, _, _ = orc.run(bg.header(cfg) + b"".join(lines[i] + b"\n" for i in pick), {"keepInfo": True})
+    want = {}
+    for r in out.split(b"\n"):
+        if r:
+            f = r.split(b"\t")
+            want.setdefault(f[-1], []).append((f[1], f[4], int(f[12]), int(f[13]), int(f[-2])))
+    for i in pick:
+        L = b.lines[i]
+        info = lines[i].split(b"\t")[7]
+        got = [(r["ac"], r["an"], r["alt_idx"]) for r in b.records(i) if r["ac"] > 0]
+        assert sorted((a, n, k) for (_, _, a, n, k) in want.get(info, [])) == sorted((int(a), int(n), int(k)) for a, n, k in got)
