@@ -101,11 +101,27 @@ struct KernelArgs {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+// Cross-lane sums stay in the VALU: DPP row shifts inside each row of 16 lanes, then the two row
+// broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  __shfl_* goes through
+// the LDS crossbar (ds_bpermute + an lgkmcnt wait per step), which is what the per-line tail of
+// k_stream used to spend most of its time on.
+// inclusive prefix sum over the 64 lanes (lane 63 ends up with the wave total)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
+
+// value of lane `src` (wave-uniform index) in every lane's scalar view: v_readlane, no LDS
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int src) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return lane_value(wave_incl_scan(v), kWave - 1); }
 
 // three per-lane counts -> wave totals; two of them share a register while they fit 16 bits
 __device__ __forceinline__ void wave_sum3(uint32_t a, uint32_t b, uint32_t c, uint32_t limit, uint32_t *sa,
@@ -123,17 +139,12 @@ __device__ __forceinline__ void wave_sum3(uint32_t a, uint32_t b, uint32_t c, ui
 
 // exclusive prefix sum over the 64 lanes; *total receives the wave sum
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) {
-  uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    uint32_t t = __shfl_up(inc, d, kWave);
-    if (lane_id() >= d) inc += t;
-  }
-  *total = __shfl(inc, kWave - 1, kWave);
+  const uint32_t inc = wave_incl_scan(v);
+  *total = lane_value(inc, kWave - 1);
   return inc - v;
 }
 
-__device__ __forceinline__ uint32_t bcast0(uint32_t v) { return __shfl(v, 0, kWave); }
+__device__ __forceinline__ uint32_t bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // 16 bytes at buf+off for this lane (any alignment); zeros if the window leaves [0, cap)
 __device__ __forceinline__ u32x4 load16(const uint8_t *buf, uint32_t off, uint32_t cap) {
@@ -146,6 +157,23 @@ __device__ __forceinline__ u32x4 load16(const uint8_t *buf, uint32_t off, uint32
 // what the caches are asked to keep (measured on k_stream: -3 %)
 __device__ __forceinline__ u32x4 ld_stream(const uint8_t *p) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
+}
+
+// A 16 B-per-lane load whose address is not a multiple of 4 runs at 3/4 of the bandwidth of one
+// that is (tools/membench.hip: 5.3 vs 6.9 TB/s on 1.3 GB; 4-, 8- and 16-byte alignment are all
+// equal).  Text fields start anywhere, so the streaming loads start at the dword at or before the
+// wanted byte (p & ~3) and the shift r = p & 3 is undone here: the lane's window becomes its own four
+// dwords plus the first dword of the next lane -- of the next chunk's lane 0 (`next0`, wave-uniform)
+// for lane 63.
+__device__ __forceinline__ u32x4 realign(u32x4 v, uint32_t next0, uint32_t r) {
+  // wave_shl:1 -- lane i reads lane i + 1; lane 63 has no source and keeps `old` = next0
+  const uint32_t w4 = (uint32_t)__builtin_amdgcn_update_dpp((int)next0, (int)v.x, 0x130, 0xF, 0xF, false);
+  u32x4 o;
+  o.x = __builtin_amdgcn_alignbyte(v.y, v.x, r);
+  o.y = __builtin_amdgcn_alignbyte(v.z, v.y, r);
+  o.z = __builtin_amdgcn_alignbyte(v.w, v.z, r);
+  o.w = __builtin_amdgcn_alignbyte(w4, v.w, r);
+  return o;
 }
 
 // 0x80 in every byte of x that is zero, exact (no borrow artefacts)

@@ -399,6 +399,10 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream, kWgThreads, 0) != hipSuccess || per_cu < 1)
     per_cu = 3;
+  if (const char *e = getenv("BVCF_STREAM_WGS")) {  // experiment: workgroups per CU, up to the occupancy limit
+    const int w = atoi(e);
+    if (w >= 1 && w <= per_cu) per_cu = w;
+  }
   c->stream_grid = c->n_cu * per_cu;
 
   FilterTable ft;
@@ -603,13 +607,26 @@ int bvcf_bench_device(bvcf_ctx *c, const void *const *dblocks, const size_t *nby
   }
   const uint64_t b_need = std::max<uint64_t>(std::max<uint64_t>((uint64_t)ctr.n_lines + ctr.n_alleles, ctr.n_errs),
                                              (uint64_t)ctr.n_lines + ctr.n_tasks);
-  if (ctr.n_lines > s.cap_lines || b_need > s.cap_alleles ||
+  if ((ctr.n_lines > s.cap_lines || b_need > s.cap_alleles ||
       (c->p.want_class_maps && c->n_samples &&
-       (c->fused ? (uint64_t)ctr.cmap_maps : (uint64_t)ctr.n_lines + ctr.n_tasks) * c->cmap_stride > s.cap_cmap)) {
-    c->err = "bench block exceeds reserved result capacity";
+       (c->fused ? (uint64_t)ctr.cmap_maps : (uint64_t)ctr.n_lines + ctr.n_tasks) * c->cmap_stride > s.cap_cmap))) {
+    c->err = "bench block exceeds reserved result capacity: lines " + std::to_string(ctr.n_lines) + " records " +
+             std::to_string(b_need) + " maps " + std::to_string(ctr.cmap_maps);
     return BVCF_E_CAPACITY;
   }
   return BVCF_OK;
 }
 
 }  // extern "C"
+
+#ifdef BVCF_EXP_TIMES
+extern "C" int bvcf_debug_phase_times(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bvcf_dev::g_phase_t), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int bvcf_debug_wave_hw(unsigned int *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bvcf_dev::g_wave_hw), sizeof(unsigned int) * n, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int bvcf_debug_wave_times(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bvcf_dev::g_wave_t), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -133,11 +133,12 @@ constexpr uint32_t kStageChunks = 64;                 // class-map bytes staged 
 constexpr uint32_t kStageBytes = kStageChunks * 64u;  // 64 chunks x 64 B = 4 KiB = 16 384 samples
 
 // all-reference chunks never touch the stage: it is zeroed once per window instead
-__device__ __forceinline__ void zero_stage(uint8_t *stage) {
+// (only the part the next `n_chunks` chunks can touch: 1 KiB of stage per 16 chunks)
+__device__ __forceinline__ void zero_stage(uint8_t *stage, uint32_t n_chunks = kStageChunks) {
   const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (uint32_t i = 0; i < kStageBytes / (16u * kWave); i++)
-    *reinterpret_cast<u32x4 *>(stage + 16u * (lane_id() + i * kWave)) = z;
+    if (i * 16u < n_chunks) *reinterpret_cast<u32x4 *>(stage + 16u * (lane_id() + i * kWave)) = z;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
@@ -191,7 +192,7 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
   }
   if (cmap && ((c % kStageChunks) == kStageChunks - 1u || c + 1 == n_chunks)) {
     flush_stage(stage, cmap, c - (c % kStageChunks), ((c % kStageChunks) + 1u) * 64u, stride);
-    if (c + 1 != n_chunks) zero_stage(stage);
+    if (c + 1 != n_chunks) zero_stage(stage, n_chunks - (c + 1u));
   }
 }
 
@@ -202,27 +203,34 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
   const int lane = lane_id();
   const uint32_t table = (allele <= 9 ? (1u << (2u * allele)) : 0u) | (3u << 28);
   const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;
-  const uint32_t last_off = a.cap - 16u;
+  // dword-aligned loads, shift undone in registers (see realign).  The last field of a full last
+  // chunk would need one dword past the chunks: such geometries (ns % 256 == 0) load unaligned.
+  const uint32_t r = (ns & 255u) ? (s_begin & 3u) : 0u;
+  const uint32_t l_begin = s_begin - r;
+  const uint32_t last_off = (a.cap - 16u) & ~3u;
   const uint8_t *base = a.buf;
   // every chunk of the region ends before the buffer does (the common case): no per-load clamp
-  const bool inside = (unsigned long long)s_begin + (unsigned long long)n_chunks * kChunk <= a.cap;
-  const uint8_t *lane_base = base + s_begin + 16u * lane;
+  const bool inside = (unsigned long long)l_begin + (unsigned long long)n_chunks * kChunk <= a.cap;
+  const uint8_t *lane_base = base + l_begin + 16u * lane;
   auto fetch = [&](uint32_t c) -> u32x4 {
     if (inside) return ld_stream(lane_base + c * kChunk);
-    const uint32_t off = min(s_begin + c * kChunk + 16u * lane, last_off);
+    const uint32_t off = min(l_begin + c * kChunk + 16u * lane, last_off);
     return ld_stream(base + off);
   };
+  // first dword of the chunk after c (held in register `nxt`), or 0 past the region
+  auto next0 = [&](uint32_t c, const u32x4 &nxt) -> uint32_t {
+    return c + 1 < n_chunks ? (uint32_t)__builtin_amdgcn_readfirstlane(nxt.x) : 0u;
+  };
   FastAcc acc = {0, 1, 0, 0, 0};
-  if (cmap) zero_stage(stage);
+  if (cmap) zero_stage(stage, n_chunks);
   u32x4 va[kFastGroup], vb[kFastGroup];
 #pragma unroll
-  for (int g = 0; g < kFastGroup; g++)
-    if ((uint32_t)g < n_chunks) va[g] = fetch(g);
+  for (int g = 0; g < kFastGroup; g++) va[g] = (uint32_t)g < n_chunks ? fetch(g) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int g = 0; g < kFastGroup; g++)
-    if ((uint32_t)(kFastGroup + g) < n_chunks) vb[g] = fetch(kFastGroup + g);
+  for (int g = 0; g < kFastGroup; g++) vb[g] = (uint32_t)(kFastGroup + g) < n_chunks ? fetch(kFastGroup + g) : u32x4{0u, 0u, 0u, 0u};
   // the separator of the first field is the line's separator; mixed lines fail the frame test
-  const uint32_t sep = (__builtin_amdgcn_readfirstlane(va[0].x) >> 8) & 0xFFu;
+  const uint32_t w0 = __builtin_amdgcn_alignbyte(__builtin_amdgcn_readfirstlane(va[0].y), __builtin_amdgcn_readfirstlane(va[0].x), r);
+  const uint32_t sep = (w0 >> 8) & 0xFFu;
   if (sep != '|' && sep != '/') return false;
   const uint32_t kref = 0x09300030u | (sep << 8);
   // the 32-bit compare below cannot be expressed with a 0 sentinel (0 is a valid xor), so "no check"
@@ -232,13 +240,17 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
   for (uint32_t c0 = 0; c0 < n_chunks; c0 += 2 * kFastGroup) {
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
-      if (c0 + g < n_chunks) fast_chunk(va[g], c0 + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
+      if (c0 + g < n_chunks)
+        fast_chunk(realign(va[g], next0(c0 + g, g + 1 < kFastGroup ? va[g + 1 < kFastGroup ? g + 1 : 0] : vb[0]), r), c0 + g,
+                   n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
       if (c0 + 2 * kFastGroup + g < n_chunks) va[g] = fetch(c0 + 2 * kFastGroup + g);
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
-      if (c0 + kFastGroup + g < n_chunks) fast_chunk(vb[g], c0 + kFastGroup + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
+      if (c0 + kFastGroup + g < n_chunks)
+        fast_chunk(realign(vb[g], next0(c0 + kFastGroup + g, g + 1 < kFastGroup ? vb[g + 1 < kFastGroup ? g + 1 : 0] : va[0]), r),
+                   c0 + kFastGroup + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
       if (c0 + 3 * kFastGroup + g < n_chunks) vb[g] = fetch(c0 + 3 * kFastGroup + g);

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scatter_eol(KernelArgs a, uint32
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const uint32_t cc = c0 + src;
-      uint32_t idx = __shfl(mine, src, kWave);
+      uint32_t idx = lane_value(mine, src);
       const uint32_t off = cc * kChunk + 16u * lane;
       u32x4 v = load16(a.buf, off, a.cap);
       uint32_t m = eq_mask16(v, a.eol_byte) & low_bits16((int)a.nbytes - (int)off);

@@ -15,19 +15,20 @@ constexpr uint32_t kDeferred = 0xFFFFFFFEu;  // StreamEntry.n_miss / GtResult.n_
 // first terminator byte at a position in [from, limit), or kNone; 4 KiB in flight per step
 __device__ inline uint32_t find_eol(const KernelArgs &a, uint32_t from, uint32_t limit) {
   const int lane = lane_id();
-  const uint32_t last_off = a.cap - 16u;
-  for (uint32_t base = from; base < limit; base += 4u * kChunk) {
+  const uint32_t last_off = (a.cap - 16u) & ~3u;
+  for (uint32_t base = from & ~3u; base < limit; base += 4u * kChunk) {  // dword-aligned loads (see realign)
     u32x4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) v[q] = ld_stream(a.buf + min(base + q * kChunk + 16u * lane, last_off));
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const uint32_t off = base + q * kChunk + 16u * lane;
-      const uint32_t m = eq_mask16(v[q], a.eol_byte) & low_bits16((int)limit - (int)off);
+      uint32_t m = eq_mask16(v[q], a.eol_byte) & low_bits16((int)limit - (int)off);
+      if (off < from) m &= ~low_bits16((int)from - (int)off);  // the up to 3 bytes before `from`
       const unsigned long long b = __ballot(m != 0);
       if (b) {
         const int src = __ffsll((long long)b) - 1;
-        return __builtin_amdgcn_readfirstlane(__shfl(off + __ffs(m) - 1, src, kWave));
+        return lane_value(off + __ffs(m) - 1, src);
       }
     }
   }
@@ -56,7 +57,7 @@ __device__ __forceinline__ uint32_t head_window(const KernelArgs &a, u32x4 v, ui
   uint32_t eol_here = kNone;
   if (be) {
     const int src = __ffsll((long long)be) - 1;
-    eol_here = __builtin_amdgcn_readfirstlane(__shfl(off + __ffs(me) - 1, src, kWave));
+    eol_here = lane_value(off + __ffs(me) - 1, src);
     mt &= low_bits16((int)eol_here - (int)off);  // TABs of this line only
   }
   uint32_t tot;
@@ -68,7 +69,7 @@ __device__ __forceinline__ uint32_t head_window(const KernelArgs &a, u32x4 v, ui
     const unsigned long long bm = __ballot(mine);
     const int src = __ffsll((long long)bm) - 1;
     const uint32_t pos = mine ? off + nth_bit(mt, target - prefix) : 0u;
-    return __builtin_amdgcn_readfirstlane(__shfl(pos, src, kWave));
+    return lane_value(pos, src);
   }
   *found_io += tot;
   *eolp = eol_here;
@@ -78,9 +79,12 @@ __device__ __forceinline__ uint32_t head_window(const KernelArgs &a, u32x4 v, ui
 // The same for a 256 B window held by lanes 0..15 (the prefetched head of the next line): a DPP row
 // scan replaces the 64-lane shuffle scan, and a terminator anywhere in the window simply declines
 // (returns kNone: such a line is shorter than 256 B and goes through the general head scan).
-__device__ __forceinline__ uint32_t head_window16(const KernelArgs &a, u32x4 v, uint32_t base) {
+__device__ __forceinline__ uint32_t head_window16(const KernelArgs &a, u32x4 v, uint32_t start) {
   const int lane = lane_id();
   const uint32_t need = 9;
+  // the window was loaded from the dword at or before `start`: blank the bytes of the previous line
+  const uint32_t base = start & ~3u;
+  if (lane == 0) v.x &= 0xFFFFFFFFu << (8u * (start & 3u));
   const uint32_t off = base + 16u * lane;
   uint32_t valid = low_bits16((int)a.nbytes - (int)off);
   if (lane >= 16) valid = 0;
@@ -101,12 +105,36 @@ __device__ __forceinline__ uint32_t head_window16(const KernelArgs &a, u32x4 v, 
   if (!bm) return kNone;
   const int src = __ffsll((long long)bm) - 1;
   const uint32_t pos = mine ? off + nth_bit(mt, need - 1 - prefix) : 0u;
-  return __builtin_amdgcn_readfirstlane(__shfl(pos, src, kWave));
+  return lane_value(pos, src);
 }
 
 constexpr int kPipeChunks = 10;  // chunk registers of the cross-line pipeline: lines of <= 2560 samples
 
+// -DBVCF_EXP_TIMES: per-wave start/end wall clock, hardware placement and time per pipeline phase
+// (s_memtime stamps), read back through bvcf_debug_* by tools/wave_times.py.  Not part of the product.
+#ifdef BVCF_EXP_TIMES
+__device__ unsigned long long g_wave_t[2][32768];
+__device__ unsigned long long g_phase_t[8][32768];
+__device__ unsigned int g_wave_hw[2][32768];
+// phase k = time from the previous stamp to STAMP(k)
+#define STAMP(k)                                                   \
+  {                                                                \
+    const unsigned long long now_ = __builtin_readcyclecounter();  \
+    ph_[k] += now_ - last_;                                        \
+    last_ = now_;                                                  \
+  }
+#else
+#define STAMP(k)
+#endif
 __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
+#ifdef BVCF_EXP_TIMES
+  if ((threadIdx.x & 63) == 0) {
+    g_wave_t[0][blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)] = wall_clock64();
+    g_wave_hw[0][blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    g_wave_hw[1][blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+  }
+  unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
   uint8_t *stage = s_stage[threadIdx.x >> 6];
   const int lane = lane_id();
@@ -126,6 +154,9 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   // A wave owns a contiguous run of tiles and walks it front to back, so only the first tile needs
   // a search for its first line start (those bytes are the previous wave's last line).  Entries
   // stay per tile: the quota argument is about bytes, not about who scans them.
+  // (Claiming smaller runs from a counter instead evens out the waves' finish times but costs more
+  // than it returns: every run start is a chain of dependent loads.  The kernel is bound by VALU
+  // issue, not by the slowest wave.)
   const uint32_t per_wave = (a.n_tiles + n_waves - 1) / n_waves;
   const uint32_t tile_lo = min(wave * per_wave, a.n_tiles), tile_hi = min(tile_lo + per_wave, a.n_tiles);
   const uint32_t r0 = tile_lo * T;
@@ -178,10 +209,14 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
     n_local++;
     if (maps && !deferred) cm_next++;
   };
-  auto chunk_at = [&](uint32_t s_begin, uint32_t c) -> u32x4 {
-    const uint32_t off = min(s_begin + c * kChunk + 16u * lane, a.cap - 16u);
-    return ld_stream(a.buf + off);
+  // chunk loads are dword-aligned and realigned in registers; geometries whose last field would
+  // need a dword past the chunks (ns % 256 == 0) load unaligned instead (see gt_scan_fast)
+  const uint32_t amask = (ns & 255u) ? 3u : 0u;
+  const uint32_t cap_off = (a.cap - 16u) & ~3u;
+  auto chunk_off = [&](uint32_t s_begin, uint32_t c) -> uint32_t {
+    return min((s_begin & ~amask) + c * kChunk + 16u * lane, cap_off);
   };
+  auto chunk_at = [&](uint32_t s_begin, uint32_t c) -> u32x4 { return ld_stream(a.buf + chunk_off(s_begin, c)); };
   auto finish_stats = [&](const FastAcc &acc, GtStats *st) {
     wave_sum3(acc.het, acc.hom, acc.miss, ns, &st->n_het, &st->n_hom, &st->n_miss);
     st->ac = st->n_het + 2u * st->n_hom;
@@ -215,11 +250,11 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
       u32x4 va[kPipeChunks];
       u32x4 hv = {0u, 0u, 0u, 0u};
       bool hv_ok = peA + 1u < r1;  // B starts inside this wave's run
-      if (hv_ok && lane < 16) hv = load16(a.buf, peA + 1u + 16u * lane, a.cap);
+      if (hv_ok && lane < 16) hv = load16(a.buf, ((peA + 1u) & ~3u) + 16u * lane, a.cap);
 #pragma unroll
-      for (int g = 0; g < kPipeChunks; g++)
-        if ((uint32_t)g < n_chunks) va[g] = chunk_at(sA, g);
+      for (int g = 0; g < kPipeChunks; g++) va[g] = (uint32_t)g < n_chunks ? chunk_at(sA, g) : u32x4{0u, 0u, 0u, 0u};
       for (;;) {
+        STAMP(0);
         // ---- B's head from the 256 B window
         uint32_t sB = 0, peB = 0;
         bool b_ok = false;
@@ -235,23 +270,31 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           }
         }
         const bool hvc_ok = b_ok && peB + 1u < r1;
-        if (hvc_ok && lane < 16) hv = load16(a.buf, peB + 1u + 16u * lane, a.cap);  // C's head, ahead of B's chunks
+        if (hvc_ok && lane < 16) hv = load16(a.buf, ((peB + 1u) & ~3u) + 16u * lane, a.cap);  // C's head, ahead of B's chunks
+        STAMP(1);
         // ---- scan A, re-issuing each register for B
         const uint32_t cmA = map_slot();
         uint8_t *cm = cmA != BVCF_NO_CMAP ? a.cmap + cmA : nullptr;
-        if (cm) zero_stage(stage);
+        if (cm) zero_stage(stage, n_chunks);
         FastAcc acc = {0, 1, 0, 0, 0};
-        const uint32_t sep = (__builtin_amdgcn_readfirstlane(va[0].x) >> 8) & 0xFFu;
+        const uint32_t rA = sA & amask;
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(__builtin_amdgcn_readfirstlane(va[0].y),
+                                                       __builtin_amdgcn_readfirstlane(va[0].x), rA);
+        const uint32_t sep = (w0 >> 8) & 0xFFu;
         if (sep != '|' && sep != '/') acc.bad = 1;
         const uint32_t kref = 0x09300030u | (sep << 8);
         const uint32_t term_xor = (a.eol_byte ^ 0x09u) << 24;
+        STAMP(2);
 #pragma unroll
         for (int g = 0; g < kPipeChunks; g++) {
           if ((uint32_t)g < n_chunks) {
-            fast_chunk(va[g], g, n_chunks, ns, kref, table1, cm, stage, a.cmap_stride, term_xor, acc);
+            const uint32_t nx = (uint32_t)g + 1u < n_chunks
+                                    ? (uint32_t)__builtin_amdgcn_readfirstlane(va[g + 1 < kPipeChunks ? g + 1 : g].x) : 0u;
+            fast_chunk(realign(va[g], nx, rA), g, n_chunks, ns, kref, table1, cm, stage, a.cmap_stride, term_xor, acc);
             if (b_ok) va[g] = chunk_at(sB, g);
           }
         }
+        STAMP(3);
         if (__any(acc.bad != 0 || !(acc.ok & 1u))) {
           // A is not regular after all: B was predicted from a wrong line end.  Leave the
           // pipeline (the loads in flight are simply dropped) and take A the slow way.
@@ -271,6 +314,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
         sA = sB;
         peA = peB;
         hv_ok = hvc_ok;
+        STAMP(4);
       }
       if (s_begin == kNone) continue;
       // fall through with (p, s_begin) of the line that failed the regular scan
@@ -315,6 +359,12 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
     n_local = 0;
   }
   if (lane == 0 && seen) atomicAdd(&a.counters->lines_seen, seen);
+#ifdef BVCF_EXP_TIMES
+  if (lane == 0) {
+    g_wave_t[1][wave] = wall_clock64();
+    for (int k = 0; k < 8; k++) g_phase_t[k][wave] = ph_[k];
+  }
+#endif
 }
 
 // tile-local entries -> input order (the exclusive scan of the tile counts is in census/group_base)
