@@ -116,11 +116,34 @@ def test_example_query_vcf(bv):
     # > 2 560 samples: lines no longer fit the streaming kernel's chunk registers (one line at a time);
     # > 16 384 samples: the class map is staged and flushed in several 4 KiB windows
     (13, 40, 3000, False, 0.001), (14, 14, 17000, False, 0.0003), (15, 10, 33000, False, 0.0),
+    # sample counts that are multiples of 256 end on a full last chunk (the dword-aligned loads fall back to
+    # unaligned ones there), one less/more does not
+    (16, 60, 512, False, 0.002), (17, 30, 2560, False, 0.001), (18, 30, 2559, False, 0.001), (19, 40, 1024, False, 0.01),
+    (20, 30, 2304, False, 0.001), (21, 30, 2305, False, 0.001),
 ])
 def test_fuzz_parity(bv, seed, n_lines, n_samples, fmt_extra, weird):
     vcf = vcfgen.gen_vcf(seed, n_lines, n_samples, fmt_extra, weird)
     both(bv, vcf, {"allow": ""})
     both(bv, vcf, {"keepId": True, "keepInfo": True, "keepPos": True, "exclude": "q10"})
+
+
+@pytest.mark.parametrize("n_samples", [300, 512, 1030])
+def test_chunk_boundary_alignment(bv, n_samples):
+    """a single non-reference genotype next to every 256-sample chunk boundary, at each of the four byte
+    alignments of the sample region (the ID column's length shifts it): the realigned window of lane 63
+    borrows its last dword from the next chunk"""
+    spots = sorted({k for b in range(256, n_samples + 1, 256) for k in (b - 4, b - 2, b - 1, b, b + 1, b + 3)
+                    if 0 <= k < n_samples} | {0, 1, n_samples - 2, n_samples - 1})
+    lines, pos = [], 1000
+    for shift in range(4):
+        for k in spots:
+            for g in ("0|1", "1|1", ".|.", "1|.", "2|1"):
+                gts = ["0|0"] * n_samples
+                gts[k] = g
+                pos += 7
+                lines.append("\t".join(["1", str(pos), "r" + "x" * shift, "A", "C,G", "50", "PASS", "AC=1", "GT"] + gts))
+    vcf = (vcfgen.header(n_samples) + "\n".join(lines) + "\n").encode()
+    both(bv, vcf)
 
 
 def test_crlf_and_lone_cr(bv):

@@ -9,6 +9,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters) {
   uint32_t a = threadIdx.x * seed + 1, b = a ^ 0x5bd1e995u, c = a + 77, d = b + 99;
   const uint32_t m = seed * 0x01010101u + threadIdx.x, n = m * 3 + 1, s1 = seed * 5, s2 = seed * 9 + 1;
+  asm volatile("s_mov_b64 s[22:23], exec" ::: "s22", "s23");
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int r = 0; r < 2048 / 4; r++) {
@@ -37,6 +38,30 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters
       if (KIND == 22) OP4("v_add_u32 %0, %4, %0\n v_add_u32 %1, %4, %1\n v_add_u32 %2, %4, %2\n v_add_u32 %3, %4, %3");
       if (KIND == 23) OP4("v_perm_b32 %0, %0, %4, %6\n v_perm_b32 %1, %1, %4, %6\n v_perm_b32 %2, %2, %4, %6\n v_perm_b32 %3, %3, %4, %6");
       if (KIND == 24) OP4("v_and_or_b32 %0, %0, 3, 7\n v_and_or_b32 %1, %1, 3, 7\n v_and_or_b32 %2, %2, 3, 7\n v_and_or_b32 %3, %3, 3, 7");
+      if (KIND == 25) OP4("v_lshrrev_b32 %0, %4, %0\n v_lshrrev_b32 %1, %4, %1\n v_lshrrev_b32 %2, %4, %2\n v_lshrrev_b32 %3, %4, %3");
+      if (KIND == 26) OP4("v_lshlrev_b32 %0, %4, %0\n v_lshlrev_b32 %1, %4, %1\n v_lshlrev_b32 %2, %4, %2\n v_lshlrev_b32 %3, %4, %3");
+      if (KIND == 27) OP4("v_and_b32 %0, %4, %0\n v_and_b32 %1, %4, %1\n v_and_b32 %2, %4, %2\n v_and_b32 %3, %4, %3");
+      if (KIND == 28) OP4("v_or_b32 %0, %4, %0\n v_or_b32 %1, %4, %1\n v_or_b32 %2, %4, %2\n v_or_b32 %3, %4, %3");
+      if (KIND == 29) OP4("v_min_u32 %0, %4, %0\n v_min_u32 %1, %4, %1\n v_min_u32 %2, %4, %2\n v_min_u32 %3, %4, %3");
+      if (KIND == 30) OP4("v_bfe_u32 %0, %0, %4, %5\n v_bfe_u32 %1, %1, %4, %5\n v_bfe_u32 %2, %2, %4, %5\n v_bfe_u32 %3, %3, %4, %5");
+      if (KIND == 31) OP4("v_alignbyte_b32 %0, %0, %4, %5\n v_alignbyte_b32 %1, %1, %4, %5\n v_alignbyte_b32 %2, %2, %4, %5\n v_alignbyte_b32 %3, %3, %4, %5");
+      if (KIND == 32) OP4("v_or3_b32 %0, %0, %4, %5\n v_or3_b32 %1, %1, %4, %5\n v_or3_b32 %2, %2, %4, %5\n v_or3_b32 %3, %3, %4, %5");
+      if (KIND == 33) OP4("v_bcnt_u32_b32 %0, %0, %4\n v_bcnt_u32_b32 %1, %1, %4\n v_bcnt_u32_b32 %2, %2, %4\n v_bcnt_u32_b32 %3, %3, %4");
+      if (KIND == 34) OP4("v_cmp_ne_u32 vcc, %4, %0\n v_cmp_ne_u32 vcc, %4, %1\n v_cmp_ne_u32 vcc, %4, %2\n v_cmp_ne_u32 vcc, %4, %3");
+      if (KIND == 35) OP4("v_lshl_or_b32 %0, %0, %4, %5\n v_lshl_or_b32 %1, %1, %4, %5\n v_lshl_or_b32 %2, %2, %4, %5\n v_lshl_or_b32 %3, %3, %4, %5");
+      if (KIND == 36) OP4("v_perm_b32 %0, %0, %4, %5\n v_perm_b32 %1, %1, %4, %5\n v_perm_b32 %2, %2, %4, %5\n v_perm_b32 %3, %3, %4, %5");
+      if (KIND == 37) OP4("v_cndmask_b32 %0, %0, %4, s[22:23]\n v_cndmask_b32 %1, %1, %4, s[22:23]\n v_cndmask_b32 %2, %2, %4, s[22:23]\n v_cndmask_b32 %3, %3, %4, s[22:23]");
+      if (KIND == 38) OP4("v_sub_u32 %0, %4, %0\n v_sub_u32 %1, %4, %1\n v_sub_u32 %2, %4, %2\n v_sub_u32 %3, %4, %3");
+      if (KIND == 39) OP4("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4");
+      if (KIND == 40) OP4("v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n v_mov_b32 %2, 0\n v_mov_b32 %3, 0");
+      if (KIND == 41) OP4("v_xor_b32 %0, 3, %0\n v_xor_b32 %1, 3, %1\n v_xor_b32 %2, 3, %2\n v_xor_b32 %3, 3, %3");
+      if (KIND == 42) OP4("v_add3_u32 %0, %0, %4, %5\n v_add3_u32 %1, %1, %4, %5\n v_add3_u32 %2, %2, %4, %5\n v_add3_u32 %3, %3, %4, %5");
+      if (KIND == 43) OP4("v_xad_u32 %0, %0, %4, %5\n v_xad_u32 %1, %1, %4, %5\n v_xad_u32 %2, %2, %4, %5\n v_xad_u32 %3, %3, %4, %5");
+      if (KIND == 44) OP4("v_lshl_add_u32 %0, %0, %4, %5\n v_lshl_add_u32 %1, %1, %4, %5\n v_lshl_add_u32 %2, %2, %4, %5\n v_lshl_add_u32 %3, %3, %4, %5");
+      if (KIND == 45) OP4("v_and_b32 %0, 0x7f7f7f7f, %0\n v_and_b32 %1, 0x7f7f7f7f, %1\n v_and_b32 %2, 0x7f7f7f7f, %2\n v_and_b32 %3, 0x7f7f7f7f, %3");
+      if (KIND == 46) OP4("v_mul_u32_u24 %0, %4, %0\n v_mul_u32_u24 %1, %4, %1\n v_mul_u32_u24 %2, %4, %2\n v_mul_u32_u24 %3, %4, %3");
+      if (KIND == 47) OP4("v_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n v_bitop3_b32 %1, %1, %4, %5 bitop3:0x80\n v_bitop3_b32 %2, %2, %4, %5 bitop3:0x80\n v_bitop3_b32 %3, %3, %4, %5 bitop3:0x80");
+      if (KIND == 48) OP4("v_bitop3_b32 %0, %0, 7, %5 bitop3:0x36\n v_bitop3_b32 %1, %1, 7, %5 bitop3:0x36\n v_bitop3_b32 %2, %2, 7, %5 bitop3:0x36\n v_bitop3_b32 %3, %3, 7, %5 bitop3:0x36");
     }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d;
@@ -45,8 +70,8 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters
 template <int KIND>
 static void run(const char *name, uint32_t *out) {
   printf("%-44s", name);
-  for (int wpc = 1; wpc <= 4; wpc *= 2) {
-    const int wgs = 256 * wpc, iters = 512;
+  for (int wpc = 1; wpc <= 4; wpc *= 4) {
+    const int wgs = 256 * wpc, iters = 256;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -67,29 +92,29 @@ int main() {
   uint32_t *out;
   hipMalloc(&out, 64 << 20);
   run<0>("v_xor_b32 v,v (VOP2)", out);
-  run<22>("v_add_u32 v,v (VOP2)", out);
-  run<18>("v_xor_b32 s,v (VOP2)", out);
-  run<13>("v_lshlrev_b32 1,v (VOP2)", out);
-  run<10>("v_min_u32 3,v (VOP2)", out);
-  run<4>("v_xor_b32 literal,v (VOP2+lit 8B)", out);
-  run<14>("v_cmp_ne_u32 vcc,0,v (VOPC)", out);
-  run<15>("v_cndmask_b32 v,v,vcc (VOP2)", out);
-  run<17>("v_readfirstlane_b32 (VOP1)", out);
-  run<1>("v_and_or_b32 v,v,m,m (VOP3 3 vgpr, 2 same)", out);
-  run<2>("v_and_or_b32 v,v,m,n (VOP3 3 vgpr)", out);
-  run<3>("v_and_or_b32 v,v,s,n (VOP3 2 vgpr 1 sgpr)", out);
-  run<24>("v_and_or_b32 v,v,3,7 (VOP3 1 vgpr 2 inline)", out);
-  run<5>("v_bfe_u32 v,v,3,30 (VOP3 inline)", out);
-  run<6>("v_alignbyte_b32 v,v,m,s (VOP3)", out);
-  run<11>("v_lshl_or_b32 v,v,2,m (VOP3 2 vgpr)", out);
-  run<19>("v_lshrrev_b32_e64 v,v,s (VOP3 1 vgpr)", out);
-  run<9>("v_bitop3_b32 v,v,m,n (VOP3 3 vgpr)", out);
-  run<12>("v_bitop3_b32 v,v,s,n (VOP3 2 vgpr)", out);
-  run<16>("v_bcnt_u32_b32 v,v,0 (VOP3)", out);
-  run<23>("v_perm_b32 v,v,m,s (VOP3)", out);
-  run<7>("v_mov_b32_dpp row_shr:1 (DPP 8B)", out);
-  run<8>("v_lshrrev_b32_sdwa (SDWA 8B)", out);
-  run<20>("s_add_u32 (SALU)", out);
-  run<21>("v_xor / s_add alternating", out);
+  run<25>("v_lshrrev_b32 v,v", out);
+  run<26>("v_lshlrev_b32 v,v", out);
+  run<27>("v_and_b32 v,v", out);
+  run<28>("v_or_b32 v,v", out);
+  run<29>("v_min_u32 v,v", out);
+  run<30>("v_bfe_u32 v,v,v", out);
+  run<31>("v_alignbyte_b32 v,v,v", out);
+  run<32>("v_or3_b32 v,v,v", out);
+  run<33>("v_bcnt_u32_b32 v,v", out);
+  run<34>("v_cmp_ne_u32 vcc,v,v", out);
+  run<35>("v_lshl_or_b32 v,v,v", out);
+  run<36>("v_perm_b32 v,v,v", out);
+  run<37>("v_cndmask_b32 v,v,s[22:23]", out);
+  run<38>("v_sub_u32 v,v", out);
+  run<39>("v_mov_b32 v,v", out);
+  run<40>("v_mov_b32 v,0", out);
+  run<41>("v_xor_b32 3,v (inline const)", out);
+  run<42>("v_add3_u32 v,v,v", out);
+  run<43>("v_xad_u32 v,v,v", out);
+  run<44>("v_lshl_add_u32 v,v,v", out);
+  run<45>("v_and_b32 literal,v", out);
+  run<46>("v_mul_u32_u24 v,v", out);
+  run<47>("v_bitop3 v,v,v (and3)", out);
+  run<48>("v_bitop3 v,7,v (inline)", out);
   return 0;
 }

@@ -1,18 +1,16 @@
-set -e
+#!/bin/bash
+# SQ / SQC counters of k_stream, one rocprofv3 --pmc pass per set (run from the repo root on the GPU box)
 R=$PWD
+SETS=${SETS:-"SQ_WAVE_CYCLES,SQ_BUSY_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_SCA,SQ_ACTIVE_INST_LDS,SQ_ACTIVE_INST_VMEM,SQ_ACTIVE_INST_MISC SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_INSTS_VMEM_RD,SQ_INSTS_VMEM_WR,SQ_INSTS_SMEM SQC_ICACHE_REQ,SQC_ICACHE_HITS,SQC_ICACHE_MISSES,SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH,SQ_IFETCH_LEVEL,SQ_LDS_BANK_CONFLICT,SQ_LDS_ADDR_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_INSTS_BRANCH SQ_VMEM_TA_ADDR_FIFO_FULL,SQ_VMEM_TA_CMD_FIFO_FULL,SQ_INST_CYCLES_VMEM_RD,SQ_CYCLES,SQ_BUSY_CU_CYCLES,GRBM_GUI_ACTIVE"}
 cd /tmp && export TMPDIR=/tmp
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" \
-           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
-           "SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_WAVES" \
-           "SQ_INSTS_BRANCH SQ_INSTS_CBRANCH_TAKEN SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM GRBM_GUI_ACTIVE"; do
+for set in $SETS; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --path 2 > $R/gpurun_out/pmc_$i.log 2>&1 || { echo "set $i failed"; tail -3 $R/gpurun_out/pmc_$i.log; }
+  rocprofv3 --pmc ${set//,/ } --output-format csv -d $R/gpurun_out/pmc_$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --path 2 > $R/gpurun_out/pmc_$i.log 2>&1 || { echo "set $i failed"; tail -3 $R/gpurun_out/pmc_$i.log; }
 done
 python3 - <<PY
 import csv, glob, collections
-for i in range(1, 6):
+for i in range(1, $i + 1):
     for f in glob.glob("$R/gpurun_out/pmc_%d/**/*counter_collection.csv" % i, recursive=True):
         acc = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
