@@ -2,6 +2,8 @@
 // Part of the gfx950 device code of libbvcf; see bvcf_device.hip.h for the kernel map.
 #pragma once
 
+#include <type_traits>
+
 #include "bvcf_common.hip.h"
 #include "bvcf_gtscan.hip.h"
 
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;  // of a regular line
   const uint32_t table1 = (1u << 2) | (3u << 28);              // ALT #1
   // cross-line pipelining needs the whole line in the chunk registers and the in-scan terminator check
-  const bool pipelined = n_chunks <= (uint32_t)kPipeChunks && a.eol_chars == 1;
+  const bool pipelined = n_chunks >= 1 && n_chunks <= (uint32_t)kPipeChunks && a.eol_chars == 1;
   uint32_t cm_next = 0, cm_end = 0;  // this wave's private block of class-map slots
   uint32_t seen = 0;                 // terminated lines this wave walked over
 
@@ -246,76 +248,105 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
       // A = the line being scanned (chunks in va), B = the next one: its head window (hv) is
       // requested before A's chunks, parsed as soon as A starts, and every chunk register is
       // re-issued for B right after A's chunk in it has been processed.
-      uint32_t pA = p, sA = s_begin, peA = (uint32_t)pred;
-      u32x4 va[kPipeChunks];
-      u32x4 hv = {0u, 0u, 0u, 0u};
-      bool hv_ok = peA + 1u < r1;  // B starts inside this wave's run
-      if (hv_ok && lane < 16) hv = load16(a.buf, ((peA + 1u) & ~3u) + 16u * lane, a.cap);
+      //
+      // Every load of the loop is issued unconditionally -- kLoads chunk loads per line, with a
+      // harmless address when there is no B -- so that hipcc's s_waitcnt insertion can count the
+      // loads in flight.  With loads behind `if (b_ok)` or `if (g < n_chunks)` its lower bound on
+      // "loads younger than the one I need" is zero and every wait becomes vmcnt(0), which also
+      // waits for the class-map and entry stores of the previous line (-10 % on k_stream).  The
+      // loop is instantiated per chunk count, which also folds the last-chunk tests of the scan.
+      auto run_pipeline = [&](auto loads_tag) {
+        constexpr int kLoads = decltype(loads_tag)::value;
+        constexpr uint32_t nc = kLoads;
+        uint32_t pA = p, sA = s_begin, peA = (uint32_t)pred;
+        u32x4 va[kPipeChunks];
+        u32x4 hv = {0u, 0u, 0u, 0u};
+        auto head_at = [&](uint32_t start) -> u32x4 {  // 256 B from the dword at or before `start`, four times over
+          return *reinterpret_cast<const u32x4_u *>(a.buf + min((start & ~3u) + 16u * (lane & 15), cap_off));
+        };
+        bool hv_ok = peA + 1u < r1;  // B starts inside this wave's run
+        hv = head_at(hv_ok ? peA + 1u : sA);
 #pragma unroll
-      for (int g = 0; g < kPipeChunks; g++) va[g] = (uint32_t)g < n_chunks ? chunk_at(sA, g) : u32x4{0u, 0u, 0u, 0u};
-      for (;;) {
-        STAMP(0);
-        // ---- B's head from the 256 B window
-        uint32_t sB = 0, peB = 0;
-        bool b_ok = false;
-        if (hv_ok) {
-          const uint32_t t9 = head_window16(a, hv, peA + 1u);
-          if (t9 != kNone) {
-            sB = t9 + 1;
-            const unsigned long long pb = (unsigned long long)sB + 4ull * ns - 1ull;
-            if (pb + 1ull <= nb) {
-              peB = (uint32_t)pb;
-              b_ok = true;
+        for (int g = 0; g < kPipeChunks; g++) va[g] = g < kLoads ? chunk_at(sA, g) : u32x4{0u, 0u, 0u, 0u};
+        for (;;) {
+          STAMP(0);
+          // ---- B's head from the 256 B window
+          uint32_t sB = 0, peB = 0;
+          bool b_ok = false;
+          if (hv_ok) {
+            const uint32_t t9 = head_window16(a, hv, peA + 1u);
+            if (t9 != kNone) {
+              sB = t9 + 1;
+              const unsigned long long pb = (unsigned long long)sB + 4ull * ns - 1ull;
+              if (pb + 1ull <= nb) {
+                peB = (uint32_t)pb;
+                b_ok = true;
+              }
             }
           }
-        }
-        const bool hvc_ok = b_ok && peB + 1u < r1;
-        if (hvc_ok && lane < 16) hv = load16(a.buf, ((peB + 1u) & ~3u) + 16u * lane, a.cap);  // C's head, ahead of B's chunks
-        STAMP(1);
-        // ---- scan A, re-issuing each register for B
-        const uint32_t cmA = map_slot();
-        uint8_t *cm = cmA != BVCF_NO_CMAP ? a.cmap + cmA : nullptr;
-        if (cm) zero_stage(stage, n_chunks);
-        FastAcc acc = {0, 1, 0, 0, 0};
-        const uint32_t rA = sA & amask;
-        const uint32_t w0 = __builtin_amdgcn_alignbyte(__builtin_amdgcn_readfirstlane(va[0].y),
-                                                       __builtin_amdgcn_readfirstlane(va[0].x), rA);
-        const uint32_t sep = (w0 >> 8) & 0xFFu;
-        if (sep != '|' && sep != '/') acc.bad = 1;
-        const uint32_t kref = 0x09300030u | (sep << 8);
-        const uint32_t term_xor = (a.eol_byte ^ 0x09u) << 24;
-        STAMP(2);
+          const bool hvc_ok = b_ok && peB + 1u < r1;
+          // C's head, ahead of B's chunks
+          hv = head_at(hvc_ok ? peB + 1u : sA);
+          STAMP(1);
+          // ---- scan A, re-issuing each register for B
+          const uint32_t cmA = map_slot();
+          uint8_t *cm = cmA != BVCF_NO_CMAP ? a.cmap + cmA : nullptr;
+          if (cm) zero_stage(stage, nc);
+          FastAcc acc = {0, 1, 0, 0, 0};
+          const uint32_t rA = sA & amask;
+          const uint32_t w0 = __builtin_amdgcn_alignbyte(__builtin_amdgcn_readfirstlane(va[0].y),
+                                                         __builtin_amdgcn_readfirstlane(va[0].x), rA);
+          const uint32_t sep = (w0 >> 8) & 0xFFu;
+          if (sep != '|' && sep != '/') acc.bad = 1;
+          const uint32_t kref = 0x09300030u | (sep << 8);
+          const uint32_t term_xor = (a.eol_byte ^ 0x09u) << 24;
+          const uint32_t s_next = b_ok ? sB : sA;  // (A again when there is no B: the loads are dropped)
+          STAMP(2);
 #pragma unroll
-        for (int g = 0; g < kPipeChunks; g++) {
-          if ((uint32_t)g < n_chunks) {
-            const uint32_t nx = (uint32_t)g + 1u < n_chunks
-                                    ? (uint32_t)__builtin_amdgcn_readfirstlane(va[g + 1 < kPipeChunks ? g + 1 : g].x) : 0u;
-            fast_chunk(realign(va[g], nx, rA), g, n_chunks, ns, kref, table1, cm, stage, a.cmap_stride, term_xor, acc);
-            if (b_ok) va[g] = chunk_at(sB, g);
+          for (int g = 0; g < kLoads; g++) {
+            if ((uint32_t)g < nc) {
+              const uint32_t nx = (uint32_t)g + 1u < nc
+                                      ? (uint32_t)__builtin_amdgcn_readfirstlane(va[g + 1 < kPipeChunks ? g + 1 : g].x) : 0u;
+              fast_chunk(realign(va[g], nx, rA), g, nc, ns, kref, table1, cm, stage, a.cmap_stride, term_xor, acc);
+            }
+            va[g] = chunk_at(s_next, g);
           }
+          STAMP(3);
+          if (__any(acc.bad != 0 || !(acc.ok & 1u))) {
+            // A is not regular after all: B was predicted from a wrong line end.  Leave the
+            // pipeline (the loads in flight are simply dropped) and take A the slow way.
+            s_begin = sA;
+            p = pA;
+            break;
+          }
+          finish_stats(acc, &st);
+          seen++;
+          commit(pA, peA, st, false, cmA);
+          p = peA + 1u;
+          if (!b_ok) {
+            s_begin = kNone;  // nothing pending: rediscover from p
+            break;
+          }
+          pA = peA + 1u;
+          sA = sB;
+          peA = peB;
+          hv_ok = hvc_ok;
+          STAMP(4);
         }
-        STAMP(3);
-        if (__any(acc.bad != 0 || !(acc.ok & 1u))) {
-          // A is not regular after all: B was predicted from a wrong line end.  Leave the
-          // pipeline (the loads in flight are simply dropped) and take A the slow way.
-          s_begin = sA;
-          p = pA;
-          break;
-        }
-        finish_stats(acc, &st);
-        seen++;
-        commit(pA, peA, st, false, cmA);
-        p = peA + 1u;
-        if (!b_ok) {
-          s_begin = kNone;  // nothing pending: rediscover from p
-          break;
-        }
-        pA = peA + 1u;
-        sA = sB;
-        peA = peB;
-        hv_ok = hvc_ok;
-        STAMP(4);
+      };
+      switch (n_chunks) {
+        case 1: run_pipeline(std::integral_constant<int, 1>{}); break;
+        case 2: run_pipeline(std::integral_constant<int, 2>{}); break;
+        case 3: run_pipeline(std::integral_constant<int, 3>{}); break;
+        case 4: run_pipeline(std::integral_constant<int, 4>{}); break;
+        case 5: run_pipeline(std::integral_constant<int, 5>{}); break;
+        case 6: run_pipeline(std::integral_constant<int, 6>{}); break;
+        case 7: run_pipeline(std::integral_constant<int, 7>{}); break;
+        case 8: run_pipeline(std::integral_constant<int, 8>{}); break;
+        case 9: run_pipeline(std::integral_constant<int, 9>{}); break;
+        default: run_pipeline(std::integral_constant<int, 10>{}); break;
       }
+      static_assert(kPipeChunks == 10, "the dispatch above covers 1..10 chunks");
       if (s_begin == kNone) continue;
       // fall through with (p, s_begin) of the line that failed the regular scan
     } else if (pred + a.eol_chars <= nb) {
