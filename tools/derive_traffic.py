@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""profiles/k_gt_hbm_traffic.json from the four FETCH_SIZE / WRITE_SIZE rocprofv3 csv files.
+usage: python tools/derive_traffic.py <dir with pmc_{fetch,write}_size_{streaming,census}.csv> > profiles/k_gt_hbm_traffic.json"""
+import csv, json, sys, collections
+
+d = sys.argv[1]
+rows = 131072
+raw = collections.defaultdict(dict)
+for ctr, tagc in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    for path, kernels in (("streaming", ("k_stream",)), ("census", ("k_gt", "k_count_eol"))):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open("%s/pmc_%s_size_%s.csv" % (d, tagc, path))):
+            for k in kernels:
+                if "bvcf_dev::%s(" % k in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                    acc[k].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            raw[k][ctr] = sum(v) / len(v)
+out = {
+    "_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with nothing but --output-format csv) on "
+                "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --path {1,2}` (c3, 131072 rows per dispatch), "
+                "tools/refresh_profiles.sh + tools/derive_traffic.py. Raw counters are KiB per dispatch, mean over dispatches. "
+                "gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly half of a 16 B/lane streaming read, "
+                "so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact.",
+    "rows_per_dispatch": rows,
+    "raw_KiB_per_dispatch": raw,
+    "c3": {},
+}
+c3 = out["c3"]
+for k, v in raw.items():
+    rd, wr = 2 * v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
+    c3[k + "_read_bytes_per_launch"] = rd
+    c3[k + "_write_bytes_per_launch"] = wr
+    c3[k + "_traffic_bytes_per_launch"] = rd + wr
+    c3[k + "_traffic_bytes_per_launch_per_row"] = (rd + wr) / rows
+c3["traffic_bytes_per_launch_per_row"] = c3["k_gt_traffic_bytes_per_launch_per_row"]
+c3["algorithmic"] = {"k_stream_read_bytes_per_row": "the whole line, ~10166 B", "k_gt_read_bytes_per_row": 10016,
+                     "write_bytes_per_row": 672}
+print(json.dumps(out, indent=1))
