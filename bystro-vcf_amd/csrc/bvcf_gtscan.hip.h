@@ -152,7 +152,8 @@ __device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *cmap,
   if (g0 >= stride) return;
   n = min(n, stride - g0);  // the slot is `stride` bytes (a multiple of 16)
   for (uint32_t i = 16u * lane_id(); i < n; i += 16u * kWave)
-    *reinterpret_cast<u32x4 *>(cmap + g0 + i) = *reinterpret_cast<const u32x4 *>(stage + i);
+    __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(stage + i),
+                                reinterpret_cast<u32x4 *>(cmap + g0 + i));  // written once, read by the host
   __builtin_amdgcn_wave_barrier();
 }
 
