@@ -105,6 +105,8 @@ def main():
     import benchgen as bg
     import bystro_vcf_amd as bv
 
+    if args.profile == "c5" and args.path == 0:
+        args.path = 1  # FORMAT is not plain GT: the host driver (choose_path) sends such files down the census path
     cfg = bg.make_cfg(args.profile, align16=int(args.align16))
     ns = cfg.n_samples
     # ---- synthetic batches, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)

@@ -281,62 +281,83 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
   }
   uint32_t ac = 0, an = 0, het = 0, hom = 0, miss = 0;
   uint32_t tabs_before = 0;    // TABs in earlier chunks
-  uint32_t prev_last_tab = 1;  // the byte before the region start behaves like a TAB (field start)
-  u32x4 v = {0u, 0u, 0u, 0u};
-  if (s_begin < cend) v = load16(a.buf, s_begin + 16u * lane, a.cap);
-  for (uint32_t base = s_begin; base < cend; base += kChunk) {
-    u32x4 nxt = {0u, 0u, 0u, 0u};
-    if (base + kChunk < cend) nxt = load16(a.buf, base + kChunk + 16u * lane, a.cap);  // in flight during this chunk
-    const uint32_t off = base + 16u * lane;
-    const uint32_t valid = low_bits16((int)cend - (int)off);
-    const uint32_t m = eq_mask16(v, '\t') & valid;
-    uint32_t tot;
-    const uint32_t pre = wave_excl_scan(__popc(m), &tot);
-    // field starts: the byte after each TAB, plus the region start
-    uint32_t carry = __shfl_up(m >> 15, 1, kWave) & 1u;
-    if (lane == 0) carry = prev_last_tab;
-    uint32_t starts = ((m << 1) | carry) & valid & 0xFFFFu;
-    // bytes 16..19 of this lane's window: the next lane's first dword (next chunk's for lane 63)
-    uint32_t d4 = __shfl_down(v.x, 1, kWave);
-    const uint32_t nx0 = __shfl(nxt.x, 0, kWave);
-    if (lane == kWave - 1) d4 = nx0;
-    while (starts) {
-      const uint32_t k = __ffs(starts) - 1;
-      starts &= starts - 1;
-      // sample index = TABs before this byte
-      const uint32_t s = tabs_before + pre + __popc(m & ((1u << k) - 1u));
-      if (s < ns) {
-        uint32_t cls = 0, altc = 0, gtc = 0;
-        bool done = false;
-        if (off + k + 4u <= cend) {  // four real bytes: c0 c1 c2 c3
+  uint32_t prev_last_tab = 0;  // did the previous chunk end in a TAB?
+  // Chunks are loaded dword-aligned (see realign: -25 % bandwidth otherwise) kGenDepth ahead, and
+  // unconditionally -- past the region the address is clamped -- so that the loads in flight can be
+  // counted (see k_stream).  The bytes before s_begin in the first chunk are masked out.
+  constexpr int kGenDepth = 4;
+  const uint32_t r0 = s_begin & 3u, lb = s_begin - r0;
+  const uint32_t cap_off = (a.cap - 16u) & ~3u;
+  const uint32_t n_chunks = cend > s_begin ? (cend - lb + kChunk - 1u) / kChunk : 0u;
+  auto fetch = [&](uint32_t c) -> u32x4 { return ld_stream(a.buf + min(lb + c * kChunk + 16u * lane, cap_off)); };
+  u32x4 vb[kGenDepth];
+#pragma unroll
+  for (int j = 0; j < kGenDepth; j++) vb[j] = fetch(j);
+  for (uint32_t c0 = 0; c0 < n_chunks; c0 += kGenDepth) {
+#pragma unroll
+    for (int j = 0; j < kGenDepth; j++) {
+      const uint32_t c = c0 + j;
+      if (c < n_chunks) {
+        const u32x4 v = vb[j];
+        const uint32_t off = lb + c * kChunk + 16u * lane;
+        uint32_t valid = low_bits16((int)cend - (int)off);
+        if (off < s_begin) valid &= ~low_bits16((int)s_begin - (int)off);  // lane 0 of the first chunk
+        const uint32_t m = eq_mask16(v, '\t') & valid;
+        uint32_t tot;
+        const uint32_t pre = wave_excl_scan(__popc(m), &tot);
+        // field starts: the byte after each TAB, plus the region start.  The previous lane's last byte comes
+        // over one wave_shr DPP move (lane 0: the previous chunk's lane 63)
+        uint32_t starts = (m << 1) | ((uint32_t)__builtin_amdgcn_update_dpp((int)prev_last_tab, (int)(m >> 15), 0x138, 0xF, 0xF, false) & 1u);
+        if (c == 0 && lane == 0) starts |= 1u << r0;
+        starts &= valid & 0xFFFFu;
+        // bytes 16..19 of this lane's window: the next lane's first dword (next chunk's for lane 63)
+        const uint32_t nx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)vb[(j + 1) % kGenDepth].x);
+        const uint32_t d4 = (uint32_t)__builtin_amdgcn_update_dpp((int)nx0, (int)v.x, 0x130, 0xF, 0xF, false);
+        while (starts) {
+          const uint32_t k = __ffs(starts) - 1;
+          starts &= starts - 1;
+          // sample index = TABs before this byte
+          const uint32_t s = tabs_before + pre + __popc(m & ((1u << k) - 1u));
+          // four real bytes c0 c1 c2 c3 of the field, from registers
+          const bool in4 = off + k + 4u <= cend;
           const uint32_t i = k >> 2;
           const uint32_t lo = i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
           const uint32_t hi = i == 0 ? v.y : (i == 1 ? v.z : (i == 2 ? v.w : d4));
           const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, k & 3u);
           const uint32_t c1 = (w >> 8) & 0xFFu, c3 = w >> 24;
           const uint32_t v0 = (w & 0xFFu) ^ '0', v2 = ((w >> 16) & 0xFFu) ^ '0';
-          const bool frame = (c1 == '|' || c1 == '/') && (c3 == ':' || c3 == '\t');
-          const bool plain = v0 < 32u && v2 < 32u && ((0x400003FFu >> v0) & (0x400003FFu >> v2) & 1u);
-          if (frame && plain) {
-            const uint32_t code = ((table >> ((v0 & 15u) * 2u)) & 3u) + ((table >> ((v2 & 15u) * 2u)) & 3u);
-            cls = code < 3u ? code : 3u;
-            gtc = cls == 3u ? 0u : 2u;
-            altc = cls == 3u ? 0u : cls;
-            done = true;
+          const bool frame = in4 && (c1 == '|' || c1 == '/') && (c3 == ':' || c3 == '\t');
+          // the reference genotype -- nearly every field of a cohort file -- only counts two called alleles;
+          // the rest of the body runs when some lane of the wave holds anything else
+          const bool ref = s < ns && frame && (v0 | v2) == 0;
+          if (ref) an += 2;
+          if (__any(s < ns && !ref)) {
+            if (s < ns && !ref) {
+              uint32_t cls = 0, altc = 0, gtc = 0;
+              bool done = false;
+              const bool plain = v0 < 32u && v2 < 32u && ((0x400003FFu >> v0) & (0x400003FFu >> v2) & 1u);
+              if (frame && plain) {
+                const uint32_t code = ((table >> ((v0 & 15u) * 2u)) & 3u) + ((table >> ((v2 & 15u) * 2u)) & 3u);
+                cls = code < 3u ? code : 3u;
+                gtc = cls == 3u ? 0u : 2u;
+                altc = cls == 3u ? 0u : cls;
+                done = true;
+              }
+              if (!done) classify_field(a.buf, off + k, cend, allele, a_nd, &cls, &altc, &gtc);
+              ac += altc;
+              an += gtc;
+              het += cls == BVCF_CLS_HET;
+              hom += cls == BVCF_CLS_HOM;
+              miss += cls == BVCF_CLS_MISSING;
+              if (cmap && cls) atomicOr(reinterpret_cast<uint32_t *>(cmap + (s >> 4) * 4u), cls << (2u * (s & 15u)));
+            }
           }
         }
-        if (!done) classify_field(a.buf, off + k, cend, allele, a_nd, &cls, &altc, &gtc);
-        ac += altc;
-        an += gtc;
-        het += cls == BVCF_CLS_HET;
-        hom += cls == BVCF_CLS_HOM;
-        miss += cls == BVCF_CLS_MISSING;
-        if (cmap && cls) atomicOr(reinterpret_cast<uint32_t *>(cmap + (s >> 4) * 4u), cls << (2u * (s & 15u)));
+        prev_last_tab = lane_value(m >> 15, kWave - 1) & 1u;
+        tabs_before += tot;
       }
+      vb[j] = fetch(c + kGenDepth);
     }
-    prev_last_tab = __shfl(m >> 15, kWave - 1, kWave) & 1u;
-    tabs_before += tot;
-    v = nxt;
   }
   // a field that starts exactly at cend (empty last field) was not visited above
   if (lane == 0) {
