@@ -27,7 +27,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DEVICE_PAD = 64
 NO_CMAP = 0xFFFFFFFF
 
@@ -49,7 +49,7 @@ class Params(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("device", C.c_int32), ("n_header_fields", C.c_uint32),
         ("eol_chars", C.c_uint32), ("eol_byte", C.c_uint8), ("want_class_maps", C.c_uint8),
-        ("reserved0", C.c_uint8 * 2), ("allow_filter", C.c_char_p), ("exclude_filter", C.c_char_p),
+        ("want_dosage", C.c_uint8), ("reserved0", C.c_uint8 * 1), ("allow_filter", C.c_char_p), ("exclude_filter", C.c_char_p),
         ("max_batch_bytes", C.c_uint64), ("max_lines", C.c_uint32), ("max_alleles", C.c_uint32),
         ("cmap_bytes", C.c_uint64), ("n_slots", C.c_uint32), ("path", C.c_uint32),
     ]
@@ -72,7 +72,7 @@ class Result(C.Structure):
         ("n_samples", C.c_uint32), ("lines", C.c_void_p), ("alleles", C.c_void_p), ("errs", C.c_void_p),
         ("cmap", C.c_void_p), ("need_lines", C.c_uint64), ("need_alleles", C.c_uint64),
         ("need_cmap_bytes", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32),
-        ("n_lines_seen", C.c_uint64),
+        ("n_lines_seen", C.c_uint64), ("dosage", C.c_void_p), ("dosage_stride", C.c_uint32), ("reserved2", C.c_uint32),
     ]
 
 
@@ -204,6 +204,10 @@ class Batch:
         self.alleles = arr(r.alleles, r.n_alleles, ALLELE_DTYPE)
         self.errs = arr(r.errs, r.n_errs, ERR_DTYPE)
         self.cmap = arr(r.cmap, r.n_cmap_bytes, np.dtype("u1"))
+        # want_dosage: one int8 row per alleles[] slot (rows of slots without a record hold garbage)
+        self.dosage = None
+        if r.dosage and r.n_alleles:
+            self.dosage = arr(r.dosage, r.n_alleles * r.dosage_stride, np.dtype("i1")).reshape(r.n_alleles, r.dosage_stride)
 
     def records(self, i):
         """the output alleles of line i, in order"""
@@ -213,6 +217,12 @@ class Batch:
             return self.alleles[:0]
         idx = [i] + [int(L["rec_first"]) + j - 1 for j in range(1, n)]
         return self.alleles[idx]
+
+    def record_slots(self, i):
+        """indices into alleles[] (and dosage[]) of line i's output alleles, in order"""
+        L = self.lines[i]
+        n = int(L["n_rec"])
+        return [] if n == 0 else [i] + [int(L["rec_first"]) + j - 1 for j in range(1, n)]
 
     def classes(self, allele_row):
         """per-sample class codes (0 none, 1 het, 2 hom, 3 missing) of one allele record"""
@@ -227,7 +237,7 @@ class Ctx:
 
     def __init__(self, n_header_fields, allow="PASS,.", exclude="", device=0, eol_chars=1, eol_byte=b"\n",
                  max_batch_bytes=0, max_lines=0, max_alleles=0, cmap_bytes=0, n_slots=0, want_class_maps=True,
-                 path=0):
+                 path=0, want_dosage=False):
         p = Params()
         p.abi_version = ABI_VERSION
         p.device = device
@@ -235,6 +245,7 @@ class Ctx:
         p.eol_chars = eol_chars
         p.eol_byte = eol_byte[0]
         p.want_class_maps = int(want_class_maps)
+        p.want_dosage = int(want_dosage)
         self._keep = [allow.encode(), exclude.encode()]
         p.allow_filter, p.exclude_filter = self._keep
         p.max_batch_bytes = max_batch_bytes

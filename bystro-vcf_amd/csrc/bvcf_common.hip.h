@@ -72,6 +72,8 @@ struct KernelArgs {
   uint32_t eol_chars;
   uint32_t eol_byte;
   uint32_t want_cmap;
+  int8_t *dosage;          // want_dosage: one row of dosage_stride bytes per alleles[] slot, or null
+  uint32_t dosage_stride;
   uint32_t cmap_stride;
   uint32_t max_lines, max_alleles, max_errs, max_tasks;
   unsigned long long max_cmap;

@@ -27,6 +27,7 @@ struct Slot {
   bvcf_allele *d_alleles = nullptr;
   bvcf_err *d_errs = nullptr;
   uint8_t *d_cmap = nullptr;
+  int8_t *d_dosage = nullptr;
   GtTask *d_tasks = nullptr;
   GtResult *d_results = nullptr;
   StreamEntry *d_entries = nullptr;
@@ -38,6 +39,7 @@ struct Slot {
   bvcf_allele *h_alleles = nullptr;
   bvcf_err *h_errs = nullptr;
   uint8_t *h_cmap = nullptr;
+  int8_t *h_dosage = nullptr;
   // capacities this slot was allocated with
   uint64_t cap_lines = 0, cap_alleles = 0, cap_cmap = 0, cap_census = 0;
   // in-flight batch
@@ -57,6 +59,7 @@ struct bvcf_ctx {
   uint32_t tile_bytes = 0, tile_quota = 0;
   uint32_t n_samples = 0;
   uint32_t cmap_stride = 0;
+  uint32_t dosage_stride = 0;  // 0 unless want_dosage
   uint64_t max_lines = 0, max_alleles = 0, max_cmap = 0;
   FilterTable *d_filters = nullptr;
   std::vector<Slot> slots;
@@ -115,6 +118,7 @@ void free_slot(Slot &s) {
   hipFree(s.d_alleles);
   hipFree(s.d_errs);
   hipFree(s.d_cmap);
+  hipFree(s.d_dosage);
   hipFree(s.d_tasks);
   hipFree(s.d_results);
   hipFree(s.d_entries);
@@ -126,6 +130,7 @@ void free_slot(Slot &s) {
   hipHostFree(s.h_alleles);
   hipHostFree(s.h_errs);
   hipHostFree(s.h_cmap);
+  hipHostFree(s.h_dosage);
   if (s.ev_k0) hipEventDestroy(s.ev_k0);
   if (s.ev_k1) hipEventDestroy(s.ev_k1);
   if (s.ev_ctr) hipEventDestroy(s.ev_ctr);
@@ -141,6 +146,7 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   hipFree(s.d_alleles);
   hipFree(s.d_errs);
   hipFree(s.d_cmap);
+  hipFree(s.d_dosage);
   hipFree(s.d_tasks);
   hipFree(s.d_results);
   hipFree(s.d_line_len);
@@ -149,6 +155,9 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   hipHostFree(s.h_alleles);
   hipHostFree(s.h_errs);
   hipHostFree(s.h_cmap);
+  hipHostFree(s.h_dosage);
+  s.d_dosage = nullptr;
+  s.h_dosage = nullptr;
   s.d_line_off = nullptr;
   s.d_lines = nullptr;
   s.d_alleles = nullptr;
@@ -176,6 +185,10 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   HIP_TRY(c, hipHostMalloc(&s.h_alleles, c->max_alleles * sizeof(bvcf_allele), hipHostMallocDefault));
   HIP_TRY(c, hipHostMalloc(&s.h_errs, c->max_alleles * sizeof(bvcf_err), hipHostMallocDefault));
   HIP_TRY(c, hipHostMalloc(&s.h_cmap, c->max_cmap + 64, hipHostMallocDefault));
+  if (c->dosage_stride) {
+    HIP_TRY(c, hipMalloc(&s.d_dosage, c->max_alleles * c->dosage_stride + 64));
+    HIP_TRY(c, hipHostMalloc(&s.h_dosage, c->max_alleles * c->dosage_stride + 64, hipHostMallocDefault));
+  }
   s.cap_lines = c->max_lines;
   s.cap_alleles = c->max_alleles;
   s.cap_cmap = c->max_cmap;
@@ -225,6 +238,8 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.alleles = s.d_alleles;
   a.errs = s.d_errs;
   a.cmap = s.d_cmap;
+  a.dosage = s.d_dosage;
+  a.dosage_stride = c->dosage_stride;
   a.tasks = s.d_tasks;
   a.results = s.d_results;
   a.counters = s.d_counters;
@@ -253,6 +268,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     hipLaunchKernelGGL(k_head, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
     hipLaunchKernelGGL(k_gt, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
+    if (a.dosage) hipLaunchKernelGGL(k_dosage, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     return;
   }
   const uint32_t n_chunks = (a.nbytes + kChunk - 1) / kChunk;
@@ -269,6 +285,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     hipLaunchKernelGGL(k_gt, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     if (ev_gt1) hipEventRecord(ev_gt1, st);
     hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
+    if (a.dosage) hipLaunchKernelGGL(k_dosage, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
   } else {
     if (ev_gt0) hipEventRecord(ev_gt0, st);
     if (ev_gt1) hipEventRecord(ev_gt1, st);
@@ -358,6 +375,7 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   if (!c->p.eol_byte) c->p.eol_byte = '\n';
   c->n_samples = p->n_header_fields > 9 ? p->n_header_fields - 9 : 0;
   c->cmap_stride = ((c->n_samples + 3) / 4 + 15) & ~15u;
+  c->dosage_stride = p->want_dosage && c->n_samples ? ((c->n_samples + 15) & ~15u) : 0u;
   const uint64_t min_line = std::max<uint64_t>(48, 2ull * p->n_header_fields);
   c->max_lines = p->max_lines ? p->max_lines : c->p.max_batch_bytes / min_line + 4096;
   c->max_alleles = p->max_alleles ? p->max_alleles : 2 * c->max_lines + 1024;
@@ -512,6 +530,8 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     HIP_TRY(c, hipMemcpyAsync(s.h_errs, s.d_errs, ctr.n_errs * sizeof(bvcf_err), hipMemcpyDeviceToHost, s.stream));
   if (cmap_bytes)
     HIP_TRY(c, hipMemcpyAsync(s.h_cmap, s.d_cmap, cmap_bytes, hipMemcpyDeviceToHost, s.stream));
+  if (c->dosage_stride && n_alleles)
+    HIP_TRY(c, hipMemcpyAsync(s.h_dosage, s.d_dosage, n_alleles * c->dosage_stride, hipMemcpyDeviceToHost, s.stream));
   e = hipStreamSynchronize(s.stream);
   if (e != hipSuccess) {
     c->err = std::string("result copy failed: ") + hipGetErrorString(e);
@@ -535,6 +555,8 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   r->alleles = s.h_alleles;
   r->errs = s.h_errs;
   r->cmap = s.h_cmap;
+  r->dosage = c->dosage_stride ? s.h_dosage : nullptr;
+  r->dosage_stride = c->dosage_stride;
 
   uint64_t ok = 0, ac0 = 0, recs = 0;
   for (uint32_t i = 0; i < ctr.n_lines; i++) {

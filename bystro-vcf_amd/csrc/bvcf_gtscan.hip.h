@@ -268,8 +268,10 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
 // main.go:1063-1124, at any stride — is classified from registers (the lane's 16 bytes and the next
 // lane's first dword); everything else goes through the byte-serial restatement (classify_field).
 // *n_tabs receives the number of TABs in [s_begin, cend).
+// dos (optional): the sample's dosage -- altCount, 127 at most, -1 when missing (main.go:1117-1178) -- goes to dos[s]
 __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, uint32_t cend, uint32_t ns,
-                                       uint32_t allele, uint8_t *cmap, GtStats *st, uint32_t *n_tabs) {
+                                       uint32_t allele, uint8_t *cmap, GtStats *st, uint32_t *n_tabs,
+                                       int8_t *dos = nullptr) {
   const int lane = lane_id();
   uint32_t a_nd = 1;
   for (uint32_t t = allele; t >= 10; t /= 10) a_nd++;
@@ -330,7 +332,10 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
           // the reference genotype -- nearly every field of a cohort file -- only counts two called alleles;
           // the rest of the body runs when some lane of the wave holds anything else
           const bool ref = s < ns && frame && (v0 | v2) == 0;
-          if (ref) an += 2;
+          if (ref) {
+            an += 2;
+            if (dos) dos[s] = 0;
+          }
           if (__any(s < ns && !ref)) {
             if (s < ns && !ref) {
               uint32_t cls = 0, altc = 0, gtc = 0;
@@ -349,6 +354,7 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
               het += cls == BVCF_CLS_HET;
               hom += cls == BVCF_CLS_HOM;
               miss += cls == BVCF_CLS_MISSING;
+              if (dos) dos[s] = cls == BVCF_CLS_MISSING ? (int8_t)-1 : (int8_t)(altc < 127u ? altc : 127u);
               if (cmap && cls) atomicOr(reinterpret_cast<uint32_t *>(cmap + (s >> 4) * 4u), cls << (2u * (s & 15u)));
             }
           }
@@ -362,7 +368,10 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
   // a field that starts exactly at cend (empty last field) was not visited above
   if (lane == 0) {
     const bool empty_last = (cend == s_begin) || (cend > s_begin && a.buf[cend - 1] == '\t');
-    if (empty_last && tabs_before < ns) an += 1;  // "" is one non-matching allele token
+    if (empty_last && tabs_before < ns) {
+      an += 1;  // "" is one non-matching allele token
+      if (dos) dos[tabs_before] = 0;
+    }
   }
   st->ac = wave_sum(ac);
   st->an = wave_sum(an);
@@ -415,6 +424,27 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
     }
   }
 }
-
+// ------------------------------------------------------------------ k_dosage: one wave per output allele
+// --dosageOutput (main.go:306-342,576-584): the int8 row of every alleles[] slot that holds a record.  Runs after
+// k_finish, only when the ctx asks for it; every field goes through the general scan, which knows the allele
+// count of any ploidy (the 2-bit class of the label path cannot tell "1" from "1|1").
+__global__ __launch_bounds__(kWgThreads) void k_dosage(KernelArgs a) {
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t n_alleles = min(n_lines + a.counters->n_alleles, a.max_alleles);
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  for (uint32_t k = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); k < n_alleles; k += stride) {
+    const bvcf_allele r = a.alleles[k];
+    const uint32_t li = k < n_lines ? k : r.line;
+    if (li >= n_lines) continue;
+    const bvcf_line L = a.lines[li];
+    if (L.status != BVCF_LINE_OK || L.n_rec == 0) continue;
+    // slot k belongs to line li if it is the line's own slot or one of its further alleles
+    if (k >= n_lines && (k < L.rec_first || k - L.rec_first + 1u >= L.n_rec)) continue;
+    GtStats st;
+    uint32_t tabs;
+    gt_scan_general(a, L.off + L.fend[8] + 1u, L.off + L.len, a.n_samples, r.alt_idx + 1u, nullptr, &st, &tabs,
+                    a.dosage + (size_t)k * a.dosage_stride);
+  }
+}
 
 }  // namespace bvcf_dev

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BVCF_ABI_VERSION 1
+#define BVCF_ABI_VERSION 2
 
 typedef enum {
   BVCF_OK = 0,
@@ -94,7 +94,8 @@ typedef struct {
   uint32_t eol_chars;         /* numChars: 1 for "\n", 2 for "\r\n" (main.go:250,535) */
   uint8_t eol_byte;           /* endOfLineByte, '\n' unless the file uses lone '\r' */
   uint8_t want_class_maps;    /* needsLabels: emit the 2-bit class maps (main.go:502) */
-  uint8_t reserved0[2];
+  uint8_t want_dosage;        /* needsDosages: emit one int8 per sample per output allele (main.go:503,1069-1178) */
+  uint8_t reserved0[1];
   const char *allow_filter;   /* --allowFilter text; NULL, "" or "*" = allow all (main.go:98,108-114) */
   const char *exclude_filter; /* --excludeFilter text; NULL or "" = none (main.go:99,117-123) */
   uint64_t max_batch_bytes;   /* largest block bvcf_submit accepts (0 = 64 MiB) */
@@ -179,6 +180,12 @@ typedef struct {
   uint32_t reserved;
   uint64_t n_lines_seen;     /* terminated lines in the block (>= n_lines: the streaming path does not list
                                 lines that fail len(record) == len(header), main.go:449) */
+  /* bvcf_params.want_dosage: the row of alleles[k] is dosage[k * dosage_stride .. + n_samples):
+   * the number of GT alleles equal to the ALT index, 127 at most, -1 if any allele is '.'
+   * (main.go:1069-1178).  Rows of slots without a record are not written.  NULL otherwise. */
+  const int8_t *dosage;
+  uint32_t dosage_stride;    /* n_samples rounded up to 16 */
+  uint32_t reserved2;
 } bvcf_result;
 
 /* ---- lifecycle ---- */

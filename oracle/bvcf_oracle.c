@@ -578,6 +578,7 @@ typedef struct {
   size_t *header_len;
   int n_header;
   int num_chars;
+  orc_buf *dosage; /* optional: one "locus<TAB>d0,d1,...\n" text row per output row (main.go:576-584) */
 } run_ctx;
 
 /* join the names of samples whose class == want, main.go:617,639,653 */
@@ -629,8 +630,30 @@ static void process_line(const run_ctx *rc, const char *row, size_t nrow, field_
     if (ns > 0) { /* main.go:555-564 */
       char strAlt[16];
       snprintf(strAlt, sizeof strAlt, "%d", al.alt_indices[i] + 1);
-      orc_make_het_hom(fv->ptr, fv->len, rc->n_header, strAlt, cls, NULL, &ac, &an);
-      if (ac == 0) continue;
+      int8_t *dos = rc->dosage ? (int8_t *)malloc((size_t)ns) : NULL;
+      orc_make_het_hom(fv->ptr, fv->len, rc->n_header, strAlt, cls, dos, &ac, &an);
+      if (ac == 0) {
+        free(dos);
+        continue;
+      }
+      if (dos) { /* the Arrow row, main.go:576-584: "chrom:pos:ref:alt" then one int8 per sample */
+        orc_buf *d = rc->dosage;
+        if (fv->len[0] < 4 || fv->ptr[0][0] != 'c') buf_puts(d, "chr");
+        buf_write(d, fv->ptr[0], fv->len[0]);
+        buf_putc(d, ':');
+        buf_puts(d, al.positions[i]);
+        buf_putc(d, ':');
+        buf_putc(d, al.refs[i]);
+        buf_putc(d, ':');
+        buf_puts(d, al.alts[i]);
+        buf_putc(d, '\t');
+        for (int k = 0; k < ns; k++) {
+          if (k) buf_putc(d, ',');
+          buf_itoa(d, dos[k]);
+        }
+        buf_putc(d, '\n');
+        free(dos);
+      }
       n_het = count_cls(cls, ns, ORC_CLS_HET);
       n_hom = count_cls(cls, ns, ORC_CLS_HOM);
       n_miss = count_cls(cls, ns, ORC_CLS_MISSING);
@@ -761,8 +784,8 @@ static int fatal(orc_buf *err, const char *msg) {
 }
 
 /* main.go:241-396 */
-int orc_read_vcf(const orc_config *cfg, const char *in, size_t n_in, orc_buf *out, orc_buf *err,
-                 uint64_t *n_rows_in) {
+static int read_vcf_impl(const orc_config *cfg, const char *in, size_t n_in, orc_buf *out, orc_buf *err,
+                         uint64_t *n_rows_in, orc_buf *dosage) {
   if (n_rows_in) *n_rows_in = 0;
   /* parse.FindEndOfLine(reader, ""): consume the first line, learn the terminator */
   size_t i = 0;
@@ -812,6 +835,7 @@ int orc_read_vcf(const orc_config *cfg, const char *in, size_t n_in, orc_buf *ou
   memset(&rc, 0, sizeof rc);
   rc.cfg = cfg;
   rc.num_chars = num_chars;
+  rc.dosage = dosage;
   filter_set_parse(&rc.allowed, cfg->allow_filter, 1);
   filter_set_parse(&rc.excluded, cfg->exclude_filter, 0);
 
@@ -868,7 +892,7 @@ int orc_read_vcf(const orc_config *cfg, const char *in, size_t n_in, orc_buf *ou
     pl.batch_log = (orc_buf *)calloc(pl.n_batches ? pl.n_batches : 1, sizeof(orc_buf));
     pthread_mutex_init(&pl.mu, NULL);
 
-    int nt = cfg->n_threads > 1 ? cfg->n_threads : 1;
+    int nt = cfg->n_threads > 1 && !dosage ? cfg->n_threads : 1; /* one dosage sink: serial */
     if (nt == 1) {
       worker(&pl);
     } else {
@@ -948,6 +972,27 @@ int orc_make_het_hom_flat(const char *line, size_t n, int n_header, const char *
   }
   free((void *)fv.ptr);
   free(fv.len);
+  return rv;
+}
+
+int orc_read_vcf(const orc_config *cfg, const char *in, size_t n_in, orc_buf *out, orc_buf *err,
+                 uint64_t *n_rows_in) {
+  return read_vcf_impl(cfg, in, n_in, out, err, n_rows_in, NULL);
+}
+
+/* the rows of --dosageOutput as text (test infrastructure for the Arrow writer's parity test) */
+int orc_run_dosage(const orc_config *cfg, const char *in, size_t n_in, char **dos, size_t *n_dos) {
+  orc_buf o, e, d;
+  orc_buf_init(&o);
+  orc_buf_init(&e);
+  orc_buf_init(&d);
+  int rv = read_vcf_impl(cfg, in, n_in, &o, &e, NULL, &d);
+  orc_buf_free(&o);
+  orc_buf_free(&e);
+  buf_reserve(&d, 0);
+  d.data[d.len] = 0;
+  *dos = d.data;
+  *n_dos = d.len;
   return rv;
 }
 

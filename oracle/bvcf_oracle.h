@@ -117,6 +117,10 @@ int orc_run(const orc_config *cfg, const char *in, size_t n_in, char **out, size
             char **err, size_t *n_err, uint64_t *n_rows_in);
 void orc_free(void *p);
 
+/* the rows the reference would hand to its Arrow writer (--dosageOutput, main.go:576-584), as text:
+ * "chrom:pos:ref:alt<TAB>d0,d1,...\n" per output row, in input order; malloc'd, free with orc_free */
+int orc_run_dosage(const orc_config *cfg, const char *in, size_t n_in, char **dos, size_t *n_dos);
+
 #ifdef __cplusplus
 }
 #endif

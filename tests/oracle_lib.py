@@ -109,3 +109,22 @@ def run(vcf_bytes, cfg=None, n_threads=1):
     lib().orc_free(out)
     lib().orc_free(err)
     return rc, o, e, n_rows.value
+
+
+def run_dosage(vcf_bytes, cfg=None):
+    """the rows of --dosageOutput (main.go:576-584) -> list of (locus, [int8 per sample]) in input order"""
+    L = lib()
+    L.orc_run_dosage.argtypes = [C.POINTER(OrcConfig), C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p),
+                                 C.POINTER(C.c_size_t)]
+    L.orc_run_dosage.restype = C.c_int
+    c = make_config(cfg, 1)
+    out, n_out = C.c_void_p(), C.c_size_t()
+    rc = L.orc_run_dosage(C.byref(c), vcf_bytes, len(vcf_bytes), C.byref(out), C.byref(n_out))
+    text = C.string_at(out, n_out.value).decode()
+    L.orc_free(out)
+    assert rc == 0
+    rows = []
+    for ln in text.splitlines():
+        locus, _, d = ln.partition("\t")
+        rows.append((locus, [int(x) for x in d.split(",")] if d else []))
+    return rows

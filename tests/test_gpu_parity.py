@@ -209,6 +209,52 @@ def test_device_resident_submit_matches_host_submit(bv):
             assert (ra[f] == rb[f]).all()
 
 
+def _device_dosage_rows(bv, vcf, allow=""):
+    """the int8 rows bvcf_collect returns for the output alleles of `vcf`, in input order"""
+    hdr_at = vcf.index(b"#CHROM")
+    hdr_end = vcf.index(b"\n", hdr_at)
+    n_header = vcf[hdr_at:hdr_end].count(b"\t") + 1
+    body = vcf[hdr_end + 1:]
+    ctx = bv.Ctx(n_header, allow=allow, want_dosage=True)
+    b = ctx.process(body)
+    ctx.close()
+    ns = n_header - 9
+    rows = []
+    for i in range(len(b.lines)):
+        if b.lines[i]["status"] != 0:
+            continue
+        for k in b.record_slots(i):
+            if b.alleles[k]["ac"] == 0:
+                continue  # main.go:558-560
+            rows.append([int(x) for x in b.dosage[k][:ns]])
+    return rows
+
+
+@pytest.mark.parametrize("seed,n_lines,n_samples,fmt_extra,weird", [
+    (31, 200, 3, False, 0.1), (32, 150, 70, False, 0.05), (33, 100, 300, True, 0.03), (34, 40, 2504, False, 0.002),
+    (35, 60, 257, True, 0.2), (36, 100, 1, False, 0.3),
+])
+def test_dosage_rows_match_oracle(bv, seed, n_lines, n_samples, fmt_extra, weird):
+    """bvcf_params.want_dosage: altCount per sample, -1 when missing (main.go:1069-1178), any ploidy"""
+    vcf = vcfgen.gen_vcf(seed, n_lines, n_samples, fmt_extra, weird)
+    want = [d for _, d in orc.run_dosage(vcf, {"allow": ""})]
+    got = _device_dosage_rows(bv, vcf)
+    assert len(got) == len(want)
+    for r, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "row %d: first difference at sample %d" % (r, next(i for i in range(len(w)) if g[i] != w[i]))
+
+
+def test_dosage_reference_known_answer(bv):
+    """TestGenotypeMatrix, main_test.go:2911-2977"""
+    hdr = "##fileformat=VCFv4.x\n" + "\t".join(H8 + ["FORMAT", "S1", "S2", "S3"]) + "\n"
+    rows = [["1", "1000", "rs1", "A", "T", ".", "PASS", "DP=100", "GT", "1|1", "0|1", "0|0"],
+            ["2", "200", "rs2", "C", "G", ".", "PASS", "DP=100", "GT", "0|1", "0|0", "1|1"],
+            ["22", "300", "rs2", "G", "T", ".", "PASS", "DP=100", "GT", "0|.", "0|.", "1|1"]]
+    vcf = (hdr + "".join("\t".join(r) + "\n" for r in rows)).encode()
+    assert _device_dosage_rows(bv, vcf, allow="PASS,.") == [[2, 1, 0], [1, 0, 2], [-1, -1, 2]]
+    assert orc.run_dosage(vcf) == [("chr1:1000:A:T", [2, 1, 0]), ("chr2:200:C:G", [1, 0, 2]), ("chr22:300:G:T", [-1, -1, 2])]
+
+
 def _run_cli(args, data):
     import subprocess
     exe = os.path.join(ROOT, "bystro-vcf_amd", "bystro-vcf")
