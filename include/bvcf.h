@@ -42,7 +42,8 @@ typedef enum {
   BVCF_E_CAPACITY = -7,   /* batch needs more lines/alleles/class-map bytes than reserved;
                              bvcf_result.need_* say how many; grow with bvcf_reserve or split */
   BVCF_E_NOMEM = -8,
-  BVCF_E_FATAL = -9       /* the reference's log.Fatal paths (bvcf_run_*) */
+  BVCF_E_FATAL = -9,      /* the reference's log.Fatal paths (bvcf_run_*) */
+  BVCF_E_IO = -10         /* file could not be opened / written */
 } bvcf_status;
 
 /* line verdicts, cf. main.go:537-545 */
@@ -269,6 +270,18 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
 int bvcf_decompress_fd(int fd_in, int fd_out, uint32_t n_threads, char *kind_out /* >= 8 bytes or NULL */);
 
 void bvcf_free(void *p);
+
+/* ---- the dosage matrix file (--dosageOutput) ----
+ * Replaces arrow/arrow.go's ArrowWriter + ArrowRowBuilder (NewArrowIPCFileWriter / WriteRow / Close,
+ * called from main.go:334, 576-584, 698-716) for the table main.go:319-329 declares: a utf8 column
+ * "locus" ("chrom:pos:ref:alt") and one int8 column per sample.  Writes an Arrow IPC file with record
+ * batches of rows_per_batch rows (0 = 5 000, main.go:518) whose buffers are zstd-compressed
+ * (zstd_level 0 = 3, < 0 = uncompressed).  Host-only. */
+typedef struct bvcf_arrow bvcf_arrow;
+int bvcf_arrow_open(bvcf_arrow **out, const char *path, const char *const *sample_names,
+                    const uint32_t *sample_name_lens, uint32_t n_samples, uint32_t rows_per_batch, int zstd_level);
+int bvcf_arrow_append(bvcf_arrow *w, const char *locus, uint32_t locus_len, const int8_t *dosage /* n_samples */);
+int bvcf_arrow_close(bvcf_arrow *w); /* flushes the last batch, writes the footer, frees w */
 
 #ifdef __cplusplus
 }
