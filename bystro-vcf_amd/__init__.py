@@ -63,6 +63,7 @@ class Config(C.Structure):
         ("keep_pos", C.c_uint8), ("keep_qual", C.c_uint8), ("normalize_header", C.c_uint8),
         ("reserved", C.c_uint8 * 3), ("device", C.c_int32), ("n_format_threads", C.c_uint32),
         ("max_batch_bytes", C.c_uint64), ("sample_list_path", C.c_char_p),
+        ("dosage_path", C.c_char_p), ("no_out", C.c_uint8), ("reserved3", C.c_uint8 * 7),
     ]
 
 
@@ -147,6 +148,10 @@ def make_config(cfg=None, device=0, max_batch_bytes=0, n_format_threads=0):
     if cfg.get("sample"):
         keep.append(cfg["sample"].encode())
         c.sample_list_path = keep[-1]
+    if cfg.get("dosageOutput"):
+        keep.append(str(cfg["dosageOutput"]).encode())
+        c.dosage_path = keep[-1]
+    c.no_out = int(cfg.get("noOut", False))
     c._keep = keep
     return c
 

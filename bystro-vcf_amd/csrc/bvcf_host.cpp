@@ -311,6 +311,8 @@ struct Run {
   std::vector<uint32_t> name_len;
   unsigned n_threads = 1;
   uint64_t max_batch = 0;
+  bvcf_arrow *arrow = nullptr;  // --dosageOutput
+  bool want_rows = true;        // !noOut
 };
 
 // Which device path suits this file: the streaming path shines when sample fields are the bare
@@ -373,7 +375,9 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_d
   p.n_header_fields = (uint32_t)R.pre.header.size();
   p.eol_chars = R.pre.eol_chars;
   p.eol_byte = R.pre.eol_byte;
-  p.want_class_maps = 1;
+  R.want_rows = !R.cfg->no_out;
+  p.want_class_maps = R.want_rows;  // needsLabels, main.go:502
+  p.want_dosage = R.cfg->dosage_path && *R.cfg->dosage_path && R.pre.header.size() > 9;
   p.allow_filter = R.cfg->allow_filter;
   p.exclude_filter = R.cfg->exclude_filter;
   p.max_batch_bytes = R.max_batch;
@@ -390,7 +394,68 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_d
   }
   R.n_threads = R.cfg->n_format_threads ? R.cfg->n_format_threads
                                          : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  if (R.cfg->dosage_path && *R.cfg->dosage_path) {  // main.go:306-342
+    if (R.pre.header.size() <= 9) {
+      // "No samples found in VCF file; writing empty dosage matrix file"
+      FILE *f = fopen(R.cfg->dosage_path, "wb");
+      if (!f) {
+        *msg = std::string("open ") + R.cfg->dosage_path + ": " + strerror(errno);
+        return BVCF_E_FATAL;
+      }
+      fclose(f);
+    } else if (bvcf_arrow_open(&R.arrow, R.cfg->dosage_path, R.name_ptr.data(), R.name_len.data(),
+                               (uint32_t)R.name_ptr.size(), 0, 0) != BVCF_OK) {
+      *msg = std::string("open ") + R.cfg->dosage_path + ": " + strerror(errno);
+      return BVCF_E_FATAL;
+    }
+  }
   return BVCF_OK;
+}
+
+// the Arrow rows of one collected batch, in input order (main.go:576-584): "chrom:pos:ref:alt" + one int8 per sample
+int append_dosage(Run &R, const bvcf_result *r, const uint8_t *block) {
+  if (!R.arrow || !r->dosage) return BVCF_OK;
+  std::string locus;
+  for (uint32_t li = 0; li < r->n_lines; li++) {
+    const bvcf_line &L = r->lines[li];
+    if (L.status != BVCF_LINE_OK) continue;
+    const char *row = (const char *)block + L.off;
+    for (uint32_t k = 0; k < L.n_rec; k++) {
+      const uint32_t slot = k ? L.rec_first + k - 1 : li;
+      const bvcf_allele &A = r->alleles[slot];
+      if (A.ac == 0) continue;  // main.go:558-560
+      locus.clear();
+      if (L.fend[0] < 4 || row[0] != 'c') locus.append("chr");
+      locus.append(row, L.fend[0]);
+      locus.push_back(':');
+      if (A.flags & BVCF_ALLELE_POS_TEXT)
+        locus.append(row + L.fend[0] + 1, L.fend[1] - L.fend[0] - 1);
+      else
+        append_ll(locus, A.pos);
+      locus.push_back(':');
+      locus.push_back((char)A.ref);
+      locus.push_back(':');
+      if (A.kind == BVCF_ALT_BASE) {
+        locus.push_back((char)A.alt_base);
+      } else if (A.kind == BVCF_ALT_INS) {
+        locus.push_back('+');
+        locus.append((const char *)block + A.alt_off, A.alt_len);
+      } else {
+        locus.push_back('-');
+        append_ll(locus, A.alt_len);
+      }
+      if (bvcf_arrow_append(R.arrow, locus.data(), (uint32_t)locus.size(), r->dosage + (size_t)slot * r->dosage_stride))
+        return BVCF_E_FATAL;
+    }
+  }
+  return BVCF_OK;
+}
+
+int close_dosage(Run &R) {
+  if (!R.arrow) return BVCF_OK;
+  const int rc = bvcf_arrow_close(R.arrow);
+  R.arrow = nullptr;
+  return rc;
 }
 
 // submit one block and collect it, growing the result reservation when the batch asks for it
@@ -566,9 +631,23 @@ int bvcf_run_buffer(const bvcf_config *c, const uint8_t *vcf, size_t n, char **o
         break;
       }
       lines_in += res.n_lines_seen;
-      format_batch(c, &res, vcf + pos, nm, R.n_threads, o, l);
+      if (R.want_rows) {
+        format_batch(c, &res, vcf + pos, nm, R.n_threads, o, l);
+      } else {
+        std::string none;
+        format_batch(c, &res, vcf + pos, nm, 1, none, l);  // the log lines only
+      }
+      if (append_dosage(R, &res, vcf + pos)) {
+        l.append("dosage matrix: write failed\n");
+        rc = BVCF_E_FATAL;
+        break;
+      }
       pos += nb;
     }
+  }
+  if (close_dosage(R) && rc == BVCF_OK) {
+    l.append("dosage matrix: write failed\n");
+    rc = BVCF_E_FATAL;
   }
   if (R.ctx) bvcf_destroy(R.ctx);
   if (n_lines_in) *n_lines_in = lines_in;
@@ -610,8 +689,8 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   R.max_batch = c->max_batch_bytes ? c->max_batch_bytes : (64ull << 20);
   uint64_t lines_in = 0;
 
-  // fmt.Fprintln(writer, stringHeader(config)), main.go:199
-  {
+  // fmt.Fprintln(writer, stringHeader(config)), main.go:196-200
+  if (!c->no_out) {
     char h[512];
     size_t hn = bvcf_string_header(c, h, sizeof h);
     h[hn] = '\n';
@@ -761,7 +840,9 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     t0 = now_s();
     std::string *out = new std::string();
     Names nm{R.name_ptr.data(), R.name_len.data()};
-    format_batch(c, &res, b.buf + b.start, nm, R.n_threads, *out, log);
+    format_batch(c, &res, b.buf + b.start, nm, R.want_rows ? R.n_threads : 1, *out, log);
+    if (!R.want_rows) out->clear();
+    if (append_dosage(R, &res, b.buf + b.start)) fail("dosage matrix: write failed", BVCF_E_FATAL);
     t_fmt += now_s() - t0;
     write_q.push(out);
     if (!log.empty()) {
@@ -835,6 +916,10 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   drain.join();
   write_q.push(nullptr);
   writer.join();
+  if (close_dosage(R) && rc == BVCF_OK) {
+    log.append("dosage matrix: write failed\n");
+    rc = BVCF_E_FATAL;
+  }
   if (!log.empty()) write_all(fd_err, log.data(), log.size());
   const double t_end0 = now_s();
   if (R.ctx) {

@@ -138,10 +138,6 @@ int main(int argc, char **argv) {
     dprintf(fd_err, "When specifying --noOut, must specify --dosageOutput\n");
     return 1;
   }
-  if (!c.dosage.empty() || c.no_out) {
-    dprintf(fd_err, "--dosageOutput / --noOut (Arrow dosage matrix) are outside this build's scope\n");
-    return 1;
-  }
   if (!c.out.empty()) {  // main.go:172
     fd_out = open(c.out.c_str(), O_WRONLY | O_CREAT, 0644);
     if (fd_out < 0) {
@@ -163,6 +159,8 @@ int main(int argc, char **argv) {
   cfg.device = c.device;
   if (c.batch_mb) cfg.max_batch_bytes = c.batch_mb << 20;
   cfg.sample_list_path = c.sample.c_str();
+  cfg.dosage_path = c.dosage.c_str();  // main.go:89
+  cfg.no_out = c.no_out;               // main.go:88
   const char *raw = getenv("BVCF_RAW_SAMPLE_NAMES");
   if (raw && *raw == '1') cfg.normalize_header = 0;
 

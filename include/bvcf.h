@@ -240,6 +240,9 @@ typedef struct {
   uint32_t n_format_threads;    /* 0 = hardware concurrency */
   uint64_t max_batch_bytes;     /* 0 = 64 MiB */
   const char *sample_list_path; /* --sample: write the sample names, one per line (main.go:398-445); NULL/"" = no */
+  const char *dosage_path;      /* --dosageOutput: Arrow IPC file of the dosage matrix (main.go:306-342); NULL/"" = no */
+  uint8_t no_out;               /* --noOut: no TSV rows and no header line (main.go:196-208,502) */
+  uint8_t reserved3[7];
 } bvcf_config;
 
 void bvcf_config_defaults(bvcf_config *c); /* setup() defaults, main.go:84-99 */

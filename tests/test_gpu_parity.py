@@ -255,6 +255,63 @@ def test_dosage_reference_known_answer(bv):
     assert orc.run_dosage(vcf) == [("chr1:1000:A:T", [2, 1, 0]), ("chr2:200:C:G", [1, 0, 2]), ("chr22:300:G:T", [-1, -1, 2])]
 
 
+def _read_matrix(path):
+    import pyarrow.ipc as ipc
+    t = ipc.open_file(str(path)).read_all()
+    t.validate(full=True)
+    cols = [t.column(i).to_pylist() for i in range(1, t.num_columns)]
+    return t.schema.names, [(locus, [c[r] for c in cols]) for r, locus in enumerate(t.column(0).to_pylist())]
+
+
+@pytest.mark.parametrize("seed,n_lines,n_samples,fmt_extra", [(51, 300, 12, False), (52, 120, 2504, False),
+                                                               (53, 150, 40, True)])
+def test_dosage_output_file(bv, tmp_path, seed, n_lines, n_samples, fmt_extra):
+    """--dosageOutput end to end (main.go:306-342,576-584): the Arrow file read back with pyarrow holds the rows
+    the oracle computes, in input order; the TSV is unchanged; --noOut drops the TSV only"""
+    pytest.importorskip("pyarrow")
+    vcf = vcfgen.gen_vcf(seed, n_lines, n_samples, fmt_extra, 0.03)
+    want = orc.run_dosage(vcf, {"allow": ""})
+    p = tmp_path / "dosage.feather"
+    out, _ = both(bv, vcf, {"allow": "", "dosageOutput": p})
+    names, rows = _read_matrix(p)
+    assert names == ["locus"] + ["S%05d" % i for i in range(n_samples)]
+    assert rows == want
+    # small batches cut the same file into many record batches
+    rc, out2, _, _ = bv.run_buffer(vcf, {"allow": "", "dosageOutput": p, "noOut": True}, max_batch_bytes=max(1 << 16, 8 * n_samples * 8))
+    assert rc == 0 and out2 == b""
+    assert _read_matrix(p)[1] == want
+
+
+def test_dosage_output_no_samples_writes_empty_file(bv, tmp_path):
+    """main.go:308-318"""
+    vcf = vcfgen.gen_vcf(54, 50, 0)
+    p = tmp_path / "empty.feather"
+    both(bv, vcf, {"allow": "", "dosageOutput": p})
+    assert p.exists() and p.stat().st_size == 0
+
+
+def test_cli_dosage_and_no_out(bv, tmp_path):
+    """TestGenotypeMatrix / TestNoOut through the binary (main_test.go:2911-3029), plus the flag checks of main.go:160-166"""
+    pytest.importorskip("pyarrow")
+    hdr = "##fileformat=VCFv4.x\n" + "\t".join(H8 + ["FORMAT", "S1", "S2", "S3"]) + "\n"
+    rows = [["1", "1000", "rs1", "A", "T", ".", "PASS", "DP=100", "GT", "1|1", "0|1", "0|0"],
+            ["2", "200", "rs2", "C", "G", ".", "PASS", "DP=100", "GT", "0|1", "0|0", "1|1"],
+            ["22", "300", "rs2", "G", "T", ".", "PASS", "DP=100", "GT", "0|.", "0|.", "1|1"]]
+    vcf = (hdr + "".join("\t".join(r) + "\n" for r in rows)).encode()
+    want = [("chr1:1000:A:T", [2, 1, 0]), ("chr2:200:C:G", [1, 0, 2]), ("chr22:300:G:T", [-1, -1, 2])]
+    p = tmp_path / "m.feather"
+    r = _run_cli(["--dosageOutput", str(p)], vcf)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count(b"\n") == 4  # header + 3 rows
+    assert _read_matrix(p) == (["locus", "S1", "S2", "S3"], want)
+    p2 = tmp_path / "m2.feather"
+    r = _run_cli(["--dosageOutput", str(p2), "--noOut"], vcf)
+    assert r.returncode == 0 and r.stdout == b""
+    assert _read_matrix(p2)[1] == want
+    assert _run_cli(["--noOut"], vcf).returncode == 1
+    assert _run_cli(["--noOut", "--out", str(tmp_path / "x.tsv"), "--dosageOutput", str(p2)], vcf).returncode == 1
+
+
 def _run_cli(args, data):
     import subprocess
     exe = os.path.join(ROOT, "bystro-vcf_amd", "bystro-vcf")
