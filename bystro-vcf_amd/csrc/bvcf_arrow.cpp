@@ -9,7 +9,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bvcf.h"
@@ -190,7 +192,7 @@ struct Writer {
   uint32_t n_rows = 0;
   std::vector<int32_t> locus_off;
   std::string locus_data;
-  std::vector<int8_t> cols;  // column-major: cols[s * rows_per_batch + row]
+  std::vector<int8_t> rows;  // the batch as it arrives, row-major: rows[row * ns + s]; transposed at flush
   std::string err;
 
   bool put(const void *p, size_t n) {
@@ -247,9 +249,40 @@ struct Writer {
     add_buffer(body, bufs, nullptr, 0);  // locus validity: no nulls
     add_buffer(body, bufs, locus_off.data(), locus_off.size() * 4);
     add_buffer(body, bufs, locus_data.data(), locus_data.size());
-    for (uint32_t s = 0; s < ns; s++) {
-      add_buffer(body, bufs, nullptr, 0);
-      add_buffer(body, bufs, &cols[(size_t)s * rows_per_batch], n_rows);
+    // the sample columns are independent buffers: compressed by a few threads, each into its own piece of
+    // the body, then laid end to end (every piece is a multiple of 8 bytes long)
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_thr = (unsigned)std::min<uint64_t>(std::min(16u, hw ? hw : 1u), ((uint64_t)ns * n_rows >> 16) + 1);
+    std::vector<std::string> piece(n_thr);
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> piece_bufs(n_thr);
+    auto work = [&](unsigned t) {
+      // 64 columns at a time: one cache line of every row feeds 64 column buffers that stay in L1/L2
+      constexpr uint32_t kTile = 64;
+      std::vector<int8_t> col((size_t)kTile * n_rows);
+      const uint32_t s_lo = (uint32_t)((uint64_t)ns * t / n_thr), s_hi = (uint32_t)((uint64_t)ns * (t + 1) / n_thr);
+      for (uint32_t s0 = s_lo; s0 < s_hi; s0 += kTile) {
+        const uint32_t w = std::min(kTile, s_hi - s0);
+        for (uint32_t r = 0; r < n_rows; r++) {
+          const int8_t *src = &rows[(size_t)r * ns + s0];
+          for (uint32_t j = 0; j < w; j++) col[(size_t)j * n_rows + r] = src[j];
+        }
+        for (uint32_t j = 0; j < w; j++) {
+          add_buffer(piece[t], piece_bufs[t], nullptr, 0);
+          add_buffer(piece[t], piece_bufs[t], &col[(size_t)j * n_rows], n_rows);
+        }
+      }
+    };
+    if (n_thr <= 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < n_thr; t++) th.emplace_back(work, t);
+      for (auto &x : th) x.join();
+    }
+    for (unsigned t = 0; t < n_thr; t++) {
+      const int64_t at = (int64_t)body.size();
+      for (auto &b : piece_bufs[t]) bufs.emplace_back(b.first + at, b.second);
+      body.append(piece[t]);
     }
     Fb fb;
     uint32_t compression = 0;
@@ -313,7 +346,7 @@ int bvcf_arrow_open(bvcf_arrow **out, const char *path, const char *const *sampl
   w.level = zstd_level == 0 ? 3 : zstd_level;
   w.names.emplace_back("locus");
   for (uint32_t i = 0; i < n_samples; i++) w.names.emplace_back(sample_names[i], sample_name_lens[i]);
-  w.cols.resize((size_t)n_samples * w.rows_per_batch);
+  w.rows.resize((size_t)n_samples * w.rows_per_batch);
   Fb fb;
   fb.finish(build_message(fb, kHeaderSchema, build_schema(fb, w.names), 0));
   int32_t meta_len;
@@ -331,7 +364,7 @@ int bvcf_arrow_append(bvcf_arrow *a, const char *locus, uint32_t locus_len, cons
   Writer &w = a->w;
   w.locus_off.push_back((int32_t)w.locus_data.size());
   w.locus_data.append(locus, locus_len);
-  for (uint32_t s = 0; s < w.ns; s++) w.cols[(size_t)s * w.rows_per_batch + w.n_rows] = dosage[s];
+  if (w.ns) memcpy(&w.rows[(size_t)w.n_rows * w.ns], dosage, w.ns);
   if (++w.n_rows == w.rows_per_batch && !w.flush()) return BVCF_E_IO;
   return BVCF_OK;
 }
