@@ -120,6 +120,9 @@ def test_example_query_vcf(bv):
     # unaligned ones there), one less/more does not
     (16, 60, 512, False, 0.002), (17, 30, 2560, False, 0.001), (18, 30, 2559, False, 0.001), (19, 40, 1024, False, 0.01),
     (20, 30, 2304, False, 0.001), (21, 30, 2305, False, 0.001),
+    # one case per remaining instance of the streaming kernel's pipeline (it is specialised per chunk count 1..10)
+    (22, 60, 700, False, 0.003), (23, 50, 1200, False, 0.002), (24, 40, 1500, False, 0.002), (25, 40, 1700, False, 0.002),
+    (26, 40, 2000, False, 0.001),
 ])
 def test_fuzz_parity(bv, seed, n_lines, n_samples, fmt_extra, weird):
     vcf = vcfgen.gen_vcf(seed, n_lines, n_samples, fmt_extra, weird)
