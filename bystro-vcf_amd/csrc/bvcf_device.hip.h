@@ -11,6 +11,8 @@
 //   k_gt           one wavefront per task: the per-sample GT byte scan -> ac/an/het/hom/missing
 //                  and the 2-bit class map.  THE HBM-bound kernel.   (main.go:1042-1194)
 //   k_finish       field-count verdict per line, scan results into the allele records
+//   k_dosage       (bvcf_params.want_dosage) one wave per output allele: the int8 dosage row
+//                                                                (main.go:1069-1178)
 //
 // Streaming variant for files with samples (KernelArgs.fused): the census, its scans, the scatter
 // and the ALT #1 genotype scan are replaced by ONE pass over the text,
@@ -21,10 +23,11 @@
 //   k_order        tile-local line entries -> input-ordered line_off / line_len / results
 // after which k_head, k_gt (further ALT indices only) and k_finish run as above.
 //
-// Everything is byte/integer work bounded by the HBM read of the line bytes; no MFMA.
-// Loads are 16 B per lane, 1 KiB per wave-instruction, starting exactly at the byte the
-// record window starts at (unaligned dwordx4), so that in a regular sample region
-// ("x|y\t" per sample) every dword in a lane is exactly one sample field.
+// Everything is byte/integer work over the line bytes; no MFMA.  The genotype scans are bound by
+// VALU issue at 57-70 % of the HBM peak.
+// Loads are 16 B per lane, 1 KiB per wave-instruction, from the dword at or before the byte the
+// record window starts at; the 0-3 byte shift is undone in registers (realign), after which every
+// dword of a lane in a regular sample region ("x|y\t" per sample) is exactly one sample field.
 #pragma once
 
 
