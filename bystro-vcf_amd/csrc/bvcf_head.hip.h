@@ -149,14 +149,25 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
         }
       }
     }
-    u32x4 v_next = load16(a.buf, __shfl(my_ls, 0, kGroup) + 16u * gl, a.cap);
-    for (uint32_t r = 0; r < kLinesPerStep / kGroupsPerWg; r++) {
+    // The first 256 B window of all 16 rounds is requested up front, unconditionally (lines past the end
+    // read offset 0): the rounds are then paced by the parse, not by one memory latency each.  The LDS the
+    // workgroup stages the heads in already limits a CU to two workgroups, so the 64 registers are free.
+    constexpr uint32_t kRounds = kLinesPerStep / kGroupsPerWg;
+    u32x4 v_win[kRounds];
+    uint32_t r_ls[kRounds], r_len[kRounds];
+#pragma unroll
+    for (uint32_t r = 0; r < kRounds; r++) {
+      r_ls[r] = __shfl(my_ls, r, kGroup);
+      r_len[r] = __shfl(my_len, r, kGroup);
+      v_win[r] = *reinterpret_cast<const u32x4_u *>(a.buf + min(r_ls[r] + 16u * gl, a.cap - 16u));
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kRounds; r++) {
       const uint32_t ll = r * kGroupsPerWg + g;
       const uint32_t line = line0 + ll;
-      const uint32_t ls = __shfl(my_ls, r, kGroup);
-      const uint32_t len = __shfl(my_len, r, kGroup);
-      const u32x4 v_first = v_next;
-      if (r + 1 < kLinesPerStep / kGroupsPerWg) v_next = load16(a.buf, __shfl(my_ls, r + 1, kGroup) + 16u * gl, a.cap);
+      const uint32_t ls = r_ls[r];
+      const uint32_t len = r_len[r];
+      const u32x4 v_first = v_win[r];
       if (line >= n_lines) continue;
       const uint32_t cend = ls + len;
       uint32_t found = 0, base = ls;
