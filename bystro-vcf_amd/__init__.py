@@ -27,7 +27,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DEVICE_PAD = 64
 NO_CMAP = 0xFFFFFFFF
 
@@ -234,7 +234,13 @@ class Batch:
         """per-sample class codes (0 none, 1 het, 2 hom, 3 missing) of one allele record"""
         off = int(allele_row["cmap_off"])
         ns = self.n_samples
-        m = self.cmap[off:off + (ns + 3) // 4]
+        if int(allele_row["flags"]) & 2:  # BVCF_ALLELE_CMAP_SPARSE: count, then (byte index << 8 | byte) entries
+            words = self.cmap[off:off + 64].view("<u4")
+            m = np.zeros((ns + 3) // 4, dtype=np.uint8)
+            for e in words[1:1 + int(words[0])]:
+                m[int(e) >> 8] = int(e) & 0xFF
+        else:
+            m = self.cmap[off:off + (ns + 3) // 4]
         return ((m[:, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)) & 3).reshape(-1)[:ns]
 
 

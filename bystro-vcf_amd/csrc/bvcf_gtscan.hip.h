@@ -127,7 +127,12 @@ __device__ __forceinline__ uint32_t fast_valid(uint32_t t) { return (0x400003FFu
 
 struct FastAcc {
   uint32_t bad, ok, het, hom, miss;
+  uint32_t n_sp;  // wave-uniform: entries in the sparse class list; > BVCF_CMAP_SPARSE_MAX once the line went dense
 };
+
+// the sparse class list of the line being scanned lives behind the wave's stage in LDS
+constexpr uint32_t kSparseWords = 16;  // BVCF_CMAP_SPARSE_MAX entries, padded
+constexpr uint32_t kDenseMode = BVCF_CMAP_SPARSE_MAX + 1u;
 
 constexpr uint32_t kStageChunks = 64;                 // class-map bytes staged in LDS per wave:
 constexpr uint32_t kStageBytes = kStageChunks * 64u;  // 64 chunks x 64 B = 4 KiB = 16 384 samples
@@ -158,9 +163,13 @@ __device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *cmap,
 }
 
 // one 1 KiB chunk (this lane's 4 fields) of a regular region; class bytes go to the LDS stage
+// sp (optional, lines of <= kStageChunks chunks only): the line starts with a list of its non-zero class bytes
+// (acc.n_sp entries in sp[]) instead of the staged map; the stage is zeroed and the list replayed into it when the
+// list overflows.  Most alleles of a cohort file are carried by a handful of samples: their 64-byte list replaces
+// the LDS staging and the map-sized store.
 __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunks, uint32_t ns, uint32_t kref,
                                            uint32_t table, uint8_t *cmap, uint8_t *stage, uint32_t stride,
-                                           uint32_t term_xor, FastAcc &acc) {
+                                           uint32_t term_xor, FastAcc &acc, uint32_t *sp = nullptr) {
   const int lane = lane_id();
   const uint32_t f0 = c * 256u + 4u * lane;  // sample index of the lane's first dword
   uint32_t t[4] = {v.x ^ kref, v.y ^ kref, v.z ^ kref, v.w ^ kref};
@@ -189,9 +198,36 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
     acc.het += __popc(lo & ~hi);
     acc.hom += __popc(hi & ~lo);
     acc.miss += __popc(lo & hi);
-    if (cmap) stage[(c % kStageChunks) * 64u + lane] = (uint8_t)byte;  // the stage starts zeroed
+    if (cmap && sp && acc.n_sp < kDenseMode) {
+      const unsigned long long nz = __ballot(byte != 0);
+      const uint32_t cnt = (uint32_t)__popcll(nz);
+      if (acc.n_sp + cnt <= BVCF_CMAP_SPARSE_MAX) {
+        const uint32_t at = acc.n_sp + __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
+        if (byte) sp[at] = ((c * 64u + (uint32_t)lane) << 8) | byte;
+        acc.n_sp += cnt;
+      } else {
+        // too many for the list: from here on the line is a map.  Replay the entries into the zeroed stage.
+        zero_stage(stage, n_chunks);
+        if ((uint32_t)lane < acc.n_sp) {
+          const uint32_t e = sp[lane];
+          stage[e >> 8] = (uint8_t)e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        acc.n_sp = kDenseMode;
+      }
+    }
+    if (cmap && (!sp || acc.n_sp >= kDenseMode)) stage[(c % kStageChunks) * 64u + lane] = (uint8_t)byte;  // the stage starts zeroed
   }
-  if (cmap && ((c % kStageChunks) == kStageChunks - 1u || c + 1 == n_chunks)) {
+  if (cmap && sp && acc.n_sp < kDenseMode) {
+    if (c + 1 == n_chunks) {  // the list: count, then the entries
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if ((uint32_t)lane <= acc.n_sp)
+        __builtin_nontemporal_store(lane == 0 ? acc.n_sp : sp[lane - 1], reinterpret_cast<uint32_t *>(cmap) + lane);
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else if (cmap && ((c % kStageChunks) == kStageChunks - 1u || c + 1 == n_chunks)) {
     flush_stage(stage, cmap, c - (c % kStageChunks), ((c % kStageChunks) + 1u) * 64u, stride);
     if (c + 1 != n_chunks) zero_stage(stage, n_chunks - (c + 1u));
   }
@@ -222,7 +258,7 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
   auto next0 = [&](uint32_t c, const u32x4 &nxt) -> uint32_t {
     return c + 1 < n_chunks ? (uint32_t)__builtin_amdgcn_readfirstlane(nxt.x) : 0u;
   };
-  FastAcc acc = {0, 1, 0, 0, 0};
+  FastAcc acc = {0, 1, 0, 0, 0, kDenseMode};
   if (cmap) zero_stage(stage, n_chunks);
   u32x4 va[kFastGroup], vb[kFastGroup];
 #pragma unroll

@@ -65,13 +65,15 @@ __device__ inline void write_allele(const KernelArgs &a, uint32_t idx, uint32_t 
   r.n_het = 0;
   r.n_hom = 0;
   r.n_miss = 0;
-  r.cmap_off = cmap_off;
+  // offsets are multiples of 16; k_stream sets bit 0 when the slot holds a sparse list
+  const bool sparse = cmap_off != BVCF_NO_CMAP && (cmap_off & 1u);
+  r.cmap_off = sparse ? cmap_off & ~1u : cmap_off;
   r.ref = ref;
   r.alt_base = alt_base;
   r.kind = e.mnp ? (uint8_t)BVCF_ALT_BASE : e.kind;
   r.site_type = site_type;
   r.trtv = (site_type == BVCF_SITE_MULTI || r.kind != BVCF_ALT_BASE) ? 0 : trtv_of(ref, alt_base);
-  r.flags = (!e.mnp && e.pos_text) ? BVCF_ALLELE_POS_TEXT : 0;
+  r.flags = ((!e.mnp && e.pos_text) ? BVCF_ALLELE_POS_TEXT : 0) | (sparse ? BVCF_ALLELE_CMAP_SPARSE : 0);
   r.pad[0] = r.pad[1] = 0;
   r.gt_task = task;
   r.pad2 = 0;

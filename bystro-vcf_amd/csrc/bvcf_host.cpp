@@ -52,14 +52,12 @@ struct Names {
   const uint32_t *len;
 };
 
-// strings.Join(names of samples with class `want`, fieldDelimiter)
-void join_class(std::string &o, const uint8_t *cmap, uint32_t ns, unsigned want, const Names &nm, const char *delim,
-                size_t ndelim) {
+// strings.Join(names of samples with class `want`, fieldDelimiter); `sparse`: the map is a list of its non-zero
+// bytes (BVCF_ALLELE_CMAP_SPARSE)
+void join_class(std::string &o, const uint8_t *cmap, bool sparse, uint32_t ns, unsigned want, const Names &nm,
+                const char *delim, size_t ndelim) {
   bool first = true;
-  const uint32_t nbytes = (ns + 3) / 4;
-  for (uint32_t b = 0; b < nbytes; b++) {
-    const unsigned byte = cmap[b];
-    if (!byte) continue;
+  auto emit = [&](uint32_t b, unsigned byte) {
     for (unsigned j = 0; j < 4; j++) {
       if (((byte >> (2 * j)) & 3u) != want) continue;
       const uint32_t s = b * 4 + j;
@@ -68,6 +66,21 @@ void join_class(std::string &o, const uint8_t *cmap, uint32_t ns, unsigned want,
       o.append(nm.ptr[s], nm.len[s]);
       first = false;
     }
+  };
+  if (sparse) {
+    uint32_t n;
+    memcpy(&n, cmap, 4);
+    for (uint32_t i = 0; i < n && i < BVCF_CMAP_SPARSE_MAX; i++) {
+      uint32_t e;
+      memcpy(&e, cmap + 4 + 4 * i, 4);
+      emit(e >> 8, e & 0xFFu);
+    }
+    return;
+  }
+  const uint32_t nbytes = (ns + 3) / 4;
+  for (uint32_t b = 0; b < nbytes; b++) {
+    const unsigned byte = cmap[b];
+    if (byte) emit(b, byte);
   }
 }
 
@@ -167,7 +180,7 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
           out.append(empty);
           out.append("\t0");
         } else {
-          join_class(out, cm, ns, lists[q].cls, nm, delim, ndelim);
+          join_class(out, cm, (A.flags & BVCF_ALLELE_CMAP_SPARSE) != 0, ns, lists[q].cls, nm, delim, ndelim);
           out.push_back('\t');
           append_g3(out, (double)lists[q].n / lists[q].denom);
         }

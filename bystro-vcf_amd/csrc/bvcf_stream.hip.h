@@ -138,7 +138,9 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
 #endif
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
+  __shared__ uint32_t s_sparse[kWavesPerWg][kSparseWords];
   uint8_t *stage = s_stage[threadIdx.x >> 6];
+  uint32_t *sparse = s_sparse[threadIdx.x >> 6];
   const int lane = lane_id();
   const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
   const uint32_t n_waves = gridDim.x * kWavesPerWg;
@@ -291,8 +293,14 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           // ---- scan A, re-issuing each register for B
           const uint32_t cmA = map_slot();
           uint8_t *cm = cmA != BVCF_NO_CMAP ? a.cmap + cmA : nullptr;
-          if (cm) zero_stage(stage, nc);
-          FastAcc acc = {0, 1, 0, 0, 0};
+          // the class map starts as a sparse list (nothing to zero) when a list fits the map's slot
+#ifdef BVCF_EXP_NO_SPARSE
+          const bool sparse_ok = false;
+#else
+          const bool sparse_ok = a.cmap_stride >= 4u * kSparseWords;
+#endif
+          FastAcc acc = {0, 1, 0, 0, 0, sparse_ok ? 0u : kDenseMode};
+          if (cm && !sparse_ok) zero_stage(stage, nc);
           const uint32_t rA = sA & amask;
           const uint32_t w0 = __builtin_amdgcn_alignbyte(__builtin_amdgcn_readfirstlane(va[0].y),
                                                          __builtin_amdgcn_readfirstlane(va[0].x), rA);
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
             if ((uint32_t)g < nc) {
               const uint32_t nx = (uint32_t)g + 1u < nc
                                       ? (uint32_t)__builtin_amdgcn_readfirstlane(va[g + 1 < kPipeChunks ? g + 1 : g].x) : 0u;
-              fast_chunk(realign(va[g], nx, rA), g, nc, ns, kref, table1, cm, stage, a.cmap_stride, term_xor, acc);
+              fast_chunk(realign(va[g], nx, rA), g, nc, ns, kref, table1, cm, stage, a.cmap_stride, term_xor, acc, sparse_ok ? sparse : nullptr);
             }
             va[g] = chunk_at(s_next, g);
           }
@@ -321,7 +329,8 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           }
           finish_stats(acc, &st);
           seen++;
-          commit(pA, peA, st, false, cmA);
+          // (bit 0 of the offset tells k_head that the slot holds a list, BVCF_ALLELE_CMAP_SPARSE)
+          commit(pA, peA, st, false, cm && acc.n_sp < kDenseMode ? cmA | 1u : cmA);
           p = peA + 1u;
           if (!b_ok) {
             s_begin = kNone;  // nothing pending: rediscover from p

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BVCF_ABI_VERSION 2
+#define BVCF_ABI_VERSION 3
 
 typedef enum {
   BVCF_OK = 0,
@@ -82,6 +82,11 @@ enum {
 };
 
 #define BVCF_ALLELE_POS_TEXT 1u /* bvcf_allele.flags: output pos is the POS field verbatim */
+/* bvcf_allele.flags: the class map at cmap_off is a short list, not the 2-bit map: uint32 n (<= BVCF_CMAP_SPARSE_MAX),
+ * then n entries (map byte index << 8 | map byte) in ascending order; every map byte that is not listed is 0.
+ * The streaming path writes this form for alleles that few samples carry (most of a cohort file). */
+#define BVCF_ALLELE_CMAP_SPARSE 2u
+#define BVCF_CMAP_SPARSE_MAX 15u
 #define BVCF_NO_CMAP 0xFFFFFFFFu
 #define BVCF_DEVICE_PAD 64      /* bytes a device-resident block must own past nbytes */
 
