@@ -149,6 +149,32 @@ def test_chunk_boundary_alignment(bv, n_samples):
     both(bv, vcf)
 
 
+@pytest.mark.parametrize("n_samples", [260, 2504])
+def test_sparse_class_list_boundary(bv, n_samples):
+    """alleles whose class map has 0..20 non-zero bytes: the streaming path keeps up to 15 as a list
+    (BVCF_ALLELE_CMAP_SPARSE) and turns the line into a map at the 16th, possibly in the middle of a chunk"""
+    import random
+    rng = random.Random(n_samples)
+    lines, pos = [], 5000
+    for k in list(range(0, 21)) + [40, 64, 65]:
+        for rep in range(3):
+            gts = ["0|0"] * n_samples
+            n_bytes = (n_samples + 3) // 4
+            picks = rng.sample(range(n_bytes), min(k, n_bytes))
+            for b in picks:
+                for q in rng.sample(range(4), rng.randint(1, 4)):
+                    if b * 4 + q < n_samples:
+                        gts[b * 4 + q] = rng.choice(["0|1", "1|0", "1|1", ".|.", "1|.", "2|1"])
+            if rep == 2 and picks:  # everything in the last chunk(s)
+                gts = ["0|0"] * n_samples
+                for j in range(min(k, n_samples)):
+                    gts[n_samples - 1 - 4 * j if n_samples - 1 - 4 * j >= 0 else 0] = "0|1"
+            pos += 3
+            lines.append("\t".join(["7", str(pos), ".", "G", "A,T", "9", "PASS", ".", "GT"] + gts))
+    vcf = (vcfgen.header(n_samples) + "\n".join(lines) + "\n").encode()
+    both(bv, vcf)
+
+
 def test_crlf_and_lone_cr(bv):
     v = vcfgen.gen_vcf(21, 120, 9, weird=0.05, eol="\r\n")
     both(bv, v, {"allow": ""})
