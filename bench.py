@@ -138,7 +138,7 @@ def main():
     n_alt_cap = args.rows * (4 if args.profile == "c4" or args.golden else 1) + 1024
     ctx = bv.Ctx(bg.n_header_fields(cfg), device=local_rank, max_batch_bytes=max_bytes, n_slots=1,
                  max_lines=args.rows + 16, max_alleles=n_alt_cap,
-                 cmap_bytes=(n_alt_cap + 16 * 8192) * stride + 4096,  # + the streaming path's per-wave map blocks
+                 cmap_bytes=(n_alt_cap + 16 * 8192) * stride + 4096,  # + the slack of the streaming path's per-wave slot ranges
                  path=args.path,
                  want_class_maps=not args.no_class_maps)
     ptrs = [t.data_ptr() for t in blocks]

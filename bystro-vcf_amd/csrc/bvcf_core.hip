@@ -422,6 +422,11 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
     if (w >= 1 && w <= per_cu) per_cu = w;
   }
   c->stream_grid = c->n_cu * per_cu;
+  // the streaming kernel gives every wave its own range of class-map slots (two of them slack): room for that
+  if (!p->cmap_bytes) {
+    c->max_cmap += (uint64_t)c->stream_grid * kWavesPerWg * 2u * c->cmap_stride + c->max_lines / 16 * (uint64_t)c->cmap_stride;
+    c->max_cmap = std::min<uint64_t>((c->max_cmap + 63) & ~63ull, 0xFFFFFF00ull);
+  }
 
   FilterTable ft;
   memset(&ft, 0, sizeof ft);

@@ -175,15 +175,18 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
     }
   }
 
-  // class-map slot for the next listed line
+  // Class-map slots without atomics.  A line that is scanned here is regular, i.e. at least 4*ns + 8 bytes long,
+  // so a run of B bytes holds at most B / (4*ns + 8) + 2 of them: wave w owns slots [w * W, (w + 1) * W) and the
+  // arena stays within a few percent of compact.  (Asking a device counter for slots cost 8 % of this kernel
+  // either way: 16 at a time, every request drains the loads in flight; a whole run at a time, 3 072 waves
+  // hit one address when the kernel starts, and a single address serves about 90 atomics per microsecond.)
+  const uint32_t slots_per_wave = (uint32_t)(((unsigned long long)per_wave * T) / (4ull * ns + 8ull)) + 2u;
+  cm_next = wave * slots_per_wave;
+  cm_end = cm_next + slots_per_wave;
+  if (maps && wave == 0 && lane == 0)  // only waves that own tiles own slots; k_head's maps follow
+    a.counters->cmap_maps = ((a.n_tiles + per_wave - 1u) / max(per_wave, 1u)) * slots_per_wave;
   auto map_slot = [&]() -> uint32_t {
-    if (!maps) return BVCF_NO_CMAP;
-    if (cm_next == cm_end) {
-      uint32_t b = 0;
-      if (lane == 0) b = atomicAdd(&a.counters->cmap_maps, 16u);
-      cm_next = __builtin_amdgcn_readfirstlane(b);
-      cm_end = cm_next + 16u;
-    }
+    if (!maps || cm_next >= cm_end) return BVCF_NO_CMAP;  // (the bound above makes the second case unreachable)
     return cmap_of(a, cm_next, true);
   };
   // list a line (in input order) in the tile it starts in
