@@ -386,7 +386,7 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   // streaming path: lines are found by the genotype scan itself.  Its tile-local entry quota is
   // bounded because a line that passes the field count is at least n_header - 1 bytes long; for
   // narrow files the quota would dwarf the text, so they stay on the census path unless asked.
-  c->tile_bytes = 64u << 10;
+  c->tile_bytes = 64u << 10;  // (8-64 KiB measure alike now that the runs are balanced)
   if (const char *e = getenv("BVCF_TILE_KB")) {
     const unsigned kb = (unsigned)atoi(e);
     if (kb >= 4 && kb <= (1u << 20)) c->tile_bytes = kb << 10;

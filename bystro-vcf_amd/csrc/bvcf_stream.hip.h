@@ -161,8 +161,12 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   // (Claiming smaller runs from a counter instead evens out the waves' finish times but costs more
   // than it returns: every run start is a chain of dependent loads.  The kernel is bound by VALU
   // issue, not by the slowest wave.)
-  const uint32_t per_wave = (a.n_tiles + n_waves - 1) / n_waves;
-  const uint32_t tile_lo = min(wave * per_wave, a.n_tiles), tile_hi = min(tile_lo + per_wave, a.n_tiles);
+  // Balanced: the first n_tiles % n_waves waves walk one tile more than the others (a plain ceil() split left 5 %
+  // of the waves without work on the benchmark's 20 332 tiles).
+  const uint32_t q_tiles = a.n_tiles / n_waves, r_tiles = a.n_tiles % n_waves;
+  const uint32_t per_wave = q_tiles + (r_tiles ? 1u : 0u);  // the longest run, in tiles
+  const uint32_t tile_lo = wave * q_tiles + min(wave, r_tiles);
+  const uint32_t tile_hi = tile_lo + q_tiles + (wave < r_tiles ? 1u : 0u);
   const uint32_t r0 = tile_lo * T;
   const uint32_t r1 = (uint32_t)min((unsigned long long)tile_hi * T, (unsigned long long)nb);
   uint32_t tile = tile_lo, n_local = 0;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   cm_next = wave * slots_per_wave;
   cm_end = cm_next + slots_per_wave;
   if (maps && wave == 0 && lane == 0)  // only waves that own tiles own slots; k_head's maps follow
-    a.counters->cmap_maps = ((a.n_tiles + per_wave - 1u) / max(per_wave, 1u)) * slots_per_wave;
+    a.counters->cmap_maps = min(n_waves, a.n_tiles) * slots_per_wave;
   auto map_slot = [&]() -> uint32_t {
     if (!maps || cm_next >= cm_end) return BVCF_NO_CMAP;  // (the bound above makes the second case unreachable)
     return cmap_of(a, cm_next, true);
