@@ -51,7 +51,7 @@ lib.bvcf_debug_phase_times.argtypes = [C.c_void_p, C.c_int]
 lib.bvcf_debug_phase_times(pb, 8 * 32768)
 ph = np.frombuffer(pb, dtype=np.uint64).reshape(8, 32768).astype(np.float64)[:, :nw]
 busy = d > 50
-names = ["7->0 loop top", "wait hv", "head parse + hvC issue", "map_slot+zero_stage", "chunk: realign..", "chunk: scan+reissue", "chunk: wait", "tail: any/stats/commit"]
+names = ["4->0 loop back-edge", "head parse + next head load", "map slot, separator, line constants", "10 chunks: scan + re-issue", "verdict, wave sums, commit", "-", "-", "-"]
 tot = ph[:, busy].mean(1).sum()
 for k in range(8):
     print("  %-26s %10.0f  %5.1f%%" % (names[k], ph[k, busy].mean(), 100 * ph[k, busy].mean() / tot))
