@@ -118,13 +118,18 @@ constexpr int kPipeChunks = 10;  // chunk registers of the cross-line pipeline: 
 __device__ unsigned long long g_wave_t[2][32768];
 __device__ unsigned long long g_phase_t[8][32768];
 __device__ unsigned int g_wave_hw[2][32768];
-// phase k = time from the previous stamp to STAMP(k)
+// phase k = time from the previous stamp to STAMP(k); -DBVCF_EXP_TIMES=2 keeps only the per-wave start/end (the stamps
+// cost registers, i.e. occupancy)
+#if BVCF_EXP_TIMES + 0 == 2
+#define STAMP(k)
+#else
 #define STAMP(k)                                                   \
   {                                                                \
     const unsigned long long now_ = __builtin_readcyclecounter();  \
     ph_[k] += now_ - last_;                                        \
     last_ = now_;                                                  \
   }
+#endif
 #else
 #define STAMP(k)
 #endif
@@ -160,7 +165,9 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   // stay per tile: the quota argument is about bytes, not about who scans them.
   // (Claiming smaller runs from a counter instead evens out the waves' finish times but costs more
   // than it returns: every run start is a chain of dependent loads.  The kernel is bound by VALU
-  // issue, not by the slowest wave.)
+  // issue, not by the slowest wave: a SIMD arbitrates by age, so with equal runs the waves of the three
+  // dispatch rounds finish at 161 / 196 / 216 us of a 240 us kernel, but runs weighted by those speeds
+  // changed nothing -- two waves keep a SIMD as busy as three.)
   // Balanced: the first n_tiles % n_waves waves walk one tile more than the others (a plain ceil() split left 5 %
   // of the waves without work on the benchmark's 20 332 tiles).
   const uint32_t q_tiles = a.n_tiles / n_waves, r_tiles = a.n_tiles % n_waves;
