@@ -17,6 +17,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -47,26 +48,43 @@ void append_g3(std::string &o, double x) {
   o.append(tmp, (size_t)n);
 }
 
+// sample names for the het / hom / missing lists: one contiguous arena of "name<delimiter>" entries, so that
+// joining is a run of short memcpys from one array (the header's std::strings live all over the heap)
 struct Names {
-  const char *const *ptr;
-  const uint32_t *len;
+  std::string arena;
+  std::vector<uint32_t> off;  // entry s is arena[off[s], off[s + 1]); the delimiter is its last n_delim bytes
+  size_t n_delim = 0;
+  Names(const char *const *ptr, const uint32_t *len, size_t n, const char *delim) {
+    n_delim = strlen(delim);
+    off.reserve(n + 1);
+    for (size_t s = 0; s < n; s++) {
+      off.push_back((uint32_t)arena.size());
+      arena.append(ptr[s], len[s]);
+      arena.append(delim, n_delim);
+    }
+    off.push_back((uint32_t)arena.size());
+  }
 };
 
 // strings.Join(names of samples with class `want`, fieldDelimiter); `sparse`: the map is a list of its non-zero
 // bytes (BVCF_ALLELE_CMAP_SPARSE)
-void join_class(std::string &o, const uint8_t *cmap, bool sparse, uint32_t ns, unsigned want, const Names &nm,
-                const char *delim, size_t ndelim) {
-  bool first = true;
+void join_class(std::string &o, const uint8_t *cmap, bool sparse, uint32_t ns, unsigned want, const Names &nm) {
+  const size_t at = o.size();
   auto emit = [&](uint32_t b, unsigned byte) {
     for (unsigned j = 0; j < 4; j++) {
       if (((byte >> (2 * j)) & 3u) != want) continue;
       const uint32_t s = b * 4 + j;
       if (s >= ns) break;
-      if (!first) o.append(delim, ndelim);
-      o.append(nm.ptr[s], nm.len[s]);
-      first = false;
+      o.append(nm.arena.data() + nm.off[s], nm.off[s + 1] - nm.off[s]);  // name + delimiter
     }
   };
+  struct Trim {  // the last entry's delimiter goes
+    std::string &o;
+    size_t at, n;
+    ~Trim() {
+      if (o.size() > at) o.resize(o.size() - n);
+    }
+  } trim{o, at, nm.n_delim};
   if (sparse) {
     uint32_t n;
     memcpy(&n, cmap, 4);
@@ -127,8 +145,6 @@ void append_err(std::string &log, const bvcf_err &e, const bvcf_line &L, const u
 void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm, uint32_t lo,
                   uint32_t hi, std::string &out) {
   const char *empty = or_default(c->empty_field, "!");
-  const char *delim = or_default(c->field_delimiter, ";");
-  const size_t ndelim = strlen(delim);
   const uint32_t ns = r->n_samples;
   const double num_samples = (double)ns;
   for (uint32_t li = lo; li < hi; li++) {
@@ -180,7 +196,7 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
           out.append(empty);
           out.append("\t0");
         } else {
-          join_class(out, cm, (A.flags & BVCF_ALLELE_CMAP_SPARSE) != 0, ns, lists[q].cls, nm, delim, ndelim);
+          join_class(out, cm, (A.flags & BVCF_ALLELE_CMAP_SPARSE) != 0, ns, lists[q].cls, nm);
           out.push_back('\t');
           append_g3(out, (double)lists[q].n / lists[q].denom);
         }
@@ -324,6 +340,7 @@ struct Run {
   std::vector<uint32_t> name_len;
   unsigned n_threads = 1;
   uint64_t max_batch = 0;
+  std::unique_ptr<Names> names; // built once the header is known
   bvcf_arrow *arrow = nullptr;  // --dosageOutput
   bool want_rows = true;        // !noOut
 };
@@ -405,6 +422,7 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_d
     R.name_ptr.push_back(R.pre.header[i].data());
     R.name_len.push_back((uint32_t)R.pre.header[i].size());
   }
+  R.names.reset(new Names(R.name_ptr.data(), R.name_len.data(), R.name_ptr.size(), or_default(R.cfg->field_delimiter, ";")));
   R.n_threads = R.cfg->n_format_threads ? R.cfg->n_format_threads
                                          : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   if (R.cfg->dosage_path && *R.cfg->dosage_path) {  // main.go:306-342
@@ -594,7 +612,7 @@ int bvcf_format_tsv(const bvcf_config *c, const bvcf_result *r, const uint8_t *b
   if (!c || !r || !out || !n_out) return BVCF_E_ARG;
   if (r->n_samples && (!sample_names || !sample_name_lens)) return BVCF_E_ARG;
   std::string o, l;
-  Names nm{sample_names, sample_name_lens};
+  Names nm(sample_names, sample_name_lens, r->n_samples, or_default(c->field_delimiter, ";"));
   const unsigned nt =
       c->n_format_threads ? c->n_format_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   format_batch(c, r, block, nm, nt, o, l);
@@ -622,7 +640,7 @@ int bvcf_run_buffer(const bvcf_config *c, const uint8_t *vcf, size_t n, char **o
   if (rc == BVCF_OK) {
     if (R.pre.header.size() == 9)  // main.go:507-509
       l.append("Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n");
-    Names nm{R.name_ptr.data(), R.name_len.data()};
+    const Names &nm = *R.names;
     size_t pos = R.pre.data_off;
     uint64_t seq = 0;
     while (pos < n) {
@@ -852,7 +870,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     lines_in += res.n_lines_seen;
     t0 = now_s();
     std::string *out = new std::string();
-    Names nm{R.name_ptr.data(), R.name_len.data()};
+    const Names &nm = *R.names;
     format_batch(c, &res, b.buf + b.start, nm, R.want_rows ? R.n_threads : 1, *out, log);
     if (!R.want_rows) out->clear();
     if (append_dosage(R, &res, b.buf + b.start)) fail("dosage matrix: write failed", BVCF_E_FATAL);
