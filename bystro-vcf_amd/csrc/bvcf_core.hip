@@ -647,6 +647,9 @@ int bvcf_bench_device(bvcf_ctx *c, const void *const *dblocks, const size_t *nby
 }  // extern "C"
 
 #ifdef BVCF_EXP_TIMES
+extern "C" int bvcf_debug_head_times(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bvcf_dev::g_head_t), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
 extern "C" int bvcf_debug_phase_times(unsigned long long *out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bvcf_dev::g_phase_t), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
 }

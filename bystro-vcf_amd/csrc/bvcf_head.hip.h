@@ -18,22 +18,26 @@ constexpr uint32_t kHeadStage = 128;             // line-head bytes kept in LDS 
 
 __device__ __forceinline__ int glane() { return threadIdx.x & (kGroup - 1); }
 
+// A 16-lane group is one DPP row: scans and sums stay in the VALU (row shifts / rotations) instead of going
+// through the LDS crossbar five times per call (__shfl_up x 4 + __shfl), which was most of phase T's time.
+// sum of the row, in every lane of the row
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);  // row_ror:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false);  // row_ror:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);  // row_ror:1
+  return v;
+}
+
 // exclusive prefix sum inside a 16-lane group; *total = group sum
 __device__ __forceinline__ uint32_t group_excl_scan(uint32_t v, uint32_t *total) {
   uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < kGroup; d <<= 1) {
-    uint32_t t = __shfl_up(inc, d, kGroup);
-    if (glane() >= d) inc += t;
-  }
-  *total = __shfl(inc, kGroup - 1, kGroup);
+  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);  // row_shr:1, zero fill
+  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
+  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
+  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
+  *total = group_sum(v);
   return inc - v;
-}
-
-__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
-#pragma unroll
-  for (int d = kGroup / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, kGroup);
-  return v;
 }
 
 __device__ __forceinline__ uint32_t gbcast0(uint32_t v) { return __shfl(v, 0, kGroup); }
@@ -109,7 +113,21 @@ constexpr uint32_t kLinesPerStep = kWgThreads;
 constexpr uint32_t kHeadRow = kHeadStage / 4 + 1;  // dwords per staged line; odd => conflict-free columns
 constexpr uint32_t kTabRow = 11;                   // 9 TAB offsets + pad, odd stride
 
+#ifdef BVCF_EXP_TIMES
+__device__ unsigned long long g_head_t[6][8192];
+#define HSTAMP(k)                                                  \
+  {                                                                \
+    const unsigned long long now_ = __builtin_readcyclecounter();  \
+    hph_[k] += now_ - hlast_;                                      \
+    hlast_ = now_;                                                 \
+  }
+#else
+#define HSTAMP(k)
+#endif
 __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
+#ifdef BVCF_EXP_TIMES
+  unsigned long long hph_[6] = {0, 0, 0, 0, 0, 0}, hlast_ = __builtin_readcyclecounter();
+#endif
   __shared__ uint32_t s_head[kLinesPerStep * kHeadRow];
   __shared__ uint32_t s_tab[kLinesPerStep * kTabRow];
   __shared__ uint32_t s_ls[kLinesPerStep], s_len[kLinesPerStep], s_found[kLinesPerStep], s_staged[kLinesPerStep],
@@ -134,6 +152,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
 
   for (uint32_t line0 = blockIdx.x * kLinesPerStep; line0 < n_lines; line0 += stride) {
     __syncthreads();  // LDS of the previous step is free (also covers the s_ft copy)
+    HSTAMP(0);
 
     // ================= phase T: 16 lanes per line =================
     // lane gl of a group fetches the offsets of the group's round-gl line, so the 16 rounds' offsets
@@ -217,6 +236,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
     }
     __syncthreads();
 
+    HSTAMP(1);
     // ================= phase S: one lane per line =================
     const uint32_t ll = threadIdx.x;
     const uint32_t line = line0 + ll;
@@ -297,6 +317,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       bound = mode == 1 ? 1u : (mode == 2 ? b2 : 0u);
     }
 
+    HSTAMP(2);
     // ---- slot reservation, once per workgroup step: record slot `line` and task slot `line` are
     // the line's own; only further records / ALT indices draw from the batch counters.  Biallelic
     // lines — all of a 1KG-shaped file — never touch an atomic.
@@ -332,6 +353,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
     task_base = n_lines + s_base[1] + task_rank;
     const uint32_t map_base = a.fused ? s_base[2] + task_rank : task_base;
 
+    HSTAMP(3);
     // ---- part 2: evaluate the ALT tokens, write records and scan tasks
     if (eval) {
       if (mode == 0) log_err(a, line, 0, BVCF_ERR_SAME);
@@ -431,6 +453,7 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       if (ns == 0) n_fields = a.n_header;
     }
 
+    HSTAMP(4);
     // ---- line record
     if (active) {
       bvcf_line L;
@@ -451,7 +474,12 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
       if (ns > 0 && !task_written && !a.fused) put_task(a, line, line, 0, cend, cend, BVCF_NO_CMAP);
       if (!primary_written && line < a.max_alleles) a.alleles[line].gt_task = kNoTask;
     }
+    HSTAMP(5);
   }
+#ifdef BVCF_EXP_TIMES
+  if (threadIdx.x == 0 && blockIdx.x < 8192)
+    for (int k = 0; k < 6; k++) g_head_t[k][blockIdx.x] = hph_[k];
+#endif
 }
 
 // ------------------------------------------------------------------ k_finish

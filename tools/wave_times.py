@@ -72,3 +72,14 @@ share = dict(zip(u2, cnt2))
 per = np.array([share[k] for k in ks])
 for c in np.unique(per):
     print("    waves on a SIMD with %d waves: mean dur %.1f us (n=%d)" % (c, d[per == c].mean(), (per == c).sum()))
+print("--- k_head phases per workgroup (s_memtime ticks, mean over workgroups with work)")
+hbuf = (C.c_ulonglong * (6 * 8192))()
+lib.bvcf_debug_head_times.argtypes = [C.c_void_p, C.c_int]
+lib.bvcf_debug_head_times(hbuf, 6 * 8192)
+hp = np.frombuffer(hbuf, dtype=np.uint64).reshape(6, 8192).astype(np.float64)
+busy_h = hp[1] > 0
+hn = ["loop top / barrier", "phase T: tokenise 16 rounds", "phase S part 1: gate, ALT shape", "slot reservation", "part 2: alleles, records, tasks", "line record"]
+tot_h = hp[:, busy_h].mean(1).sum()
+for k in range(6):
+    print("  %-36s %10.0f  %5.1f%%" % (hn[k], hp[k, busy_h].mean(), 100 * hp[k, busy_h].mean() / tot_h))
+print("  workgroups with work: %d; sum %.0f ticks = %.1f us at 2.28 ticks/ns" % (busy_h.sum(), tot_h, tot_h / 2280))
