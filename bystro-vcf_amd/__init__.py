@@ -40,7 +40,7 @@ CLS_NONE, CLS_HET, CLS_HOM, CLS_MISSING = 0, 1, 2, 3
 # every symbol include/bvcf.h declares
 EXPORTS = [
     "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_alloc_pinned",
-    "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_bench_device", "bvcf_counters",
+    "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_bench_device", "bvcf_bench_device_slots", "bvcf_counters",
     "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_free",
     "bvcf_arrow_open", "bvcf_arrow_append", "bvcf_arrow_close",
 ]
@@ -105,6 +105,8 @@ lib.bvcf_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint6
 lib.bvcf_collect.argtypes = [C.c_void_p, C.POINTER(Result)]
 lib.bvcf_bench_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
                                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+lib.bvcf_bench_device_slots.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
+                                        C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
 lib.bvcf_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 lib.bvcf_path.argtypes = [C.c_void_p]
 lib.bvcf_config_defaults.argtypes = [C.POINTER(Config)]
@@ -308,16 +310,17 @@ class Ctx:
         self.submit(block)
         return self.collect()
 
-    def bench_device(self, dptrs, nbytes, iters):
-        """kernel chain `iters` times over resident blocks (rotating); results stay on the device.
-        -> (chain ms per step, genotype-scan ms per step, [lines, alleles, errs, cmap bytes, tasks])"""
+    def bench_device(self, dptrs, nbytes, iters, slots=0):
+        """kernel chain `iters` times over resident blocks (rotating); results stay on the device.  Batch i runs on
+        slot i % slots (0 = all of the ctx's slots; 1 = strictly one batch after the other).
+        -> (chain ms per batch, genotype-scan ms per batch, [lines, alleles, errs, cmap bytes, tasks])"""
         n = len(dptrs)
         ptrs = (C.c_void_p * n)(*dptrs)
         sizes = (C.c_size_t * n)(*nbytes)
         chain = (C.c_float * iters)()
         scan = (C.c_float * iters)()
         counts = (C.c_uint64 * 5)()
-        self._check(lib.bvcf_bench_device(self.h, ptrs, sizes, n, iters, chain, scan, counts))
+        self._check(lib.bvcf_bench_device_slots(self.h, ptrs, sizes, n, iters, slots, chain, scan, counts))
         return list(chain), list(scan), list(counts)
 
     def path(self):

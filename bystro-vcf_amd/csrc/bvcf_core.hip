@@ -594,6 +594,11 @@ int bvcf_counters(bvcf_ctx *c, uint64_t out[8]) {
 
 int bvcf_bench_device(bvcf_ctx *c, const void *const *dblocks, const size_t *nbytes, int n_blocks, int iters,
                       float *chain_ms, float *gt_ms, uint64_t counts[5]) {
+  return bvcf_bench_device_slots(c, dblocks, nbytes, n_blocks, iters, 0, chain_ms, gt_ms, counts);
+}
+
+int bvcf_bench_device_slots(bvcf_ctx *c, const void *const *dblocks, const size_t *nbytes, int n_blocks, int iters,
+                            uint32_t slots_in_use, float *chain_ms, float *gt_ms, uint64_t counts[5]) {
   if (!c || !dblocks || !nbytes || n_blocks < 1 || iters < 1) return BVCF_E_ARG;
   if (c->in_flight) {
     c->err = "bvcf_bench_device with batches in flight";
@@ -602,20 +607,26 @@ int bvcf_bench_device(bvcf_ctx *c, const void *const *dblocks, const size_t *nby
   for (int b = 0; b < n_blocks; b++)
     if (!dblocks[b] || nbytes[b] > c->p.max_batch_bytes || nbytes[b] >= 0xFFFFFF00ull) return BVCF_E_TOO_BIG;
   HIP_TRY(c, hipSetDevice(c->device));
-  Slot &s = c->slots[0];
-  int rc = alloc_results(c, s);
-  if (rc) return rc;
+  // Batch i runs on slot i % n_use, each slot on its own stream, exactly as bvcf_submit deals them: with two
+  // slots the short latency-bound kernels that end one batch's chain overlap the next batch's scan.
+  const size_t n_use = slots_in_use ? std::min<size_t>(slots_in_use, c->slots.size()) : c->slots.size();
+  for (size_t k = 0; k < n_use; k++) {
+    int rc = alloc_results(c, c->slots[k]);
+    if (rc) return rc;
+  }
+  Slot &s = c->slots[(size_t)(iters - 1) % n_use];  // the slot whose counters are reported
   std::vector<hipEvent_t> ev((size_t)iters * 4);
   for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
   for (int i = 0; i < iters; i++) {
-    KernelArgs a = make_args(c, s, (const uint8_t *)dblocks[i % n_blocks], nbytes[i % n_blocks]);
-    HIP_TRY(c, hipEventRecord(ev[4 * i], s.stream));
-    launch_chain(c, a, s.stream, ev[4 * i + 1], ev[4 * i + 2]);
-    HIP_TRY(c, hipEventRecord(ev[4 * i + 3], s.stream));
+    Slot &si = c->slots[(size_t)i % n_use];
+    KernelArgs a = make_args(c, si, (const uint8_t *)dblocks[i % n_blocks], nbytes[i % n_blocks]);
+    HIP_TRY(c, hipEventRecord(ev[4 * i], si.stream));
+    launch_chain(c, a, si.stream, ev[4 * i + 1], ev[4 * i + 2]);
+    HIP_TRY(c, hipEventRecord(ev[4 * i + 3], si.stream));
   }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(s.h_counters, s.d_counters, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.stream));
-  HIP_TRY(c, hipStreamSynchronize(s.stream));
+  for (size_t k = 0; k < n_use; k++) HIP_TRY(c, hipStreamSynchronize(c->slots[k].stream));
   for (int i = 0; i < iters; i++) {
     float t0 = 0, t1 = 0;
     hipEventElapsedTime(&t0, ev[4 * i], ev[4 * i + 3]);

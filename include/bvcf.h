@@ -225,6 +225,10 @@ int bvcf_path(const bvcf_ctx *ctx);
 
 int bvcf_bench_device(bvcf_ctx *ctx, const void *const *dblocks, const size_t *nbytes, int n_blocks, int iters,
                       float *chain_ms, float *gt_ms, uint64_t counts[5]);
+/* the same with batch i on slot i % slots_in_use (0 = every slot of the ctx, which is what bvcf_bench_device does):
+ * 1 times the chains strictly one after the other, 2 lets consecutive batches overlap as bvcf_submit would */
+int bvcf_bench_device_slots(bvcf_ctx *ctx, const void *const *device_blocks, const size_t *nbytes, int n_blocks, int iters,
+                            uint32_t slots_in_use, float *chain_ms, float *scan_ms, uint64_t counts[5]);
 
 /* running totals since bvcf_create: {lines_in, lines_ok, alleles_out, alleles_ac0, errs,
  * bytes_in, cmap_bytes, kernel_ns} */

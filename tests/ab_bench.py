@@ -21,7 +21,7 @@ for r in range(rounds):
     for l in libs:
         env = dict(os.environ, BVCF_LIB=os.path.abspath(l))
         out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2",
-                                       "--no-cpu-baseline"] + extra, env=env, stderr=subprocess.DEVNULL)
+                                       "--no-cpu-baseline", "--slots", "1"] + extra, env=env, stderr=subprocess.DEVNULL)
         d = json.loads(out.decode().strip().splitlines()[-1])
         res[l].append((d["roofline"]["mean_launch_ms"], d["chain"]["mean_ms"]))
 for l in libs:
