@@ -513,7 +513,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   const bool maps = c->p.want_class_maps && c->n_samples;
   const uint64_t cmap_bytes = !maps ? 0 : (c->fused ? (uint64_t)ctr.cmap_maps : n_tasks) * c->cmap_stride;
   if (ctr.pad[0]) {
-    c->err = "internal error: streaming tile quota exceeded";
+    c->err = "internal error: streaming tile quota or class-map slot range exceeded";
     release();
     return BVCF_E_HIP;
   }

@@ -197,7 +197,11 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   if (maps && wave == 0 && lane == 0)  // only waves that own tiles own slots; k_head's maps follow
     a.counters->cmap_maps = min(n_waves, a.n_tiles) * slots_per_wave;
   auto map_slot = [&]() -> uint32_t {
-    if (!maps || cm_next >= cm_end) return BVCF_NO_CMAP;  // (the bound above makes the second case unreachable)
+    if (!maps) return BVCF_NO_CMAP;
+    if (cm_next >= cm_end) {  // unreachable by the bound above; never hand out a silent "no map"
+      if (lane == 0) a.counters->pad[0] = 1;
+      return BVCF_NO_CMAP;
+    }
     return cmap_of(a, cm_next, true);
   };
   // list a line (in input order) in the tile it starts in
