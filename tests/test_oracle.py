@@ -100,3 +100,15 @@ def test_threads_preserve_input_order(golden_1kg):
     a = orc.run(vcf, n_threads=1)[1]
     b = orc.run(vcf, n_threads=8)[1]
     assert a == b
+
+
+def test_dosage_rows_reference_table():
+    """TestGenotypeMatrix, main_test.go:2911-2977: the rows the reference hands to its Arrow writer"""
+    hdr = "##fileformat=VCFv4.x\n" + "\t".join(["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT",
+                                                "S1", "S2", "S3"]) + "\n"
+    rows = [["1", "1000", "rs1", "A", "T", ".", "PASS", "DP=100", "GT", "1|1", "0|1", "0|0"],
+            ["2", "200", "rs2", "C", "G", ".", "PASS", "DP=100", "GT", "0|1", "0|0", "1|1"],
+            ["22", "300", "rs2", "G", "T", ".", "PASS", "DP=100", "GT", "0|.", "0|.", "1|1"]]
+    vcf = (hdr + "".join("\t".join(r) + "\n" for r in rows)).encode()
+    assert orc.run_dosage(vcf) == [("chr1:1000:A:T", [2, 1, 0]), ("chr2:200:C:G", [1, 0, 2]),
+                                   ("chr22:300:G:T", [-1, -1, 2])]
