@@ -60,7 +60,9 @@ struct GtTask {
 struct GtResult {
   uint32_t ac, an, n_het, n_hom, n_miss;
   uint32_t n_fields;     // sample fields present on the line
-  uint32_t pad[2];
+  uint32_t regular;      // 1: every sample field was "x<sep>y" with single-digit alleles (the fast scan), so the dosage
+                         // of a sample is its class (none 0, het 1, hom 2, missing -1)
+  uint32_t pad;
 };
 
 struct KernelArgs {

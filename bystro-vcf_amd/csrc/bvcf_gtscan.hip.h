@@ -440,8 +440,10 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
     GtStats st = {0, 0, 0, 0, 0};
     uint32_t n_fields;
     // regular region: 4 bytes per sample, every dword of a lane is one "x|y<TAB>" field
+    bool regular = false;
     if (t.cend + 1u - t.s_begin == 4u * ns && gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, false, &st)) {
       n_fields = ns;
+      regular = true;
     } else {
       uint32_t tabs;
       gt_scan_general(a, t.s_begin, t.cend, ns, t.allele, cm, &st, &tabs);
@@ -455,7 +457,8 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
       r.n_hom = st.n_hom;
       r.n_miss = st.n_miss;
       r.n_fields = n_fields;
-      r.pad[0] = r.pad[1] = 0;
+      r.regular = regular ? 1u : 0u;
+      r.pad = 0;
       a.results[ti] = r;
     }
   }
@@ -476,10 +479,33 @@ __global__ __launch_bounds__(kWgThreads) void k_dosage(KernelArgs a) {
     if (L.status != BVCF_LINE_OK || L.n_rec == 0) continue;
     // slot k belongs to line li if it is the line's own slot or one of its further alleles
     if (k >= n_lines && (k < L.rec_first || k - L.rec_first + 1u >= L.n_rec)) continue;
+    int8_t *row = a.dosage + (size_t)k * a.dosage_stride;
+    const int lane = lane_id();
+    if (r.cmap_off != BVCF_NO_CMAP && r.gt_task < a.max_tasks && a.results[r.gt_task].regular) {
+      // the scan that produced this allele's class map was the regular one: the row is the map, 2 bits -> int8
+      const uint8_t *cm = a.cmap + r.cmap_off;
+      const uint32_t n_bytes = (a.n_samples + 3u) / 4u;
+      auto expand = [](uint32_t byte) -> uint32_t {  // codes 0 1 2 3 -> bytes 0x00 0x01 0x02 0xFF
+        const uint32_t e = (byte | (byte << 6) | (byte << 12) | (byte << 18)) & 0x03030303u;
+        const uint32_t miss = (e & (e >> 1)) & 0x01010101u;
+        return e | (miss * 0xFCu);
+      };
+      if (r.flags & BVCF_ALLELE_CMAP_SPARSE) {
+        for (uint32_t i = lane; i < n_bytes; i += kWave) reinterpret_cast<uint32_t *>(row)[i] = 0u;
+        __builtin_amdgcn_s_waitcnt(0);  // the zeros land before the few entries below overwrite them
+        const uint32_t n = min(reinterpret_cast<const uint32_t *>(cm)[0], (uint32_t)BVCF_CMAP_SPARSE_MAX);
+        if ((uint32_t)lane < n) {
+          const uint32_t e = reinterpret_cast<const uint32_t *>(cm)[1 + lane];
+          if ((e >> 8) < n_bytes) reinterpret_cast<uint32_t *>(row)[e >> 8] = expand(e & 0xFFu);
+        }
+      } else {
+        for (uint32_t i = lane; i < n_bytes; i += kWave) reinterpret_cast<uint32_t *>(row)[i] = expand(cm[i]);
+      }
+      continue;
+    }
     GtStats st;
     uint32_t tabs;
-    gt_scan_general(a, L.off + L.fend[8] + 1u, L.off + L.len, a.n_samples, r.alt_idx + 1u, nullptr, &st, &tabs,
-                    a.dosage + (size_t)k * a.dosage_stride);
+    gt_scan_general(a, L.off + L.fend[8] + 1u, L.off + L.len, a.n_samples, r.alt_idx + 1u, nullptr, &st, &tabs, row);
   }
 }
 

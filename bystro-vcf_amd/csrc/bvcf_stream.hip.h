@@ -449,7 +449,8 @@ __global__ __launch_bounds__(kWgThreads) void k_order(KernelArgs a) {
       r.n_hom = en.n_hom;
       r.n_miss = en.n_miss;
       r.n_fields = en.n_miss == kDeferred ? kDeferred : a.n_header - 9u;
-      r.pad[0] = r.pad[1] = 0;
+      r.regular = en.n_miss == kDeferred ? 0u : 1u;  // k_stream only lists counts of lines its regular scan accepted
+      r.pad = 0;
       a.results[g] = r;
     }
   }

@@ -262,6 +262,8 @@ def _device_dosage_rows(bv, vcf, allow=""):
 @pytest.mark.parametrize("seed,n_lines,n_samples,fmt_extra,weird", [
     (31, 200, 3, False, 0.1), (32, 150, 70, False, 0.05), (33, 100, 300, True, 0.03), (34, 40, 2504, False, 0.002),
     (35, 60, 257, True, 0.2), (36, 100, 1, False, 0.3),
+    # all-regular files: every row comes from the class map (sparse list or 2-bit map), not from a second scan
+    (37, 60, 2504, False, 0.0), (38, 80, 300, False, 0.0),
 ])
 def test_dosage_rows_match_oracle(bv, seed, n_lines, n_samples, fmt_extra, weird):
     """bvcf_params.want_dosage: altCount per sample, -1 when missing (main.go:1069-1178), any ploidy"""
