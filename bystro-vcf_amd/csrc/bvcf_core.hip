@@ -265,7 +265,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, a.n_tiles);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
     hipLaunchKernelGGL(k_order, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
-    hipLaunchKernelGGL(k_head, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
+    hipLaunchKernelGGL(k_head_lean, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
     hipLaunchKernelGGL(k_gt, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
     if (a.dosage) hipLaunchKernelGGL(k_dosage, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
@@ -417,9 +417,13 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream, kWgThreads, 0) != hipSuccess || per_cu < 1)
     per_cu = 3;
+  // Two waves per SIMD run the scan as fast as three (it is bound by VALU issue).  With more than one batch in
+  // flight the third wave's registers are better spent on the previous batch's k_head_lean / k_gt / k_finish, which
+  // then run beside this kernel instead of waiting for its workgroups to finish (+7 % on the two-slot benchmark).
+  if (c->p.n_slots > 1 && per_cu > 2) per_cu = 2;
   if (const char *e = getenv("BVCF_STREAM_WGS")) {  // experiment: workgroups per CU, up to the occupancy limit
     const int w = atoi(e);
-    if (w >= 1 && w <= per_cu) per_cu = w;
+    if (w >= 1 && w <= 4) per_cu = w;
   }
   c->stream_grid = c->n_cu * per_cu;
   // the streaming kernel gives every wave its own range of class-map slots (two of them slack): room for that

@@ -124,7 +124,8 @@ __device__ unsigned long long g_head_t[6][8192];
 #else
 #define HSTAMP(k)
 #endif
-__global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
+template <bool kAllWindows>
+__device__ __forceinline__ void k_head_body(const KernelArgs &a) {
 #ifdef BVCF_EXP_TIMES
   unsigned long long hph_[6] = {0, 0, 0, 0, 0, 0}, hlast_ = __builtin_readcyclecounter();
 #endif
@@ -170,26 +171,27 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
         }
       }
     }
-    // The first 256 B window of all 16 rounds is requested up front, unconditionally (lines past the end
-    // read offset 0): the rounds are then paced by the parse, not by one memory latency each.  The LDS the
-    // workgroup stages the heads in already limits a CU to two workgroups, so the 64 registers are free.
+    // kAllWindows (census path): the first 256 B window of all 16 rounds is requested up front, unconditionally
+    // (lines past the end read offset 0), so the rounds are paced by the parse, not by one memory latency each;
+    // costs 64 registers.  Otherwise (streaming path) one window ahead: at 142 registers a wave of this kernel
+    // fits on a SIMD beside two waves of the next batch's k_stream instead of waiting for them to finish.
     constexpr uint32_t kRounds = kLinesPerStep / kGroupsPerWg;
-    u32x4 v_win[kRounds];
-    uint32_t r_ls[kRounds], r_len[kRounds];
+    u32x4 v_win[kAllWindows ? kRounds : 1u];
+    uint32_t r_ls[kAllWindows ? kRounds : 1u], r_len[kAllWindows ? kRounds : 1u];
+    if (kAllWindows) {
 #pragma unroll
-    for (uint32_t r = 0; r < kRounds; r++) {
-      r_ls[r] = __shfl(my_ls, r, kGroup);
-      r_len[r] = __shfl(my_len, r, kGroup);
-      v_win[r] = *reinterpret_cast<const u32x4_u *>(a.buf + min(r_ls[r] + 16u * gl, a.cap - 16u));
+      for (uint32_t r = 0; r < kRounds; r++) {
+        r_ls[r] = __shfl(my_ls, r, kGroup);
+        r_len[r] = __shfl(my_len, r, kGroup);
+        v_win[r] = *reinterpret_cast<const u32x4_u *>(a.buf + min(r_ls[r] + 16u * gl, a.cap - 16u));
+      }
+    } else {
+      v_win[0] = load16(a.buf, __shfl(my_ls, 0, kGroup) + 16u * gl, a.cap);
     }
-#pragma unroll
-    for (uint32_t r = 0; r < kRounds; r++) {
+    auto tokenise = [&](uint32_t r, uint32_t ls, uint32_t len, const u32x4 &v_first) {
       const uint32_t ll = r * kGroupsPerWg + g;
       const uint32_t line = line0 + ll;
-      const uint32_t ls = r_ls[r];
-      const uint32_t len = r_len[r];
-      const u32x4 v_first = v_win[r];
-      if (line >= n_lines) continue;
+      if (line >= n_lines) return;
       const uint32_t cend = ls + len;
       uint32_t found = 0, base = ls;
       // strings.Split(row, "\t") for the fixed columns, main.go:535
@@ -232,6 +234,17 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
         s_found[ll] = found;
         s_staged[ll] = staged;
         s_extra[ll] = extra;
+      }
+    };
+    if (kAllWindows) {
+#pragma unroll
+      for (uint32_t r = 0; r < kRounds; r++) tokenise(r, r_ls[kAllWindows ? r : 0], r_len[kAllWindows ? r : 0], v_win[kAllWindows ? r : 0]);
+    } else {
+#pragma nounroll
+      for (uint32_t r = 0; r < kRounds; r++) {
+        const u32x4 v_first = v_win[0];
+        if (r + 1 < kRounds) v_win[0] = load16(a.buf, __shfl(my_ls, r + 1, kGroup) + 16u * gl, a.cap);
+        tokenise(r, __shfl(my_ls, r, kGroup), __shfl(my_len, r, kGroup), v_first);
       }
     }
     __syncthreads();
@@ -481,6 +494,10 @@ __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) {
     for (int k = 0; k < 6; k++) g_head_t[k][blockIdx.x] = hph_[k];
 #endif
 }
+
+__global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) { k_head_body<true>(a); }
+// the same at 142 registers, for chains that overlap with another batch's k_stream (see kAllWindows)
+__global__ __launch_bounds__(kWgThreads) void k_head_lean(KernelArgs a) { k_head_body<false>(a); }
 
 // ------------------------------------------------------------------ k_finish
 
