@@ -3,6 +3,7 @@
 
 #include <errno.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -118,6 +119,45 @@ ssize_t ByteSource::read_text(uint8_t *dst, size_t cap) {
       cpos_ = 0;
     }
     return (ssize_t)n;
+  }
+  // a regular file: a few threads pread() disjoint parts of the request (one thread copies out of the page cache
+  // at about 10 GB/s, which is what the CLI waited for once the device and the formatter were done)
+  if (cap >= (8u << 20)) {
+    struct stat st;
+    const off_t at = lseek(fd_, 0, SEEK_CUR);
+    if (at >= 0 && fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > at) {
+      const size_t want = (size_t)std::min<off_t>((off_t)cap, st.st_size - at);
+      const unsigned n_thr = std::max(1u, std::min({8u, n_threads_ ? n_threads_ : 8u, (unsigned)(want >> 22)}));
+      std::vector<size_t> got_n(n_thr, 0);
+      std::vector<int> err_n(n_thr, 0);
+      auto part = [&](unsigned t) {
+        const size_t lo = want * t / n_thr, hi = want * (t + 1) / n_thr;
+        size_t done = 0;
+        while (lo + done < hi) {
+          const ssize_t g = pread(fd_, dst + lo + done, hi - lo - done, at + (off_t)(lo + done));
+          if (g < 0 && errno == EINTR) continue;
+          if (g < 0) err_n[t] = errno;
+          if (g <= 0) break;  // error, or the file got shorter
+          done += (size_t)g;
+        }
+        got_n[t] = done;
+      };
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < n_thr; t++) th.emplace_back(part, t);
+      part(0);
+      for (auto &x : th) x.join();
+      size_t total = 0;
+      for (unsigned t = 0; t < n_thr; t++) {
+        if (err_n[t]) {
+          err_ = std::string("read: ") + strerror(err_n[t]);
+          return -1;
+        }
+        total += got_n[t];
+        if (got_n[t] != want * (t + 1) / n_thr - want * t / n_thr) break;  // short part: what follows it is not contiguous
+      }
+      lseek(fd_, at + (off_t)total, SEEK_SET);
+      return (ssize_t)total;
+    }
   }
   for (;;) {
     ssize_t got = ::read(fd_, dst, cap);
