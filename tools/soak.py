@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Randomised differential soak (not part of the test suite): many random VCF shapes through the HIP path and the
+oracle, both device paths, TSV + log + dosage rows compared.  usage: python tools/soak.py [n_cases] [seed0]"""
+import os
+import random
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bystro_vcf_amd as bv  # noqa: E402
+import oracle_lib as orc  # noqa: E402
+import vcfgen  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad = 0
+for i in range(n_cases):
+    rng = random.Random(seed0 + i)
+    ns = rng.choice([0, 1, 3, 17, 63, 64, 65, 255, 256, 257, 300, 511, 512, 700, 1023, 1024, 1500, 2047, 2048, 2504,
+                     2559, 2560, 2561, 3000, rng.randint(1, 3500)])
+    n_lines = rng.randint(20, 160 if ns > 1000 else 400)
+    weird = rng.choice([0.0, 0.0, 0.001, 0.01, 0.05, 0.3])
+    fmt_extra = rng.random() < 0.25
+    vcf = vcfgen.gen_vcf(seed0 + i, n_lines, ns, fmt_extra, weird)
+    cfg = rng.choice([{"allow": ""}, {}, {"keepId": True, "keepInfo": True, "keepPos": True, "exclude": "q10"}])
+    rc_o, out_o, log_o, n_o = orc.run(vcf, cfg)
+    want_dos = orc.run_dosage(vcf, cfg) if ns else []
+    for path in ("1", "2"):
+        os.environ["BVCF_PATH"] = path
+        with tempfile.TemporaryDirectory() as td:
+            c = dict(cfg)
+            if ns:
+                c["dosageOutput"] = os.path.join(td, "d.arrow")
+            rc_g, out_g, log_g, n_g = bv.run_buffer(vcf, c, max_batch_bytes=rng.choice([0, 1 << 20, 1 << 22]))
+            ok = (rc_g != 0) == (rc_o != 0) and out_g == out_o and log_g == log_o and n_g == n_o
+            if ok and ns and rc_g == 0:
+                import pyarrow.ipc as ipc
+                t = ipc.open_file(c["dosageOutput"]).read_all()
+                cols = [t.column(k).to_pylist() for k in range(1, t.num_columns)]
+                got = [(loc, [col[r] for col in cols]) for r, loc in enumerate(t.column(0).to_pylist())]
+                ok = got == want_dos
+        if not ok:
+            bad += 1
+            print("MISMATCH case %d seed %d path %s ns %d lines %d weird %g fmt_extra %s cfg %s" % (
+                i, seed0 + i, path, ns, n_lines, weird, fmt_extra, cfg), flush=True)
+    if i % 20 == 19:
+        print("%d cases done, %d mismatches" % (i + 1, bad), flush=True)
+print("soak: %d cases x 2 paths, %d mismatches" % (n_cases, bad))
+sys.exit(1 if bad else 0)
