@@ -40,7 +40,7 @@ CLS_NONE, CLS_HET, CLS_HOM, CLS_MISSING = 0, 1, 2, 3
 # every symbol include/bvcf.h declares
 EXPORTS = [
     "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_alloc_pinned",
-    "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_bench_device", "bvcf_bench_device_slots", "bvcf_counters",
+    "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_bench_device", "bvcf_bench_device_slots", "bvcf_counters", "bvcf_sum_counters",
     "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_free",
     "bvcf_arrow_open", "bvcf_arrow_append", "bvcf_arrow_close",
 ]

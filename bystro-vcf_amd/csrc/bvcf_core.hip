@@ -596,6 +596,16 @@ int bvcf_counters(bvcf_ctx *c, uint64_t out[8]) {
   return BVCF_OK;
 }
 
+int bvcf_sum_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8]) {
+  if (!ctxs || n < 0 || !out) return BVCF_E_ARG;
+  for (int k = 0; k < 8; k++) out[k] = 0;
+  for (int i = 0; i < n; i++) {
+    if (!ctxs[i]) return BVCF_E_ARG;
+    for (int k = 0; k < 8; k++) out[k] += ctxs[i]->totals[k];
+  }
+  return BVCF_OK;
+}
+
 int bvcf_bench_device(bvcf_ctx *c, const void *const *dblocks, const size_t *nbytes, int n_blocks, int iters,
                       float *chain_ms, float *gt_ms, uint64_t counts[5]) {
   return bvcf_bench_device_slots(c, dblocks, nbytes, n_blocks, iters, 0, chain_ms, gt_ms, counts);

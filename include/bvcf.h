@@ -233,6 +233,10 @@ int bvcf_bench_device_slots(bvcf_ctx *ctx, const void *const *device_blocks, con
 /* running totals since bvcf_create: {lines_in, lines_ok, alleles_out, alleles_ac0, errs,
  * bytes_in, cmap_bytes, kernel_ns} */
 int bvcf_counters(bvcf_ctx *ctx, uint64_t out[8]);
+/* the run summary over several ctxs (one per GPU) driven by one process: element-wise sum of their counters.  The
+ * totals live on the host, so this is a host-side sum; one-process-per-GPU deployments gather them with one
+ * RCCL all-reduce instead (bench.py does, through torch.distributed) -- the only collective the path has. */
+int bvcf_sum_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8]);
 
 /* ---- host side of the path: header, TSV assembly, whole-stream driver ---- */
 
