@@ -23,7 +23,8 @@ for i in range(n_cases):
     n_lines = rng.randint(20, 160 if ns > 1000 else 400)
     weird = rng.choice([0.0, 0.0, 0.001, 0.01, 0.05, 0.3])
     fmt_extra = rng.random() < 0.25
-    vcf = vcfgen.gen_vcf(seed0 + i, n_lines, ns, fmt_extra, weird)
+    eol = "\r\n" if rng.random() < float(os.environ.get("SOAK_CRLF", "0.1")) else "\n"
+    vcf = vcfgen.gen_vcf(seed0 + i, n_lines, ns, fmt_extra, weird, eol)
     cfg = rng.choice([{"allow": ""}, {}, {"keepId": True, "keepInfo": True, "keepPos": True, "exclude": "q10"}])
     rc_o, out_o, log_o, n_o = orc.run(vcf, cfg)
     want_dos = orc.run_dosage(vcf, cfg) if ns else []
@@ -43,8 +44,8 @@ for i in range(n_cases):
                 ok = got == want_dos
         if not ok:
             bad += 1
-            print("MISMATCH case %d seed %d path %s ns %d lines %d weird %g fmt_extra %s cfg %s" % (
-                i, seed0 + i, path, ns, n_lines, weird, fmt_extra, cfg), flush=True)
+            print("MISMATCH case %d seed %d path %s ns %d lines %d weird %g fmt_extra %s eol %r cfg %s" % (
+                i, seed0 + i, path, ns, n_lines, weird, fmt_extra, eol, cfg), flush=True)
     if i % 20 == 19:
         print("%d cases done, %d mismatches" % (i + 1, bad), flush=True)
 print("soak: %d cases x 2 paths, %d mismatches" % (n_cases, bad))
