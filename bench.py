@@ -224,6 +224,9 @@ def main():
                 # timed region the end of the previous batch's chain shares the GPU with it
                 "mean_launch_ms_one_batch_at_a_time": alone_ms,
                 "frac_one_batch_at_a_time": (gt_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if alone_ms and ns else None,
+                "note": ("with --slots > 1 a launch shares the GPU with the kernels that end the previous batch's chain, so "
+                         "its duration (mean_launch_ms, achieved, frac) is longer than the step time would suggest; "
+                         "*_one_batch_at_a_time is the same kernel with the GPU to itself") if args.slots > 1 else None,
             },
             # one batch's kernel chain from its first to its last kernel (HIP events): a latency -- with more than one
             # batch in flight consecutive chains overlap, and the step time is ms_per_step
