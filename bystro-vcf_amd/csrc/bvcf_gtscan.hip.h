@@ -108,25 +108,14 @@ __device__ inline void classify_field(const uint8_t *buf, uint32_t p, uint32_t c
 //   t == 0                      the field is the reference genotype (the common case)
 //   t & 0xFFE0FFE0 != 0         separator / TAB bytes differ, or an allele byte is outside
 //                               '0'^[0,31]: not a regular field
-//   v = allele byte ^ '0'       0..9 for digits, 0x1E for '.'; valid iff bit v of 0x400003FF
-// Classes come from a 16-entry x 2-bit table indexed by v & 15 (digit d -> 1 iff d == allele,
-// 14 ('.') -> 3): cls = min(code(b0) + code(b2), 3) gives none/het/hom/missing (main.go:1063-1124).
+//   v = allele byte ^ '0'       0..9 for digits, 0x1E for '.'
+// The allele characters of four fields are gathered into two dwords (first alleles, second alleles) with v_perm and
+// classified byte-parallel: a byte equal to the counted allele's digit scores one, '.' in either position makes the
+// field missing, anything outside {0-9, .} fails the line over to the general scan (main.go:1063-1124).
 constexpr int kFastGroup = 5;  // chunks per buffer; two buffers => 10 KiB in flight per wave
 
-// v_bfe_u32 and the shifts use only the low 5 bits of their offset operand, so (t << 1) selects entry
-// t & 15 of the 2-bit table for byte 0, and (t >> 15) entry (t >> 16) & 15 for byte 2 (bit 0 of that
-// offset is bit 7 of the separator xor, zero whenever the frame test passes).
-__device__ __forceinline__ uint32_t fast_codes(uint32_t t, uint32_t table) {
-  const uint32_t k = __builtin_amdgcn_ubfe(table, t << 1, 2u) + __builtin_amdgcn_ubfe(table, t >> 15, 2u);
-  return k < 3u ? k : 3u;
-}
-
-// both allele bytes in {0-9, .}: bit (byte ^ '0') of 0x400003FF (the bytes are < 32 when the frame
-// test passes; the hardware shift takes the amount mod 32)
-__device__ __forceinline__ uint32_t fast_valid(uint32_t t) { return (0x400003FFu >> t) & (0x400003FFu >> (t >> 16)); }
-
 struct FastAcc {
-  uint32_t bad, ok, het, hom, miss;
+  uint32_t bad, het, hom, miss;
   uint32_t n_sp;  // wave-uniform: entries in the sparse class list; > BVCF_CMAP_SPARSE_MAX once the line went dense
 };
 
@@ -187,17 +176,28 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
     }
   }
   if (__any((t[0] | t[1] | t[2] | t[3]) != 0)) {
-    uint32_t byte = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      acc.bad |= t[q] & 0xFFE0FFE0u;
-      acc.ok &= fast_valid(t[q]);
-      byte |= fast_codes(t[q], table) << (2 * q);
-    }
-    const uint32_t lo = byte & 0x55u, hi = (byte >> 1) & 0x55u;
-    acc.het += __popc(lo & ~hi);
-    acc.hom += __popc(hi & ~lo);
-    acc.miss += __popc(lo & hi);
+    // The four fields at once, one byte lane per field.  A = first alleles, B = second alleles (each byte is the
+    // allele character ^ '0': 0..9 for digits, 0x1E for '.'; below 32 whenever the frame test passes, which makes the
+    // carry-free zero-byte test ~((x + 0x7F..) | x) & 0x80.. exact).
+    acc.bad |= (t[0] | t[1] | t[2] | t[3]) & 0xFFE0FFE0u;
+    const uint32_t p01 = __builtin_amdgcn_perm(t[1], t[0], 0x06020400u);  // a0 a1 b0 b1
+    const uint32_t p23 = __builtin_amdgcn_perm(t[3], t[2], 0x06020400u);  // a2 a3 b2 b3
+    const uint32_t A = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+    const uint32_t B = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+    const uint32_t low = table & 0x0FFFFFFFu;  // digit d -> 1 at bits 2d..2d+1 (k_order's / k_stream's per-allele table): the allele digit
+    const uint32_t ka = low ? (uint32_t)(__builtin_ctz(low) >> 1) * 0x01010101u : 0xFFFFFFFFu;
+    auto zero_b = [](uint32_t x) -> uint32_t { return ~((x + 0x7F7F7F7Fu) | x) & 0x80808080u; };
+    const uint32_t dA = zero_b(A ^ 0x1E1E1E1Eu), dB = zero_b(B ^ 0x1E1E1E1Eu);  // '.'
+    const uint32_t eA = zero_b(A ^ ka), eB = zero_b(B ^ ka);                    // the allele being counted
+    // alphabet: a byte is a digit (<= 9) or '.'
+    acc.bad |= (((A + 0x76767676u) & ~dA) | ((B + 0x76767676u) & ~dB)) & 0x80808080u;
+    const uint32_t dm = dA | dB;
+    const uint32_t LO = (eA ^ eB) | dm, HI = (eA & eB) | dm;  // class bits of the four fields at bits 7, 15, 23, 31
+    acc.het += __popc(LO & ~HI);
+    acc.hom += __popc(HI & ~LO);
+    acc.miss += __popc(LO & HI);
+    // gather the four (lo, hi) pairs into one byte: pair i sits at bits 8i, 8i+1 and moves to 24 + 2i
+    const uint32_t byte = ((((LO >> 7) | (HI >> 6)) & 0x03030303u) * 0x01041040u) >> 24;
     if (cmap && sp && acc.n_sp < kDenseMode) {
       const unsigned long long nz = __ballot(byte != 0);
       const uint32_t cnt = (uint32_t)__popcll(nz);
@@ -258,7 +258,7 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
   auto next0 = [&](uint32_t c, const u32x4 &nxt) -> uint32_t {
     return c + 1 < n_chunks ? (uint32_t)__builtin_amdgcn_readfirstlane(nxt.x) : 0u;
   };
-  FastAcc acc = {0, 1, 0, 0, 0, kDenseMode};
+  FastAcc acc = {0, 0, 0, 0, kDenseMode};
   if (cmap) zero_stage(stage, n_chunks);
   u32x4 va[kFastGroup], vb[kFastGroup];
 #pragma unroll
@@ -292,7 +292,7 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
     for (int g = 0; g < kFastGroup; g++)
       if (c0 + 3 * kFastGroup + g < n_chunks) vb[g] = fetch(c0 + 3 * kFastGroup + g);
   }
-  if (__any(acc.bad != 0 || !(acc.ok & 1u))) return false;
+  if (__any(acc.bad != 0)) return false;
   wave_sum3(acc.het, acc.hom, acc.miss, ns, &st->n_het, &st->n_hom, &st->n_miss);
   st->ac = st->n_het + 2u * st->n_hom;
   st->an = 2u * (ns - st->n_miss);

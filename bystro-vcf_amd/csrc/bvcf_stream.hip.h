@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
 #else
           const bool sparse_ok = a.cmap_stride >= 4u * kSparseWords;
 #endif
-          FastAcc acc = {0, 1, 0, 0, 0, sparse_ok ? 0u : kDenseMode};
+          FastAcc acc = {0, 0, 0, 0, sparse_ok ? 0u : kDenseMode};
           if (cm && !sparse_ok) zero_stage(stage, nc);
           const uint32_t rA = sA & amask;
           const uint32_t w0 = __builtin_amdgcn_alignbyte(__builtin_amdgcn_readfirstlane(va[0].y),
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
             va[g] = chunk_at(s_next, g);
           }
           STAMP(3);
-          if (__any(acc.bad != 0 || !(acc.ok & 1u))) {
+          if (__any(acc.bad != 0)) {
             // A is not regular after all: B was predicted from a wrong line end.  Leave the
             // pipeline (the loads in flight are simply dropped) and take A the slow way.
             s_begin = sA;
