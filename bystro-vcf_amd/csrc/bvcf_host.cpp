@@ -17,6 +17,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -36,9 +37,15 @@ const char *const kSiteNames[5] = {"SNP", "INS", "DEL", "MNP", "MULTIALLELIC"};
 const char *or_default(const char *s, const char *d) { return s ? s : d; }
 
 void append_ll(std::string &o, long long v) {
-  char tmp[32];
-  int n = snprintf(tmp, sizeof tmp, "%lld", v);
-  o.append(tmp, (size_t)n);
+  char tmp[24];
+  char *e = tmp + sizeof tmp, *p = e;
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  do {
+    *--p = (char)('0' + u % 10);
+    u /= 10;
+  } while (u);
+  if (v < 0) *--p = '-';
+  o.append(p, (size_t)(e - p));
 }
 
 // strconv.FormatFloat(x, 'G', 3, 64) (main.go:627); "%.3G" is identical on [0, 1]
@@ -54,6 +61,7 @@ struct Names {
   std::string arena;
   std::vector<uint32_t> off;  // entry s is arena[off[s], off[s + 1]); the delimiter is its last n_delim bytes
   size_t n_delim = 0;
+  uint32_t max_entry = 0;  // longest name + delimiter; the arena is padded so that 32 bytes can be read at any entry
   Names(const char *const *ptr, const uint32_t *len, size_t n, const char *delim) {
     n_delim = strlen(delim);
     off.reserve(n + 1);
@@ -61,45 +69,103 @@ struct Names {
       off.push_back((uint32_t)arena.size());
       arena.append(ptr[s], len[s]);
       arena.append(delim, n_delim);
+      max_entry = std::max<uint32_t>(max_entry, (uint32_t)(len[s] + n_delim));
     }
     off.push_back((uint32_t)arena.size());
+    arena.append(32, '\0');
   }
 };
 
-// strings.Join(names of samples with class `want`, fieldDelimiter); `sparse`: the map is a list of its non-zero
-// bytes (BVCF_ALLELE_CMAP_SPARSE)
-void join_class(std::string &o, const uint8_t *cmap, bool sparse, uint32_t ns, unsigned want, const Names &nm) {
+// "%.3G" of the ratios nearly every row prints: n / n_samples (heterozygosity, homozygosity, missingness of a line
+// without missing genotypes) and ac / (2 n_samples) (sampleMaf).  The doubles are formed exactly as format_lines
+// forms them, so a cached string is the string snprintf would produce.
+struct Ratios {
+  uint32_t ns = 0;
+  std::vector<char> of_ns, of_2ns;  // 12 bytes per entry: length, then the characters
+  explicit Ratios(uint32_t n_samples) {
+    if (n_samples == 0 || n_samples > 50000) return;  // (big cohorts: 150 000 snprintf calls are not worth it up front)
+    ns = n_samples;
+    auto fill = [](std::vector<char> &t, uint32_t n_max, double denom) {
+      t.assign((size_t)(n_max + 1) * 12, 0);
+      for (uint32_t n = 0; n <= n_max; n++) {
+        char tmp[64];
+        const int k = snprintf(tmp, sizeof tmp, "%.3G", (double)n / denom);
+        if (k > 0 && k <= 11) {
+          t[(size_t)n * 12] = (char)k;
+          memcpy(&t[(size_t)n * 12 + 1], tmp, (size_t)k);
+        }
+      }
+    };
+    fill(of_ns, ns, (double)ns);
+    fill(of_2ns, 2 * ns, (double)(2 * ns));
+  }
+  // appends "%.3G" of num / den
+  void append(std::string &o, uint32_t num, double den_d, uint64_t den) const {
+    const std::vector<char> *t = nullptr;
+    if (ns && den == ns && num <= ns)
+      t = &of_ns;
+    else if (ns && den == 2ull * ns && num <= 2 * ns)
+      t = &of_2ns;
+    if (t && (*t)[(size_t)num * 12]) {
+      o.append(&(*t)[(size_t)num * 12 + 1], (size_t)(*t)[(size_t)num * 12]);
+      return;
+    }
+    append_g3(o, (double)num / den_d);
+  }
+};
+
+// strings.Join(names of the `count` samples with class `want`, fieldDelimiter); `sparse`: the map is a list of its
+// non-zero bytes (BVCF_ALLELE_CMAP_SPARSE).  The output is sized for `count` entries up front and written with
+// fixed-size copies; the map is read eight bytes (32 samples) at a time.
+void join_class(std::string &o, const uint8_t *cmap, bool sparse, uint32_t ns, unsigned want, uint32_t count,
+                const Names &nm) {
   const size_t at = o.size();
-  auto emit = [&](uint32_t b, unsigned byte) {
-    for (unsigned j = 0; j < 4; j++) {
-      if (((byte >> (2 * j)) & 3u) != want) continue;
-      const uint32_t s = b * 4 + j;
-      if (s >= ns) break;
-      o.append(nm.arena.data() + nm.off[s], nm.off[s + 1] - nm.off[s]);  // name + delimiter
+  o.resize(at + (size_t)count * nm.max_entry + 32);
+  char *const w0 = &o[at];
+  char *w = w0;
+  const char *const arena = nm.arena.data();
+  const uint32_t wide = nm.max_entry <= 16 ? 16u : (nm.max_entry <= 32 ? 32u : 0u);
+  uint32_t k = 0;
+  // groups j (2 bits each) of x that hold `want`, for sample base s0; false once `count` names are out
+  auto emit = [&](uint64_t x, uint32_t s0) -> bool {
+    const uint64_t y = x ^ (want * 0x5555555555555555ull);
+    uint64_t m = ~(y | (y >> 1)) & 0x5555555555555555ull;
+    while (m) {
+      const uint32_t sidx = s0 + ((uint32_t)__builtin_ctzll(m) >> 1);
+      m &= m - 1;
+      if (sidx >= ns || k == count) return false;
+      const uint32_t a = nm.off[sidx], n = nm.off[sidx + 1] - a;  // name + delimiter
+      if (wide == 16)
+        memcpy(w, arena + a, 16);
+      else if (wide == 32)
+        memcpy(w, arena + a, 32);
+      else
+        memcpy(w, arena + a, n);
+      w += n;
+      k++;
     }
+    return true;
   };
-  struct Trim {  // the last entry's delimiter goes
-    std::string &o;
-    size_t at, n;
-    ~Trim() {
-      if (o.size() > at) o.resize(o.size() - n);
-    }
-  } trim{o, at, nm.n_delim};
   if (sparse) {
     uint32_t n;
     memcpy(&n, cmap, 4);
     for (uint32_t i = 0; i < n && i < BVCF_CMAP_SPARSE_MAX; i++) {
       uint32_t e;
       memcpy(&e, cmap + 4 + 4 * i, 4);
-      emit(e >> 8, e & 0xFFu);
+      // the bits above the byte must not look like class-`want` groups: 0 never is (want != 0)
+      if (!emit(e & 0xFFu, (e >> 8) * 4u)) break;
     }
-    return;
+  } else {
+    const uint32_t nbytes = (ns + 3) / 4;
+    for (uint32_t b = 0; b < nbytes; b += 8) {
+      uint64_t x = 0;
+      memcpy(&x, cmap + b, std::min<uint32_t>(8u, nbytes - b));
+      if (x && !emit(x, b * 4u)) break;
+    }
   }
-  const uint32_t nbytes = (ns + 3) / 4;
-  for (uint32_t b = 0; b < nbytes; b++) {
-    const unsigned byte = cmap[b];
-    if (byte) emit(b, byte);
-  }
+  size_t len = (size_t)(w - w0);
+  if (len) len -= nm.n_delim;  // the last entry's delimiter goes
+  o.resize(at + len);
 }
 
 const char *err_text(uint32_t code) {
@@ -142,8 +208,8 @@ void append_err(std::string &log, const bvcf_err &e, const bvcf_line &L, const u
 }
 
 // rows of lines [lo, hi), main.go:566-695
-void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm, uint32_t lo,
-                  uint32_t hi, std::string &out) {
+void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm,
+                  const Ratios *rt, uint32_t lo, uint32_t hi, std::string &out) {
   const char *empty = or_default(c->empty_field, "!");
   const uint32_t ns = r->n_samples;
   const double num_samples = (double)ns;
@@ -185,20 +251,25 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
 
       const double effective = num_samples - (double)A.n_miss;  // main.go:563
       const uint8_t *cm = (A.cmap_off != BVCF_NO_CMAP && r->cmap) ? r->cmap + A.cmap_off : nullptr;
+      const uint64_t n_eff = ns >= A.n_miss ? ns - A.n_miss : 0;
       struct {
         uint32_t n;
         unsigned cls;
         double denom;
-      } lists[3] = {{A.n_het, BVCF_CLS_HET, effective}, {A.n_hom, BVCF_CLS_HOM, effective},
-                    {A.n_miss, BVCF_CLS_MISSING, num_samples}};
+        uint64_t den;
+      } lists[3] = {{A.n_het, BVCF_CLS_HET, effective, n_eff}, {A.n_hom, BVCF_CLS_HOM, effective, n_eff},
+                    {A.n_miss, BVCF_CLS_MISSING, num_samples, ns}};
       for (int q = 0; q < 3; q++) {  // main.go:612-656
         if (lists[q].n == 0 || !cm) {
           out.append(empty);
           out.append("\t0");
         } else {
-          join_class(out, cm, (A.flags & BVCF_ALLELE_CMAP_SPARSE) != 0, ns, lists[q].cls, nm);
+          join_class(out, cm, (A.flags & BVCF_ALLELE_CMAP_SPARSE) != 0, ns, lists[q].cls, lists[q].n, nm);
           out.push_back('\t');
-          append_g3(out, (double)lists[q].n / lists[q].denom);
+          if (rt)
+            rt->append(out, lists[q].n, lists[q].denom, lists[q].den);
+          else
+            append_g3(out, (double)lists[q].n / lists[q].denom);
         }
         out.push_back('\t');
       }
@@ -208,6 +279,8 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
       out.push_back('\t');
       if (A.ac == 0)
         out.push_back('0');
+      else if (rt)
+        rt->append(out, A.ac, (double)A.an, A.an);
       else
         append_g3(out, (double)A.ac / (double)A.an);
       if (c->keep_pos) {  // main.go:674-692
@@ -229,27 +302,116 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
   }
 }
 
-void format_batch(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm,
-                  unsigned n_threads, std::string &out, std::string &log) {
-  // log lines in input order (stable: one line's messages keep their ALT order)
-  if (r->n_errs) {
-    std::vector<uint32_t> idx(r->n_errs);
-    for (uint32_t i = 0; i < r->n_errs; i++) idx[i] = i;
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return r->errs[x].line < r->errs[y].line; });
-    for (uint32_t i : idx) append_err(log, r->errs[i], r->lines[r->errs[i].line], block);
+// Persistent workers for the per-batch TSV assembly: a batch is a few thousand rows, too short to pay for
+// thread creation every time.  run() hands out task indices [0, n_tasks); the caller works too.
+class WorkPool {
+ public:
+  explicit WorkPool(unsigned n_threads) {
+    for (unsigned i = 1; i < n_threads; i++) th_.emplace_back([this] { loop(); });
   }
-  if (n_threads <= 1 || r->n_lines < 4 * n_threads) {
-    format_lines(c, r, block, nm, 0, r->n_lines, out);
-    return;
+  ~WorkPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
+    wake_.notify_all();
+    for (auto &t : th_) t.join();
   }
-  std::vector<std::string> parts(n_threads);
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < n_threads; t++) {
-    const uint32_t lo = (uint32_t)((uint64_t)r->n_lines * t / n_threads);
-    const uint32_t hi = (uint32_t)((uint64_t)r->n_lines * (t + 1) / n_threads);
-    th.emplace_back([=, &parts, &nm]() { format_lines(c, r, block, nm, lo, hi, parts[t]); });
+  unsigned size() const { return (unsigned)th_.size() + 1; }
+  template <class F>
+  void run(uint32_t n_tasks, F &&fn) {
+    if (!n_tasks) return;
+    auto job = std::make_shared<Job>();
+    job->fn = std::forward<F>(fn);
+    job->total = n_tasks;
+    job->left.store(n_tasks);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = job;
+      gen_++;
+    }
+    wake_.notify_all();
+    work(*job);
+    std::unique_lock<std::mutex> lk(job->mu);
+    job->done.wait(lk, [&] { return job->left.load() == 0; });
   }
-  for (auto &x : th) x.join();
+
+ private:
+  struct Job {
+    std::function<void(uint32_t)> fn;
+    uint32_t total = 0;
+    std::atomic<uint32_t> next{0}, left{0};
+    std::mutex mu;
+    std::condition_variable done;
+  };
+  static void work(Job &j) {
+    for (;;) {
+      const uint32_t t = j.next.fetch_add(1);
+      if (t >= j.total) return;
+      j.fn(t);
+      if (j.left.fetch_sub(1) == 1) {
+        std::lock_guard<std::mutex> lk(j.mu);
+        j.done.notify_all();
+      }
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::shared_ptr<Job> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        wake_.wait(lk, [&] { return quit_ || gen_ != seen; });
+        if (quit_) return;
+        seen = gen_;
+        job = job_;  // a worker only ever touches the job it took under the lock
+      }
+      work(*job);
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable wake_;
+  std::shared_ptr<Job> job_;
+  uint64_t gen_ = 0;
+  bool quit_ = false;
+};
+
+// the batch's log lines in input order (stable: one line's messages keep their ALT order)
+void format_log(const bvcf_result *r, const uint8_t *block, std::string &log) {
+  if (!r->n_errs) return;
+  std::vector<uint32_t> idx(r->n_errs);
+  for (uint32_t i = 0; i < r->n_errs; i++) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return r->errs[x].line < r->errs[y].line; });
+  for (uint32_t i : idx) append_err(log, r->errs[i], r->lines[r->errs[i].line], block);
+}
+
+// rows of one batch as consecutive pieces (parts[0] + parts[1] + ... is the batch's TSV): runs of lines are claimed
+// by the pool's threads, a few per thread so that lines with long sample lists do not leave the others idle
+void format_parts(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm, const Ratios *rt,
+                  WorkPool *pool, std::vector<std::string> &parts) {
+  const unsigned nt = pool ? pool->size() : 1;
+  uint32_t n_parts = 1;
+  if (nt > 1 && r->n_lines >= 4 * nt) n_parts = std::min<uint32_t>(4 * nt, r->n_lines / 32u);
+  if (n_parts < 1) n_parts = 1;
+  if (parts.size() < n_parts) parts.resize(n_parts);
+  for (auto &p : parts) p.clear();  // keeps the capacity of a recycled vector
+  auto one = [&](uint32_t t) {
+    const uint32_t lo = (uint32_t)((uint64_t)r->n_lines * t / n_parts);
+    const uint32_t hi = (uint32_t)((uint64_t)r->n_lines * (t + 1) / n_parts);
+    format_lines(c, r, block, nm, rt, lo, hi, parts[t]);
+  };
+  if (n_parts == 1)
+    one(0);
+  else
+    pool->run(n_parts, one);
+}
+
+void format_batch(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm, const Ratios *rt,
+                  WorkPool *pool, std::string &out, std::string &log) {
+  format_log(r, block, log);
+  std::vector<std::string> parts;
+  format_parts(c, r, block, nm, rt, pool, parts);
   for (auto &p : parts) out.append(p);
 }
 
@@ -341,8 +503,11 @@ struct Run {
   unsigned n_threads = 1;
   uint64_t max_batch = 0;
   std::unique_ptr<Names> names; // built once the header is known
+  std::unique_ptr<Ratios> ratios;
   bvcf_arrow *arrow = nullptr;  // --dosageOutput
   bool want_rows = true;        // !noOut
+  std::unique_ptr<WorkPool> pool;  // TSV assembly workers (n_threads of them, this thread included)
+  uint32_t n_slots = 2;            // result slots of the ctx
 };
 
 // Which device path suits this file: the streaming path shines when sample fields are the bare
@@ -411,7 +576,7 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_d
   p.allow_filter = R.cfg->allow_filter;
   p.exclude_filter = R.cfg->exclude_filter;
   p.max_batch_bytes = R.max_batch;
-  p.n_slots = 2;
+  p.n_slots = R.n_slots;
   p.path = data ? choose_path(R, data, n_data) : 0;
   int rc = bvcf_create(&R.ctx, &p);
   if (rc) {
@@ -423,8 +588,10 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_d
     R.name_len.push_back((uint32_t)R.pre.header[i].size());
   }
   R.names.reset(new Names(R.name_ptr.data(), R.name_len.data(), R.name_ptr.size(), or_default(R.cfg->field_delimiter, ";")));
+  R.ratios.reset(new Ratios((uint32_t)R.name_ptr.size()));
   R.n_threads = R.cfg->n_format_threads ? R.cfg->n_format_threads
                                          : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  if (R.want_rows && R.n_threads > 1) R.pool.reset(new WorkPool(R.n_threads));
   if (R.cfg->dosage_path && *R.cfg->dosage_path) {  // main.go:306-342
     if (R.pre.header.size() <= 9) {
       // "No samples found in VCF file; writing empty dosage matrix file"
@@ -615,7 +782,9 @@ int bvcf_format_tsv(const bvcf_config *c, const bvcf_result *r, const uint8_t *b
   Names nm(sample_names, sample_name_lens, r->n_samples, or_default(c->field_delimiter, ";"));
   const unsigned nt =
       c->n_format_threads ? c->n_format_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-  format_batch(c, r, block, nm, nt, o, l);
+  std::unique_ptr<WorkPool> pool;
+  if (nt > 1 && r->n_lines >= 4 * nt) pool.reset(new WorkPool(nt));
+  format_batch(c, r, block, nm, nullptr, pool.get(), o, l);
   *out = dup_out(o, n_out);
   if (log && n_log) *log = dup_out(l, n_log);
   return *out ? BVCF_OK : BVCF_E_NOMEM;
@@ -663,10 +832,9 @@ int bvcf_run_buffer(const bvcf_config *c, const uint8_t *vcf, size_t n, char **o
       }
       lines_in += res.n_lines_seen;
       if (R.want_rows) {
-        format_batch(c, &res, vcf + pos, nm, R.n_threads, o, l);
+        format_batch(c, &res, vcf + pos, nm, R.ratios.get(), R.pool.get(), o, l);
       } else {
-        std::string none;
-        format_batch(c, &res, vcf + pos, nm, 1, none, l);  // the log lines only
+        format_log(&res, vcf + pos, l);
       }
       if (append_dosage(R, &res, vcf + pos)) {
         l.append("dosage matrix: write failed\n");
@@ -704,19 +872,22 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// The reference's main() + readVcf (main.go:134-217, 241-396) as a four-stage pipeline:
+// The reference's main() + readVcf (main.go:134-217, 241-396) as a five-stage pipeline:
 //   reader thread  fd -> pinned buffers, cut at the last terminator         (main.go:349-380)
 //   this thread    bvcf_submit one block ahead, bvcf_collect the oldest     (processLines' input side)
-//   format pool    TSV assembly of a collected batch                        (main.go:566-695)
+//   format thread  TSV assembly of a collected batch on the worker pool     (main.go:566-695)
 //   writer thread  ordered write to fd_out                                  (main.go:524-532,705-711)
+// A collected batch's result arrays stay valid until its slot is collected into again, n_slots batches
+// later, so formatting runs one or two batches behind the device instead of between two submits.
 int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_t *n_lines_in) {
   if (!c) return BVCF_E_ARG;
   const bool timing = getenv("BVCF_TIMING") != nullptr;
   const double t_start = now_s();
-  double t_wait_read = 0, t_gpu = 0, t_fmt = 0, t_init = 0;
+  double t_wait_read = 0, t_gpu = 0, t_fmt = 0, t_fmt_wait = 0, t_init = 0, t_ctx = 0;
   std::string msg;
   Run R;
   R.cfg = c;
+  R.n_slots = 3;  // two batches on the device, one more being formatted
   R.max_batch = c->max_batch_bytes ? c->max_batch_bytes : (64ull << 20);
   uint64_t lines_in = 0;
 
@@ -732,25 +903,45 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   }
 
   const size_t cap = R.max_batch;
-  constexpr int kBufs = 4;
-  uint8_t *bufs[kBufs];
-  for (int i = 0; i < kBufs; i++) bufs[i] = (uint8_t *)bvcf_alloc_pinned(cap);
-  auto free_bufs = [&]() {
-    for (int i = 0; i < kBufs; i++) bvcf_free_pinned(bufs[i]);
-  };
-  for (int i = 0; i < kBufs; i++)
-    if (!bufs[i]) {
-      // no device => no pinned memory either; fail loudly, there is no CPU path
-      free_bufs();
-      dprintf(fd_err, "cannot allocate pinned host memory (no usable HIP device?)\n");
-      return BVCF_E_NODEV;
-    }
+  constexpr int kBufs = 6;  // being read into, two on the device, up to two with the formatter, one spare
+  // Pinning memory costs about 25 ms per 64 MiB: only the first buffer is allocated before the reader starts, the
+  // others follow in the background while the first block is read and the ctx is created, and stop at end of input
+  // (a small file never pays for six).
+  uint8_t *bufs[kBufs] = {nullptr};
+  bufs[0] = (uint8_t *)bvcf_alloc_pinned(cap);
+  const double t_pinned = now_s() - t_start;
+  if (!bufs[0]) {
+    // no device => no pinned memory either; fail loudly, there is no CPU path
+    dprintf(fd_err, "cannot allocate pinned host memory (no usable HIP device?)\n");
+    return BVCF_E_NODEV;
+  }
 
   Channel<uint8_t *> free_q(64);
   Channel<Block> ready_q(kBufs);
-  Channel<std::string *> write_q(4);
-  for (int i = 0; i < kBufs; i++) free_q.push(bufs[i]);
+  typedef std::vector<std::string> Parts;
+  Channel<Parts *> write_q(4);
+  free_q.push(bufs[0]);
   std::atomic<bool> stop{false};
+  std::atomic<bool> stop_alloc{false}, alloc_failed{false};
+  std::thread allocator([&]() {
+    for (int i = 1; i < kBufs && !stop_alloc.load(); i++) {
+      bufs[i] = (uint8_t *)bvcf_alloc_pinned(cap);
+      if (!bufs[i]) {
+        // the pipeline needs three buffers to make progress: end the run (reported below) rather than stall
+        alloc_failed.store(true);
+        stop.store(true);
+        free_q.push(nullptr);
+        return;
+      }
+      free_q.push(bufs[i]);
+    }
+  });
+  auto free_bufs = [&]() {
+    std::vector<std::thread> th;
+    for (int i = 0; i < kBufs; i++)
+      if (bufs[i]) th.emplace_back([&, i]() { bvcf_free_pinned(bufs[i]); });
+    for (auto &t : th) t.join();
+  };
   std::atomic<uint8_t> eol_byte{'\n'};
   std::atomic<bool> eol_known{false};
 
@@ -785,6 +976,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       }
       b.fill = fill;
       b.last = eof;
+      if (eof) stop_alloc.store(true);
       if (first) {
         // the terminator is learnt from line 1 (parse.FindEndOfLine, main.go:250)
         uint8_t e = '\n';
@@ -818,16 +1010,74 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     }
   });
 
-  // ---- writer
+  // ---- writer; written-out part vectors go back to the formatter with their capacity
   std::atomic<bool> write_failed{false};
+  std::mutex spare_mu;
+  std::vector<Parts *> spares;
   std::thread writer([&]() {
     for (;;) {
-      std::string *s = write_q.pop();
-      if (!s) break;
-      if (!write_failed.load() && write_all(fd_out, s->data(), s->size())) write_failed.store(true);
-      delete s;
+      Parts *ps = write_q.pop();
+      if (!ps) break;
+      for (const std::string &s : *ps)
+        if (!s.empty() && !write_failed.load() && write_all(fd_out, s.data(), s.size())) write_failed.store(true);
+      std::lock_guard<std::mutex> lk(spare_mu);
+      if (spares.size() < 4)
+        spares.push_back(ps);
+      else
+        delete ps;
     }
   });
+
+  // ---- formatter: collected batches in order
+  struct FmtJob {
+    Block b;
+    bvcf_result res;
+    bool stop = false;
+  };
+  Channel<FmtJob> fmt_q(1);
+  std::mutex fmt_mu;
+  std::condition_variable fmt_cv;
+  uint64_t fmt_done = 0;  // jobs finished (under fmt_mu)
+  std::atomic<bool> dosage_failed{false};
+  std::thread formatter([&]() {
+    for (;;) {
+      FmtJob j = fmt_q.pop();
+      if (j.stop) break;
+      const double t0 = now_s();
+      Parts *ps = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(spare_mu);
+        if (!spares.empty()) {
+          ps = spares.back();
+          spares.pop_back();
+        }
+      }
+      if (!ps) ps = new Parts();
+      const uint8_t *text = j.b.buf + j.b.start;
+      std::string jlog;
+      format_log(&j.res, text, jlog);
+      if (R.want_rows)
+        format_parts(c, &j.res, text, *R.names, R.ratios.get(), R.pool.get(), *ps);
+      else
+        for (auto &q : *ps) q.clear();
+      if (append_dosage(R, &j.res, text)) dosage_failed.store(true);
+      t_fmt += now_s() - t0;
+      write_q.push(ps);
+      if (!jlog.empty()) write_all(fd_err, jlog.data(), jlog.size());
+      free_q.push(j.b.buf);
+      {
+        std::lock_guard<std::mutex> lk(fmt_mu);
+        fmt_done++;
+      }
+      fmt_cv.notify_all();
+    }
+  });
+  auto wait_formatted = [&](uint64_t n_jobs) {
+    const double t0 = now_s();
+    std::unique_lock<std::mutex> lk(fmt_mu);
+    fmt_cv.wait(lk, [&] { return fmt_done >= n_jobs; });
+    t_fmt_wait += now_s() - t0;
+  };
 
   int rc = BVCF_OK;
   bool have_pre = false, done = false;
@@ -843,23 +1093,44 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     done = true;
   };
 
-  // collect the oldest in-flight block, format it, queue its rows; grows the reservation on demand
+  // collect the oldest in-flight block and hand it to the formatter; grows the reservation on demand.
+  // Collect number q of the ctx lands in result slot q % n_slots, whose arrays the formatter may still be
+  // reading for the batch collected n_slots collects ago.
+  uint64_t n_collects = 0, n_jobs = 0;
+  std::deque<std::pair<uint64_t, uint64_t>> outstanding;  // (job number, collect number) of jobs not known finished
+  auto slot_is_free = [&]() {
+    uint64_t need = 0;
+    while (!outstanding.empty() && outstanding.front().second + R.n_slots <= n_collects) {
+      need = outstanding.front().first + 1;
+      outstanding.pop_front();
+    }
+    if (need) wait_formatted(need);
+  };
   auto finish_oldest = [&]() {
     Block b = in_flight.front();
     bvcf_result res;
+    slot_is_free();
     double t0 = now_s();
     int r = bvcf_collect(R.ctx, &res);
+    n_collects++;
     if (r == BVCF_E_CAPACITY) {
-      // drop what is in flight, grow, resubmit everything still queued on the device side
+      // drop what is in flight, let the formatter finish with the arrays that are about to be reallocated,
+      // grow, resubmit everything still queued on the device side
+      wait_formatted(n_jobs);
+      outstanding.clear();
       for (size_t k = 1; k < in_flight.size(); k++) {
         bvcf_result tmp;
         bvcf_collect(R.ctx, &tmp);
+        n_collects++;
       }
       r = bvcf_reserve(R.ctx, res.need_lines + res.need_lines / 4 + 64, res.need_alleles + res.need_alleles / 4 + 64,
                        res.need_cmap_bytes + res.need_cmap_bytes / 4 + 4096);
       for (size_t k = 0; k < in_flight.size() && r == BVCF_OK; k++)
         r = bvcf_submit(R.ctx, in_flight[k].buf + in_flight[k].start, in_flight[k].nb, seq++);
-      if (r == BVCF_OK) r = bvcf_collect(R.ctx, &res);
+      if (r == BVCF_OK) {
+        r = bvcf_collect(R.ctx, &res);
+        n_collects++;
+      }
     }
     t_gpu += now_s() - t0;
     if (r != BVCF_OK) {
@@ -868,19 +1139,13 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     }
     in_flight.pop_front();
     lines_in += res.n_lines_seen;
-    t0 = now_s();
-    std::string *out = new std::string();
-    const Names &nm = *R.names;
-    format_batch(c, &res, b.buf + b.start, nm, R.want_rows ? R.n_threads : 1, *out, log);
-    if (!R.want_rows) out->clear();
-    if (append_dosage(R, &res, b.buf + b.start)) fail("dosage matrix: write failed", BVCF_E_FATAL);
-    t_fmt += now_s() - t0;
-    write_q.push(out);
-    if (!log.empty()) {
-      write_all(fd_err, log.data(), log.size());
-      log.clear();
-    }
-    free_q.push(b.buf);
+    FmtJob j;
+    j.b = b;
+    j.res = res;
+    outstanding.emplace_back(n_jobs, n_collects - 1);
+    n_jobs++;
+    fmt_q.push(j);
+    if (dosage_failed.load()) fail("dosage matrix: write failed", BVCF_E_FATAL);
     if (write_failed.load()) fail("write failed", BVCF_E_FATAL);
   };
 
@@ -898,10 +1163,14 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
         fail(msg, BVCF_E_FATAL);
       } else {
         have_pre = true;
+        const double tc = now_s();
         int r = open_ctx(R, &msg, b.buf + R.pre.data_off, b.fill > R.pre.data_off ? b.fill - R.pre.data_off : 0);
+        t_ctx = now_s() - tc;
         if (r) fail(msg, r);
-        if (!done && R.pre.header.size() == 9)
-          log.append("Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n");
+        if (!done && R.pre.header.size() == 9) {
+          const char *m = "Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n";
+          write_all(fd_err, m, strlen(m));
+        }
         b.start = R.pre.data_off;
         b.nb = b.nb > b.start ? b.nb - b.start : 0;
       }
@@ -922,6 +1191,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     }
     if (b.last) {
       while (!done && !in_flight.empty()) finish_oldest();
+      if (alloc_failed.load()) fail("cannot allocate pinned host memory", BVCF_E_NOMEM);
       if (!have_pre && rc == BVCF_OK) fail("EOF", BVCF_E_FATAL);
       done = true;
     }
@@ -929,6 +1199,8 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
 
   // ---- shut down
   stop.store(true);
+  stop_alloc.store(true);
+  allocator.join();
   for (int i = 0; i < kBufs; i++) free_q.push(nullptr);  // unblock a reader waiting for a buffer
   // drain blocks the reader may still push so that it can exit
   std::thread drain([&]() {
@@ -945,8 +1217,23 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     ready_q.push(end);
   }
   drain.join();
+  {
+    FmtJob end;
+    end.stop = true;
+    fmt_q.push(end);
+  }
+  formatter.join();
   write_q.push(nullptr);
   writer.join();
+  for (Parts *ps : spares) delete ps;
+  if (rc == BVCF_OK && dosage_failed.load()) {
+    log.append("dosage matrix: write failed\n");
+    rc = BVCF_E_FATAL;
+  }
+  if (rc == BVCF_OK && write_failed.load()) {
+    log.append("write failed\n");
+    rc = BVCF_E_FATAL;
+  }
   if (close_dosage(R) && rc == BVCF_OK) {
     log.append("dosage matrix: write failed\n");
     rc = BVCF_E_FATAL;
@@ -963,8 +1250,9 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   free_bufs();
   if (timing)
     dprintf(fd_err,
-            "[bvcf timing] init %.3f wait-for-reader %.3f gpu(wait) %.3f format %.3f teardown %.3f total %.3f s\n",
-            t_init, t_wait_read, t_gpu, t_fmt, now_s() - t_end0, now_s() - t_start);
+            "[bvcf timing] init %.3f (pinned buffers %.3f, ctx %.3f) wait-for-reader %.3f gpu(wait) %.3f wait-for-formatter %.3f (formatter busy %.3f) "
+            "teardown %.3f total %.3f s\n",
+            t_init, t_pinned, t_ctx, t_wait_read, t_gpu, t_fmt_wait, t_fmt, now_s() - t_end0, now_s() - t_start);
   if (n_lines_in) *n_lines_in = lines_in;
   return rc;
 }

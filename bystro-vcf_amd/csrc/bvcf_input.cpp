@@ -2,6 +2,7 @@
 #include "bvcf_input.h"
 
 #include <errno.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -127,7 +128,9 @@ ssize_t ByteSource::read_text(uint8_t *dst, size_t cap) {
     const off_t at = lseek(fd_, 0, SEEK_CUR);
     if (at >= 0 && fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > at) {
       const size_t want = (size_t)std::min<off_t>((off_t)cap, st.st_size - at);
-      const unsigned n_thr = std::max(1u, std::min({8u, n_threads_ ? n_threads_ : 8u, (unsigned)(want >> 22)}));
+      unsigned max_thr = 8;
+      if (const char *e = getenv("BVCF_READ_THREADS")) max_thr = (unsigned)std::max(1, atoi(e));  // tuning
+      const unsigned n_thr = std::max(1u, std::min({max_thr, n_threads_ ? n_threads_ : 8u, (unsigned)(want >> 21)}));
       std::vector<size_t> got_n(n_thr, 0);
       std::vector<int> err_n(n_thr, 0);
       auto part = [&](unsigned t) {

@@ -130,6 +130,30 @@ def test_fuzz_parity(bv, seed, n_lines, n_samples, fmt_extra, weird):
     both(bv, vcf, {"keepId": True, "keepInfo": True, "keepPos": True, "exclude": "q10"})
 
 
+@pytest.mark.parametrize("name_len,delim", [(3, ";"), (15, ";"), (16, "|"), (30, ";;"), (33, ","), (70, ";")])
+def test_sample_name_widths(bv, name_len, delim):
+    """the list writer moves names with fixed 16 / 32 byte copies when name + delimiter fit: each width class,
+    names of mixed length, one- and two-byte delimiters; dense maps and sparse lists both"""
+    import random
+    ns = 600
+    names = [("N%d_" % i).ljust(max(len("N%d_" % i), name_len - (i % 4)), "x") for i in range(ns)]
+    rng = random.Random(name_len)
+    rows = [vcfgen.header(ns, names=names)]
+    pos = 5000
+    for k in range(120):
+        pos += rng.randint(1, 50)
+        # common alleles (dense map) alternate with singletons/doubletons (sparse list); a few missing genotypes
+        p_alt = 0.4 if k % 2 else 1.5 / ns
+        gts = []
+        for _ in range(ns):
+            r = rng.random()
+            gts.append(".|." if r < 0.003 else ("1|1" if r < 0.003 + p_alt / 3 else ("0|1" if r < 0.003 + p_alt else "0|0")))
+        rows.append("\t".join(["chr1", str(pos), "rs%d" % k, "A", "G", ".", "PASS", "DP=1", "GT"] + gts) + "\n")
+    vcf = "".join(rows).encode()
+    both(bv, vcf, {"fieldDelimiter": delim})
+    both(bv, vcf, {"fieldDelimiter": delim, "keepId": True}, max_batch_bytes=1 << 16)
+
+
 @pytest.mark.parametrize("n_samples", [300, 512, 1030])
 def test_chunk_boundary_alignment(bv, n_samples):
     """a single non-reference genotype next to every 256-sample chunk boundary, at each of the four byte

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""End-to-end CLI timing: synthetic rows -> file -> bystro-vcf (HIP) -> /dev/null, with the stage times of
+BVCF_TIMING, and (optionally) an md5 comparison with the oracle CLI on the same file.
+
+    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH]
+
+Needs a GPU box.  The file is written to /dev/shm when it fits there, else /tmp, and removed afterwards.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import benchgen as bg  # noqa: E402
+
+CLI = os.path.join(ROOT, "bystro-vcf_amd", "bystro-vcf")
+ORACLE = os.path.join(ROOT, "oracle", "bvcf_oracle")
+
+
+def md5_of(cmd, path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        p = subprocess.Popen(cmd, stdin=f, stdout=subprocess.PIPE)
+        for chunk in iter(lambda: p.stdout.read(1 << 24), b""):
+            h.update(chunk)
+        p.wait()
+    return p.returncode, h.hexdigest()
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rows = int(args[0]) if args else 400_000
+    profile = args[1] if len(args) > 1 else "c3"
+    check = "--check" in sys.argv
+    cfg = bg.make_cfg(profile)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(base, "bvcf_e2e_%d.vcf" % os.getpid())
+    keep = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--keep=")]
+    if keep:
+        path = keep[0]
+    try:
+        t0 = time.perf_counter()
+        if not (keep and os.path.exists(path)):
+            with open(path, "wb") as f:
+                f.write(bg.header(cfg))
+                for first in range(0, rows, 25_000):
+                    f.write(bg.rows_host(cfg, first, min(25_000, rows - first)))
+        size = os.path.getsize(path)
+        print("file: %d rows, %.2f GB in %s (%.1f s to generate)" % (rows, size / 1e9, base, time.perf_counter() - t0), flush=True)
+        env = dict(os.environ, BVCF_TIMING="1")
+        extra = []
+        if "--dosage" in sys.argv:
+            extra = ["--dosageOutput", path + ".arrow"]
+        runs = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--runs=")]
+        for it in range(runs[0] if runs else 3):
+            t0 = time.perf_counter()
+            with open(path, "rb") as f, open("/dev/null", "wb") as out:
+                p = subprocess.run([CLI] + extra, stdin=f, stdout=out, stderr=subprocess.PIPE, env=env)
+            dt = time.perf_counter() - t0
+            tl = [l for l in p.stderr.decode().splitlines() if "timing" in l]
+            print("run %d: rc %d, %.3f s wall = %.2f M variants/s, %.1f GB/s   %s" %
+                  (it, p.returncode, dt, rows / dt / 1e6, size / dt / 1e9, tl[-1] if tl else ""), flush=True)
+        if check:
+            rc_g, m_g = md5_of([CLI], path)
+            rc_o, m_o = md5_of([ORACLE], path)
+            print("md5 hip %s (rc %d)  oracle %s (rc %d)  %s" % (m_g, rc_g, m_o, rc_o, "IDENTICAL" if m_g == m_o else "DIFFERENT"))
+            if m_g != m_o:
+                sys.exit(1)
+    finally:
+        for q in (path, path + ".arrow"):
+            if os.path.exists(q) and not (keep and q == path):
+                os.unlink(q)
+
+
+if __name__ == "__main__":
+    main()
