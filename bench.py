@@ -13,9 +13,9 @@ library's default), each with its own HIP stream, exactly as bvcf_submit deals t
 latency-bound kernels that end one batch's chain overlap the next batch's scan.  Records are independent: rank r owns its own rows (weak
 scaling), no collective in the data path; the per-rank variant counts are summed over RCCL at the end.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_gt, the genotype scan):
-achieved = algorithmic GT-text bytes per launch / its mean HIP-event duration inside the timed
-region.  `cpu_baseline` (rank 0, N == 1 only) times the CPU oracle — the C restatement of the
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_stream on the streaming
+path, k_gt on the census path): achieved = algorithmic text bytes per launch / its mean HIP-event
+duration inside the timed region.  `cpu_baseline` (rank 0, N == 1 only) times the CPU oracle — the C restatement of the
 reference algorithm, kind "port" — on a bounded sample of the same row model.
 """
 import argparse
