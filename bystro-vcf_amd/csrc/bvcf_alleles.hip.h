@@ -48,14 +48,18 @@ __device__ inline bool go_atoi(const Bytes &buf, Span s, long long *out) {
   return true;
 }
 
-__device__ __forceinline__ bool is_actg(uint8_t c) { return c == 'A' || c == 'C' || c == 'T' || c == 'G'; }
+// (bit tests instead of chains of ==: hipcc turns such a chain into a switch and lowers that to a tree of branches)
+__device__ __forceinline__ bool is_actg(uint8_t c) {
+  const uint32_t d = (uint32_t)c - 'A';  // A C G T = bits 0, 2, 6, 19
+  return (bool)((uint32_t)(d < 20u) & (0x80045u >> (d & 31u)));
+}
 
-// parse.GetTrTv restated (oracle/bvcf_oracle.c orc_get_trtv)
+// parse.GetTrTv restated (oracle/bvcf_oracle.c orc_get_trtv): 1 = transition (A<->G, C<->T), 2 = transversion, 0 = n/a
 __device__ __forceinline__ uint8_t trtv_of(uint8_t ref, uint8_t alt) {
-  if (!is_actg(ref) || !is_actg(alt)) return 0;
-  bool tr = (ref == 'A' && alt == 'G') || (ref == 'G' && alt == 'A') || (ref == 'C' && alt == 'T') ||
-            (ref == 'T' && alt == 'C');
-  return tr ? 1 : 2;
+  // bits 1-2 of the letters: A 0, C 1, T 2, G 3 -- a transition pairs the codes that differ in both bits
+  const uint32_t x = (((uint32_t)ref ^ (uint32_t)alt) >> 1) & 3u;
+  const uint32_t ok = (uint32_t)is_actg(ref) & (uint32_t)is_actg(alt);
+  return (uint8_t)(ok ? (x == 3u ? 1u : 2u) : 0u);
 }
 
 // per-allele GT statistics (makeHetHomozygotes' return values)

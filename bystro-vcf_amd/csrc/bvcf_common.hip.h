@@ -193,9 +193,15 @@ __device__ __forceinline__ uint32_t eq_mask4(uint32_t d, uint32_t c4) {
 }
 
 // 16-bit mask over the lane's 16 bytes
+// (zero_bytes() flags an equal byte with 0x80: a byte dot product with weights 1, 2, 4, 8 -- 16..128 for the odd
+// dwords -- gathers eight flags into one number, scaled by 128.  13 instructions fewer than four multiply-gathers.)
 __device__ __forceinline__ uint32_t eq_mask16(u32x4 v, uint32_t c) {
-  uint32_t c4 = c * 0x01010101u;
-  return eq_mask4(v.x, c4) | (eq_mask4(v.y, c4) << 4) | (eq_mask4(v.z, c4) << 8) | (eq_mask4(v.w, c4) << 12);
+  const uint32_t c4 = c * 0x01010101u;
+  uint32_t lo = __builtin_amdgcn_udot4(zero_bytes(v.x ^ c4), 0x08040201u, 0u, false);
+  lo = __builtin_amdgcn_udot4(zero_bytes(v.y ^ c4), 0x80402010u, lo, false);
+  uint32_t hi = __builtin_amdgcn_udot4(zero_bytes(v.z ^ c4), 0x08040201u, 0u, false);
+  hi = __builtin_amdgcn_udot4(zero_bytes(v.w ^ c4), 0x80402010u, hi, false);
+  return (lo >> 7) | (hi << 1);
 }
 
 // bits [0, n) of a 16-bit mask, n may be <= 0 or >= 16

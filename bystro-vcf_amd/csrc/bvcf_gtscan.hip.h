@@ -364,7 +364,10 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
           const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, k & 3u);
           const uint32_t c1 = (w >> 8) & 0xFFu, c3 = w >> 24;
           const uint32_t v0 = (w & 0xFFu) ^ '0', v2 = ((w >> 16) & 0xFFu) ^ '0';
-          const bool frame = in4 && (c1 == '|' || c1 == '/') && (c3 == ':' || c3 == '\t');
+          // (bitwise on purpose: a chain of || over compares with constants becomes a switch, which the backend lowers
+          // to a tree of divergent branches)
+          const bool frame = in4 & (bool)((uint32_t)(c1 == '|') | (uint32_t)(c1 == '/')) &
+                             (bool)((uint32_t)(c3 == ':') | (uint32_t)(c3 == '\t'));
           // the reference genotype -- nearly every field of a cohort file -- only counts two called alleles;
           // the rest of the body runs when some lane of the wave holds anything else
           const bool ref = s < ns && frame && (v0 | v2) == 0;

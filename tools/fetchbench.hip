@@ -62,6 +62,11 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters
       if (KIND == 46) OP4("v_mul_u32_u24 %0, %4, %0\n v_mul_u32_u24 %1, %4, %1\n v_mul_u32_u24 %2, %4, %2\n v_mul_u32_u24 %3, %4, %3");
       if (KIND == 47) OP4("v_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n v_bitop3_b32 %1, %1, %4, %5 bitop3:0x80\n v_bitop3_b32 %2, %2, %4, %5 bitop3:0x80\n v_bitop3_b32 %3, %3, %4, %5 bitop3:0x80");
       if (KIND == 48) OP4("v_bitop3_b32 %0, %0, 7, %5 bitop3:0x36\n v_bitop3_b32 %1, %1, 7, %5 bitop3:0x36\n v_bitop3_b32 %2, %2, 7, %5 bitop3:0x36\n v_bitop3_b32 %3, %3, 7, %5 bitop3:0x36");
+      if (KIND == 49) OP4("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4");
+      if (KIND == 50) OP4("v_dot4_u32_u8 %0, %0, %4, %5\n v_dot4_u32_u8 %1, %1, %4, %5\n v_dot4_u32_u8 %2, %2, %4, %5\n v_dot4_u32_u8 %3, %3, %4, %5");
+      if (KIND == 51) OP4("v_mul_hi_u32 %0, %0, %4\n v_mul_hi_u32 %1, %1, %4\n v_mul_hi_u32 %2, %2, %4\n v_mul_hi_u32 %3, %3, %4");
+      if (KIND == 52) OP4("v_sad_u8 %0, %0, %4, %5\n v_sad_u8 %1, %1, %4, %5\n v_sad_u8 %2, %2, %4, %5\n v_sad_u8 %3, %3, %4, %5");
+      if (KIND == 53) OP4("v_mad_u32_u24 %0, %0, %4, %5\n v_mad_u32_u24 %1, %1, %4, %5\n v_mad_u32_u24 %2, %2, %4, %5\n v_mad_u32_u24 %3, %3, %4, %5");
     }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d;
@@ -116,5 +121,10 @@ int main() {
   run<46>("v_mul_u32_u24 v,v", out);
   run<47>("v_bitop3 v,v,v (and3)", out);
   run<48>("v_bitop3 v,7,v (inline)", out);
+  run<49>("v_mul_lo_u32 v,v", out);
+  run<50>("v_dot4_u32_u8 v,v,v", out);
+  run<51>("v_mul_hi_u32 v,v", out);
+  run<52>("v_sad_u8 v,v,v", out);
+  run<53>("v_mad_u32_u24 v,v,v", out);
   return 0;
 }
