@@ -397,6 +397,32 @@ def test_cli_matches_oracle(bv, tmp_path):
     assert p.returncode == 1
 
 
+def test_cli_many_batches_with_capacity_growth(bv):
+    """the pipelined driver over a dozen one-megabyte batches whose line count exceeds the first reservation (short junk
+    lines between the records): the formatter runs behind the device, the reservation grows mid-stream, and the
+    rows still come out complete and in input order"""
+    import random
+    rng = random.Random(77)
+    ns = 300
+    rows = [vcfgen.header(ns)]
+    pos = 1000
+    for k in range(24000):
+        pos += rng.randint(1, 40)
+        if k % 3 == 0:
+            gts = ["0|1" if rng.random() < 0.02 else ("1|1" if rng.random() < 0.01 else "0|0") for _ in range(ns)]
+            rows.append("\t".join(["chr2", str(pos), ".", "C", "T", ".", "PASS", ".", "GT"] + gts) + "\n")
+        else:
+            # far more lines per megabyte than the reservation assumes (it divides by the header width)
+            rows.extend(["chr2\t%d\t.\tA\tG\n" % pos] * (200 if k % 50 == 1 else 2))
+    vcf = "".join(rows).encode()
+    rc_o, out_o, log_o, n_o = orc.run(vcf)
+    assert rc_o == 0 and out_o.count(b"\n") > 1000
+    p = _run_cli(["--batchMB", "1"], vcf)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert p.stdout == (bv.string_header() + "\n").encode() + out_o
+    assert p.stderr.decode() == log_o
+
+
 def test_cli_large_stream(bv, golden_1kg):
     """the 200 MB 1KG regression input through the pipelined driver with small blocks"""
     vcf, want_sorted, hdr = golden_1kg
