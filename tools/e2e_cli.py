@@ -2,7 +2,7 @@
 """End-to-end CLI timing: synthetic rows -> file -> bystro-vcf (HIP) -> /dev/null, with the stage times of
 BVCF_TIMING, and (optionally) an md5 comparison with the oracle CLI on the same file.
 
-    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH]
+    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH] [--bgzf]
 
 Needs a GPU box.  The file is written to /dev/shm when it fits there, else /tmp, and removed afterwards.
 """
@@ -14,7 +14,28 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import benchgen as bg  # noqa: E402
+
+
+def _bgzf_part(args):
+    import bgzf
+    path, off, n = args
+    with open(path, "rb") as f:
+        f.seek(off)
+        return bgzf.bgzf_compress(f.read(n), level=1, eof_marker=False)
+
+
+def bgzf_file(src, dst, part=0xFF00 * 256):
+    """BGZF-compress src into dst with a process pool (test helper speed, not bgzip's)"""
+    import multiprocessing as mp
+    import bgzf
+    size = os.path.getsize(src)
+    jobs = [(src, off, min(part, size - off)) for off in range(0, size, part)]
+    with mp.Pool(min(16, os.cpu_count() or 1)) as pool, open(dst, "wb") as out:
+        for blob in pool.imap(_bgzf_part, jobs):
+            out.write(blob)
+        out.write(bgzf.bgzf_block(b""))
 
 CLI = os.path.join(ROOT, "bystro-vcf_amd", "bystro-vcf")
 ORACLE = os.path.join(ROOT, "oracle", "bvcf_oracle")
@@ -49,6 +70,12 @@ def main():
                 for first in range(0, rows, 25_000):
                     f.write(bg.rows_host(cfg, first, min(25_000, rows - first)))
         size = os.path.getsize(path)
+        text_path = path
+        if "--bgzf" in sys.argv:
+            t1 = time.perf_counter()
+            bgzf_file(path, path + ".gz")
+            print("bgzf: %.3f GB (%.1f s to compress)" % (os.path.getsize(path + ".gz") / 1e9, time.perf_counter() - t1), flush=True)
+            path = path + ".gz"
         print("file: %d rows, %.2f GB in %s (%.1f s to generate)" % (rows, size / 1e9, base, time.perf_counter() - t0), flush=True)
         env = dict(os.environ, BVCF_TIMING="1")
         extra = []
@@ -65,13 +92,13 @@ def main():
                   (it, p.returncode, dt, rows / dt / 1e6, size / dt / 1e9, tl[-1] if tl else ""), flush=True)
         if check:
             rc_g, m_g = md5_of([CLI], path)
-            rc_o, m_o = md5_of([ORACLE], path)
+            rc_o, m_o = md5_of([ORACLE], text_path)
             print("md5 hip %s (rc %d)  oracle %s (rc %d)  %s" % (m_g, rc_g, m_o, rc_o, "IDENTICAL" if m_g == m_o else "DIFFERENT"))
             if m_g != m_o:
                 sys.exit(1)
     finally:
-        for q in (path, path + ".arrow"):
-            if os.path.exists(q) and not (keep and q == path):
+        for q in (text_path, text_path + ".gz", path + ".arrow"):
+            if os.path.exists(q) and not (keep and q == text_path):
                 os.unlink(q)
 
 
