@@ -21,6 +21,10 @@ extern "C" {
 size_t ZSTD_compress(void *dst, size_t dstCapacity, const void *src, size_t srcSize, int compressionLevel);
 size_t ZSTD_compressBound(size_t srcSize);
 unsigned ZSTD_isError(size_t code);
+typedef struct ZSTD_CCtx_s ZSTD_CCtx;
+ZSTD_CCtx *ZSTD_createCCtx(void);
+size_t ZSTD_freeCCtx(ZSTD_CCtx *cctx);
+size_t ZSTD_compressCCtx(ZSTD_CCtx *cctx, void *dst, size_t dstCapacity, const void *src, size_t srcSize, int compressionLevel);
 }
 
 namespace {
@@ -194,6 +198,38 @@ struct Writer {
   std::string locus_data;
   std::vector<int8_t> rows;  // the batch as it arrives, row-major: rows[row * ns + s]; transposed at flush
   std::string err;
+  // the batch being written: a full batch is handed to a background thread (transpose, zstd, file write) while the
+  // next one fills; only that thread touches the file between open and close
+  std::thread bg;
+  bool bg_ok = true;
+  uint32_t bg_n_rows = 0;
+  std::vector<int32_t> bg_locus_off;
+  std::string bg_locus_data;
+  std::vector<int8_t> bg_rows;
+
+  bool wait_bg() {
+    if (bg.joinable()) bg.join();
+    return bg_ok;
+  }
+  // hands the filled batch to the background writer (after the previous one has finished)
+  bool flush_async() {
+    if (!wait_bg()) return false;
+    if (n_rows == 0) return true;
+    std::swap(rows, bg_rows);
+    std::swap(locus_off, bg_locus_off);
+    std::swap(locus_data, bg_locus_data);
+    bg_n_rows = n_rows;
+    if (rows.size() != bg_rows.size()) rows.resize(bg_rows.size());
+    n_rows = 0;
+    locus_off.clear();
+    locus_data.clear();
+    bg = std::thread([this]() { bg_ok = write_batch(bg_rows, bg_locus_off, bg_locus_data, bg_n_rows); });
+    return true;
+  }
+  bool flush() {
+    if (!flush_async()) return false;
+    return wait_bg();
+  }
 
   bool put(const void *p, size_t n) {
     if (n && fwrite(p, 1, n, f) != n) {
@@ -215,7 +251,8 @@ struct Writer {
     return put(&cont, 4) && put(&len, 4) && put(fb.data(), fb.size()) && pad8();
   }
   // one body buffer: int64 uncompressed length + zstd frame (or -1 + the raw bytes)
-  void add_buffer(std::string &body, std::vector<std::pair<int64_t, int64_t>> &bufs, const void *p, size_t n) {
+  void add_buffer(std::string &body, std::vector<std::pair<int64_t, int64_t>> &bufs, const void *p, size_t n,
+                  ZSTD_CCtx *cctx = nullptr) {
     const int64_t at = (int64_t)body.size();
     if (n == 0) {
       bufs.emplace_back(at, 0);
@@ -227,7 +264,9 @@ struct Writer {
     } else {
       const size_t bound = ZSTD_compressBound(n);
       body.resize(body.size() + 8 + bound);
-      const size_t got = ZSTD_compress(&body[(size_t)at + 8], bound, p, n, level);
+      // (a context per thread: the one-shot call builds and tears down its own for every 5 000-byte column)
+      const size_t got = cctx ? ZSTD_compressCCtx(cctx, &body[(size_t)at + 8], bound, p, n, level)
+                              : ZSTD_compress(&body[(size_t)at + 8], bound, p, n, level);
       int64_t raw = (int64_t)n;
       size_t used = got;
       if (ZSTD_isError(got) || got >= n) {  // not worth it: the format's "stored" form
@@ -241,7 +280,8 @@ struct Writer {
     }
     body.resize((body.size() + 7) & ~(size_t)7, '\0');
   }
-  bool flush() {
+  bool write_batch(const std::vector<int8_t> &rows, std::vector<int32_t> &locus_off, const std::string &locus_data,
+                   const uint32_t n_rows) {
     if (n_rows == 0) return true;
     std::string body;
     std::vector<std::pair<int64_t, int64_t>> bufs;
@@ -259,6 +299,7 @@ struct Writer {
       // 64 columns at a time: one cache line of every row feeds 64 column buffers that stay in L1/L2
       constexpr uint32_t kTile = 64;
       std::vector<int8_t> col((size_t)kTile * n_rows);
+      ZSTD_CCtx *cctx = level >= 0 ? ZSTD_createCCtx() : nullptr;
       const uint32_t s_lo = (uint32_t)((uint64_t)ns * t / n_thr), s_hi = (uint32_t)((uint64_t)ns * (t + 1) / n_thr);
       for (uint32_t s0 = s_lo; s0 < s_hi; s0 += kTile) {
         const uint32_t w = std::min(kTile, s_hi - s0);
@@ -268,9 +309,10 @@ struct Writer {
         }
         for (uint32_t j = 0; j < w; j++) {
           add_buffer(piece[t], piece_bufs[t], nullptr, 0);
-          add_buffer(piece[t], piece_bufs[t], &col[(size_t)j * n_rows], n_rows);
+          add_buffer(piece[t], piece_bufs[t], &col[(size_t)j * n_rows], n_rows, cctx);
         }
       }
+      if (cctx) ZSTD_freeCCtx(cctx);
     };
     if (n_thr <= 1) {
       work(0);
@@ -315,9 +357,6 @@ struct Writer {
     b.body_len = (int64_t)body.size();
     if (!put_message(fb, &b.meta_len) || !put(body.data(), body.size())) return false;
     blocks.push_back(b);
-    n_rows = 0;
-    locus_off.clear();
-    locus_data.clear();
     return true;
   }
 };
@@ -365,7 +404,7 @@ int bvcf_arrow_append(bvcf_arrow *a, const char *locus, uint32_t locus_len, cons
   w.locus_off.push_back((int32_t)w.locus_data.size());
   w.locus_data.append(locus, locus_len);
   if (w.ns) memcpy(&w.rows[(size_t)w.n_rows * w.ns], dosage, w.ns);
-  if (++w.n_rows == w.rows_per_batch && !w.flush()) return BVCF_E_IO;
+  if (++w.n_rows == w.rows_per_batch && !w.flush_async()) return BVCF_E_IO;
   return BVCF_OK;
 }
 
