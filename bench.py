@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--rows", type=int, default=131072, help="rows per step per GPU")
     ap.add_argument("--blocks", type=int, default=4, help="distinct resident batches per GPU")
     ap.add_argument("--profile", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--samples", type=int, default=0, help="experiment: another sample count for the profile (e.g. 100000 with --rows 640)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
     ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
@@ -113,7 +114,7 @@ def main():
 
     if args.profile == "c5" and args.path == 0:
         args.path = 1  # FORMAT is not plain GT: the host driver (choose_path) sends such files down the census path
-    cfg = bg.make_cfg(args.profile, align16=int(args.align16))
+    cfg = bg.make_cfg(args.profile, align16=int(args.align16), **({"n_samples": args.samples} if args.samples else {}))
     ns = cfg.n_samples
     # ---- synthetic batches, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)
     blocks, sizes = [], []

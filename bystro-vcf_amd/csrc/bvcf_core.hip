@@ -56,6 +56,7 @@ struct bvcf_ctx {
   int n_cu = 0;
   int gt_grid = 0, stream_grid = 0;
   bool fused = false;
+  bool wide = false;  // census path with k_gt_wide in front of k_gt (see kWideSamples)
   uint32_t tile_bytes = 0, tile_quota = 0;
   uint32_t n_samples = 0;
   uint32_t cmap_stride = 0;
@@ -244,6 +245,7 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.results = s.d_results;
   a.counters = s.d_counters;
   a.fused = c->fused ? 1u : 0u;
+  a.wide = c->wide ? 1u : 0u;
   a.tile_bytes = c->tile_bytes;
   a.tile_quota = c->tile_quota;
   a.n_tiles = c->fused ? (uint32_t)((nbytes + c->tile_bytes - 1) / c->tile_bytes) : 0u;
@@ -290,6 +292,10 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     hipLaunchKernelGGL(k_head, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
   if (a.n_samples) {
     if (ev_gt0) hipEventRecord(ev_gt0, st);
+    if (c->wide) {
+      hipMemsetAsync(a.results, 0, (size_t)a.max_tasks * sizeof(GtResult), st);
+      hipLaunchKernelGGL(k_gt_wide, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
+    }
     hipLaunchKernelGGL(k_gt, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     if (ev_gt1) hipEventRecord(ev_gt1, st);
     hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
@@ -401,7 +407,13 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   }
   uint32_t path = p->path;
   if (const char *e = getenv("BVCF_PATH")) path = (uint32_t)atoi(e);  // test / tuning override
-  c->fused = c->n_samples > 0 && (path == 2 || (path == 0 && p->n_header_fields >= 256));
+  // From kWideSamples samples up a line is hundreds of kilobytes and a batch holds too few of them to fill the GPU
+  // with one wave per line: the census path then splits the regular scan of a line over several waves, and is
+  // what `choose` picks.
+  const bool many_samples = c->n_samples >= kWideSamples;
+  c->fused = c->n_samples > 0 && (path == 2 || (path == 0 && p->n_header_fields >= 256 && !many_samples));
+  c->wide = !c->fused && many_samples;
+  if (const char *e = getenv("BVCF_WIDE")) c->wide = !c->fused && c->n_samples > 0 && atoi(e) != 0;  // test / tuning override
   c->tile_quota = c->tile_bytes / (p->n_header_fields - 1 + p->eol_chars) + 2;
   auto fail = [&](int rc) {
     g_create_err = c->err;

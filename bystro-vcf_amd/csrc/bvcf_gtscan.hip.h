@@ -123,6 +123,7 @@ struct FastAcc {
 constexpr uint32_t kSparseWords = 16;  // BVCF_CMAP_SPARSE_MAX entries, padded
 constexpr uint32_t kDenseMode = BVCF_CMAP_SPARSE_MAX + 1u;
 
+constexpr uint32_t kWideSamples = 32768;  // from here up the census path splits a line's regular scan over waves (k_gt_wide)
 constexpr uint32_t kStageChunks = 64;                 // class-map bytes staged in LDS per wave:
 constexpr uint32_t kStageBytes = kStageChunks * 64u;  // 64 chunks x 64 B = 4 KiB = 16 384 samples
 
@@ -235,11 +236,16 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
 
 // check_term: also require the byte after the last sample to be the line terminator (the caller
 // predicted the end of the line from the region's regular length)
+// [c_lo, c_hi) (optional; c_lo a multiple of kStageChunks): only these chunks of the region -- one wave's share of
+// a line that is split across waves (k_gt_wide).  st then holds the share's n_het / n_hom / n_miss only.
 __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint32_t ns, uint32_t allele, uint8_t *cmap,
-                                    uint8_t *stage, bool check_term, GtStats *st) {
+                                    uint8_t *stage, bool check_term, GtStats *st, uint32_t c_lo = 0,
+                                    uint32_t c_hi = 0xFFFFFFFFu) {
   const int lane = lane_id();
   const uint32_t table = (allele <= 9 ? (1u << (2u * allele)) : 0u) | (3u << 28);
   const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;
+  c_hi = min(c_hi, n_chunks);
+  const uint32_t f_hi = min(c_hi + 1u, n_chunks);  // loads go one chunk further: its first dword ends chunk c_hi - 1
   // dword-aligned loads, shift undone in registers (see realign).  The last field of a full last
   // chunk would need one dword past the chunks: such geometries (ns % 256 == 0) load unaligned.
   const uint32_t r = (ns & 255u) ? (s_begin & 3u) : 0u;
@@ -259,12 +265,12 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
     return c + 1 < n_chunks ? (uint32_t)__builtin_amdgcn_readfirstlane(nxt.x) : 0u;
   };
   FastAcc acc = {0, 0, 0, 0, kDenseMode};
-  if (cmap) zero_stage(stage, n_chunks);
+  if (cmap) zero_stage(stage, c_hi - c_lo);
   u32x4 va[kFastGroup], vb[kFastGroup];
 #pragma unroll
-  for (int g = 0; g < kFastGroup; g++) va[g] = (uint32_t)g < n_chunks ? fetch(g) : u32x4{0u, 0u, 0u, 0u};
+  for (int g = 0; g < kFastGroup; g++) va[g] = c_lo + g < f_hi ? fetch(c_lo + g) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int g = 0; g < kFastGroup; g++) vb[g] = (uint32_t)(kFastGroup + g) < n_chunks ? fetch(kFastGroup + g) : u32x4{0u, 0u, 0u, 0u};
+  for (int g = 0; g < kFastGroup; g++) vb[g] = c_lo + kFastGroup + g < f_hi ? fetch(c_lo + kFastGroup + g) : u32x4{0u, 0u, 0u, 0u};
   // the separator of the first field is the line's separator; mixed lines fail the frame test
   const uint32_t w0 = __builtin_amdgcn_alignbyte(__builtin_amdgcn_readfirstlane(va[0].y), __builtin_amdgcn_readfirstlane(va[0].x), r);
   const uint32_t sep = (w0 >> 8) & 0xFFu;
@@ -274,23 +280,23 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
   // is any value above 0xFF000000
   const uint32_t term_xor = check_term ? ((a.eol_byte ^ 0x09u) << 24) : 0xFFFFFFFFu;
 
-  for (uint32_t c0 = 0; c0 < n_chunks; c0 += 2 * kFastGroup) {
+  for (uint32_t c0 = c_lo; c0 < c_hi; c0 += 2 * kFastGroup) {
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
-      if (c0 + g < n_chunks)
+      if (c0 + g < c_hi)
         fast_chunk(realign(va[g], next0(c0 + g, g + 1 < kFastGroup ? va[g + 1 < kFastGroup ? g + 1 : 0] : vb[0]), r), c0 + g,
                    n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
-      if (c0 + 2 * kFastGroup + g < n_chunks) va[g] = fetch(c0 + 2 * kFastGroup + g);
+      if (c0 + 2 * kFastGroup + g < f_hi) va[g] = fetch(c0 + 2 * kFastGroup + g);
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
-      if (c0 + kFastGroup + g < n_chunks)
+      if (c0 + kFastGroup + g < c_hi)
         fast_chunk(realign(vb[g], next0(c0 + kFastGroup + g, g + 1 < kFastGroup ? vb[g + 1 < kFastGroup ? g + 1 : 0] : va[0]), r),
                    c0 + kFastGroup + g, n_chunks, ns, kref, table, cmap, stage, a.cmap_stride, term_xor, acc);
 #pragma unroll
     for (int g = 0; g < kFastGroup; g++)
-      if (c0 + 3 * kFastGroup + g < n_chunks) vb[g] = fetch(c0 + 3 * kFastGroup + g);
+      if (c0 + 3 * kFastGroup + g < f_hi) vb[g] = fetch(c0 + 3 * kFastGroup + g);
   }
   if (__any(acc.bad != 0)) return false;
   wave_sum3(acc.het, acc.hom, acc.miss, ns, &st->n_het, &st->n_hom, &st->n_miss);
@@ -444,7 +450,18 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
     uint32_t n_fields;
     // regular region: 4 bytes per sample, every dword of a lane is one "x|y<TAB>" field
     bool regular = false;
-    if (t.cend + 1u - t.s_begin == 4u * ns && gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, false, &st)) {
+    if (a.wide && t.cend + 1u - t.s_begin == 4u * ns && a.results[ti].pad == 0) {
+      // k_gt_wide scanned the region window by window and every window was regular: add up
+      const GtResult part = a.results[ti];
+      st.n_het = part.n_het;
+      st.n_hom = part.n_hom;
+      st.n_miss = part.n_miss;
+      st.ac = st.n_het + 2u * st.n_hom;
+      st.an = 2u * (ns - st.n_miss);
+      n_fields = ns;
+      regular = true;
+    } else if (!a.wide && t.cend + 1u - t.s_begin == 4u * ns &&
+               gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, false, &st)) {
       n_fields = ns;
       regular = true;
     } else {
@@ -466,6 +483,44 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
     }
   }
 }
+// ------------------------------------------------------------------ k_gt_wide: one wave per (task, window)
+// Cohorts of tens of thousands of samples and more: a 64 MiB batch holds a few hundred lines of several hundred
+// kilobytes each, far fewer than the GPU has waves.  The regular scan of a line is therefore split into windows of
+// kStageChunks chunks (16 384 samples, the span of the LDS class-map stage), one wave each; a window adds its counts
+// to the task's result with atomics (zeroed by the host before the launch) and writes its own stretch of the class
+// map.  k_gt, launched after it, turns the sums into the task's result -- or, if some window met a field that is
+// not regular, rescans the task with the general scan.
+__global__ __launch_bounds__(kWgThreads) void k_gt_wide(KernelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
+  uint8_t *stage = s_stage[threadIdx.x >> 6];
+  const int lane = lane_id();
+  const uint32_t ns = a.n_samples;
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t n_tasks = min(n_lines + a.counters->n_tasks, a.max_tasks);
+  const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;
+  const uint32_t n_win = (n_chunks + kStageChunks - 1u) / kStageChunks;
+  const unsigned long long n_items = (unsigned long long)n_tasks * n_win;
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  for (unsigned long long it = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); it < n_items; it += stride) {
+    const uint32_t ti = (uint32_t)(it / n_win), w = (uint32_t)(it % n_win);
+    const GtTask t = a.tasks[ti];
+    if (t.allele == 0 || t.cend + 1u - t.s_begin != 4u * ns) continue;  // k_gt's general scan
+    uint8_t *cm = t.cmap_off != BVCF_NO_CMAP ? a.cmap + t.cmap_off : nullptr;
+    GtStats st = {0, 0, 0, 0, 0};
+    const bool ok = gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, false, &st, w * kStageChunks, (w + 1u) * kStageChunks);
+    if (lane == 0) {
+      GtResult *r = &a.results[ti];
+      if (!ok) {
+        atomicOr(&r->pad, 1u);
+      } else {
+        if (st.n_het) atomicAdd(&r->n_het, st.n_het);
+        if (st.n_hom) atomicAdd(&r->n_hom, st.n_hom);
+        if (st.n_miss) atomicAdd(&r->n_miss, st.n_miss);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ k_dosage: one wave per output allele
 // --dosageOutput (main.go:306-342,576-584): the int8 row of every alleles[] slot that holds a record.  Runs after
 // k_finish, only when the ctx asks for it; every field goes through the general scan, which knows the allele

@@ -12,10 +12,13 @@ import vcfgen
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["census", "streaming"])
+@pytest.fixture(autouse=True, params=["census", "streaming", "census-wide"])
 def bvcf_path(request, monkeypatch):
-    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`)"""
-    monkeypatch.setenv("BVCF_PATH", "1" if request.param == "census" else "2")
+    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`), and on the census
+    path with the regular scan split over waves as it is for cohorts of >= 32 768 samples (k_gt_wide)"""
+    monkeypatch.setenv("BVCF_PATH", "2" if request.param == "streaming" else "1")
+    if request.param == "census-wide":
+        monkeypatch.setenv("BVCF_WIDE", "1")
     return request.param
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -152,6 +155,38 @@ def test_sample_name_widths(bv, name_len, delim):
     vcf = "".join(rows).encode()
     both(bv, vcf, {"fieldDelimiter": delim})
     both(bv, vcf, {"fieldDelimiter": delim, "keepId": True}, max_batch_bytes=1 << 16)
+
+
+@pytest.mark.parametrize("n_samples", [32768, 40001, 16384 * 3 + 255])
+def test_many_samples_split_scan(bv, n_samples, monkeypatch):
+    """cohorts of >= 32 768 samples: the regular scan of one line is split into 16 384-sample windows over several waves
+    (k_gt_wide, chosen by the library itself here).  Non-reference genotypes on both sides of every window boundary, a
+    line with one irregular field in the middle window (the whole task falls back to the general scan), multiallelic
+    lines, missing genotypes, mixed separators between windows"""
+    import random
+    monkeypatch.delenv("BVCF_WIDE", raising=False)
+    rng = random.Random(n_samples)
+    ns = n_samples
+    rows = [vcfgen.header(ns)]
+    edges = [e for w in range(1, ns // 16384 + 1) for e in (w * 16384 - 1, w * 16384) if e < ns]
+    for k in range(14):
+        alt = "G,T" if k % 4 == 1 else "G"
+        sep = "|" if k % 3 else "/"
+        gts = ["0%s0" % sep] * ns
+        for e in edges + [0, ns - 1] + [rng.randrange(ns) for _ in range(40)]:
+            gts[e] = rng.choice(["0%s1", "1%s1", ".%s.", "1%s0", "0%s2" if "," in alt else "0%s1"]) % sep
+        if k == 5:
+            gts[ns // 2] = "0|1:9"      # not a 4-byte field: the line's length is no longer 4*ns
+        if k == 6:
+            a, b = ns // 2, ns // 2 + 1  # same length, but two fields are not regular ("0|10", "|1" ...)
+            gts[a], gts[b] = "0|10", "|1"
+        if k == 7:
+            for i in range(20000, min(ns, 36000)):
+                gts[i] = gts[i].replace("|", "/")   # another separator from the second window on
+        rows.append("\t".join(["chr3", str(1000 + 7 * k), ".", "A", alt, ".", "PASS", ".", "GT"] + gts) + "\n")
+    vcf = "".join(rows).encode()
+    both(bv, vcf)
+    both(bv, vcf, {"keepId": True, "keepInfo": True}, max_batch_bytes=1 << 20)
 
 
 @pytest.mark.parametrize("n_samples", [300, 512, 1030])

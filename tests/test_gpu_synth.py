@@ -8,10 +8,13 @@ import oracle_lib as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["census", "streaming"])
+@pytest.fixture(autouse=True, params=["census", "streaming", "census-wide"])
 def bvcf_path(request, monkeypatch):
-    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`)"""
-    monkeypatch.setenv("BVCF_PATH", "1" if request.param == "census" else "2")
+    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`), and on the census
+    path with the regular scan split over waves as it is for cohorts of >= 32 768 samples (k_gt_wide)"""
+    monkeypatch.setenv("BVCF_PATH", "2" if request.param == "streaming" else "1")
+    if request.param == "census-wide":
+        monkeypatch.setenv("BVCF_WIDE", "1")
     return request.param
 
 
