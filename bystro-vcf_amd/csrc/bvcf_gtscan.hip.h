@@ -123,7 +123,7 @@ struct FastAcc {
 constexpr uint32_t kSparseWords = 16;  // BVCF_CMAP_SPARSE_MAX entries, padded
 constexpr uint32_t kDenseMode = BVCF_CMAP_SPARSE_MAX + 1u;
 
-constexpr uint32_t kWideSamples = 32768;  // from here up the census path splits a line's regular scan over waves (k_gt_wide)
+constexpr uint32_t kWideSamples = BVCF_WIDE_SAMPLES;  // from here up the census path splits a line's regular scan over waves (k_gt_wide)
 constexpr uint32_t kStageChunks = 64;                 // class-map bytes staged in LDS per wave:
 constexpr uint32_t kStageBytes = kStageChunks * 64u;  // 64 chunks x 64 B = 4 KiB = 16 384 samples
 

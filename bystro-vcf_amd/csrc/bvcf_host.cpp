@@ -515,6 +515,7 @@ struct Run {
 // sub-fields are scanned by the general path, for which the census path is the faster frame.
 uint32_t choose_path(const Run &R, const uint8_t *data, size_t n) {
   if (R.pre.header.size() < 256) return 0;  // the library's own rule (census for narrow files)
+  if (R.pre.header.size() >= 9 + (size_t)BVCF_WIDE_SAMPLES) return 0;  // very wide lines: the census path's split scan
   // FORMAT column (index 8) of the first record
   size_t pos = 0;
   for (int tabs = 0; pos < n && tabs < 8; pos++) {

@@ -87,6 +87,8 @@ enum {
  * The streaming path writes this form for alleles that few samples carry (most of a cohort file). */
 #define BVCF_ALLELE_CMAP_SPARSE 2u
 #define BVCF_CMAP_SPARSE_MAX 15u
+/* from this many samples up, path 0 / 1 split the regular genotype scan of one line over several waves */
+#define BVCF_WIDE_SAMPLES 32768u
 #define BVCF_NO_CMAP 0xFFFFFFFFu
 #define BVCF_DEVICE_PAD 64      /* bytes a device-resident block must own past nbytes */
 

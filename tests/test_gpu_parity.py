@@ -187,6 +187,12 @@ def test_many_samples_split_scan(bv, n_samples, monkeypatch):
     vcf = "".join(rows).encode()
     both(bv, vcf)
     both(bv, vcf, {"keepId": True, "keepInfo": True}, max_batch_bytes=1 << 20)
+    # left to itself the library takes the census path for such files (the host driver asks for "choose")
+    monkeypatch.delenv("BVCF_PATH", raising=False)
+    ctx = bv.Ctx(9 + ns)
+    assert ctx.path() == 1
+    ctx.close()
+    both(bv, vcf, {"allow": ""})
 
 
 @pytest.mark.parametrize("n_samples", [300, 512, 1030])
