@@ -93,6 +93,9 @@ struct KernelArgs {
   // streaming path
   uint32_t fused;        // 1: k_stream found the lines and scanned ALT #1
   uint32_t wide;         // 1: census path, regular scans split into windows over several waves (k_gt_wide)
+  uint32_t win_bytes;    // wide: bytes of a line's sample region per wave of the split general scan
+  uint32_t win_tabs_cap; // entries of win_tabs
+  uint32_t *win_tabs;    // wide: TABs per (line, window), see k_tabs_wide
   uint32_t tile_bytes;   // bytes of text a wave owns (lines belong to the tile they start in)
   uint32_t tile_quota;   // entries reserved per tile: a line that passes the field count is at
                          // least n_header - 1 + eol_chars bytes long

@@ -30,6 +30,8 @@ struct Slot {
   int8_t *d_dosage = nullptr;
   GtTask *d_tasks = nullptr;
   GtResult *d_results = nullptr;
+  uint32_t *d_win_tabs = nullptr;  // wide ctxs only
+  uint32_t win_tabs_cap = 0;
   StreamEntry *d_entries = nullptr;
   uint32_t *d_line_len = nullptr, *d_line_cmap = nullptr;
   BatchCounters *d_counters = nullptr;
@@ -57,6 +59,7 @@ struct bvcf_ctx {
   int gt_grid = 0, stream_grid = 0;
   bool fused = false;
   bool wide = false;  // census path with k_gt_wide in front of k_gt (see kWideSamples)
+  uint32_t win_bytes = 64u << 10;  // wide: bytes of a line's sample region per wave of the split general scan
   uint32_t tile_bytes = 0, tile_quota = 0;
   uint32_t n_samples = 0;
   uint32_t cmap_stride = 0;
@@ -122,6 +125,7 @@ void free_slot(Slot &s) {
   hipFree(s.d_dosage);
   hipFree(s.d_tasks);
   hipFree(s.d_results);
+  hipFree(s.d_win_tabs);
   hipFree(s.d_entries);
   hipFree(s.d_line_len);
   hipFree(s.d_line_cmap);
@@ -150,6 +154,8 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   hipFree(s.d_dosage);
   hipFree(s.d_tasks);
   hipFree(s.d_results);
+  hipFree(s.d_win_tabs);
+  s.d_win_tabs = nullptr;
   hipFree(s.d_line_len);
   hipFree(s.d_line_cmap);
   hipHostFree(s.h_lines);
@@ -180,6 +186,10 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   HIP_TRY(c, hipMalloc(&s.d_cmap, c->max_cmap + 64));
   HIP_TRY(c, hipMalloc(&s.d_tasks, c->max_alleles * sizeof(GtTask)));
   HIP_TRY(c, hipMalloc(&s.d_results, c->max_alleles * sizeof(GtResult)));
+  if (c->wide) {
+    s.win_tabs_cap = (uint32_t)std::min<uint64_t>(2 * (c->p.max_batch_bytes / c->win_bytes) + c->max_lines + 64, 0x7FFFFFFFu);
+    HIP_TRY(c, hipMalloc(&s.d_win_tabs, (size_t)s.win_tabs_cap * sizeof(uint32_t)));
+  }
   HIP_TRY(c, hipMalloc(&s.d_line_len, c->max_lines * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&s.d_line_cmap, c->max_lines * sizeof(uint32_t)));
   HIP_TRY(c, hipHostMalloc(&s.h_lines, c->max_lines * sizeof(bvcf_line), hipHostMallocDefault));
@@ -246,6 +256,9 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.counters = s.d_counters;
   a.fused = c->fused ? 1u : 0u;
   a.wide = c->wide ? 1u : 0u;
+  a.win_bytes = c->win_bytes;
+  a.win_tabs = s.d_win_tabs;
+  a.win_tabs_cap = s.d_win_tabs ? s.win_tabs_cap : 0u;
   a.tile_bytes = c->tile_bytes;
   a.tile_quota = c->tile_quota;
   a.n_tiles = c->fused ? (uint32_t)((nbytes + c->tile_bytes - 1) / c->tile_bytes) : 0u;
@@ -295,6 +308,10 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     if (c->wide) {
       hipMemsetAsync(a.results, 0, (size_t)a.max_tasks * sizeof(GtResult), st);
       hipLaunchKernelGGL(k_gt_wide, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
+      if (a.win_tabs) {
+        hipLaunchKernelGGL(k_tabs_wide, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
+        hipLaunchKernelGGL(k_gt_wide_general, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
+      }
     }
     hipLaunchKernelGGL(k_gt, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     if (ev_gt1) hipEventRecord(ev_gt1, st);
@@ -414,6 +431,10 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   c->fused = c->n_samples > 0 && (path == 2 || (path == 0 && p->n_header_fields >= 256 && !many_samples));
   c->wide = !c->fused && many_samples;
   if (const char *e = getenv("BVCF_WIDE")) c->wide = !c->fused && c->n_samples > 0 && atoi(e) != 0;  // test / tuning override
+  if (const char *e = getenv("BVCF_WIDE_WIN")) {  // test / tuning: window of the split general scan, bytes
+    const long v = atol(e);
+    if (v >= 64 && v <= (64l << 20)) c->win_bytes = (uint32_t)v;
+  }
   c->tile_quota = c->tile_bytes / (p->n_header_fields - 1 + p->eol_chars) + 2;
   auto fail = [&](int rc) {
     g_create_err = c->err;

@@ -311,14 +311,29 @@ __device__ inline bool gt_scan_fast(const KernelArgs &a, uint32_t s_begin, uint3
 // lane's first dword); everything else goes through the byte-serial restatement (classify_field).
 // *n_tabs receives the number of TABs in [s_begin, cend).
 // dos (optional): the sample's dosage -- altCount, 127 at most, -1 when missing (main.go:1117-1178) -- goes to dos[s]
+// win (optional): only the fields that START in [win->lo, win->hi) -- one wave's share of a line whose scan is split
+// over waves (k_gt_wide_general).  win->base = TABs of the region before win->lo, i.e. the sample index of the field
+// that holds byte win->lo.  The class map is then zeroed by the caller's predecessor, not here; st and *n_tabs are
+// the share's.
+struct ScanWindow {
+  uint32_t lo, hi, base;
+};
 __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, uint32_t cend, uint32_t ns,
                                        uint32_t allele, uint8_t *cmap, GtStats *st, uint32_t *n_tabs,
-                                       int8_t *dos = nullptr) {
+                                       int8_t *dos = nullptr, const ScanWindow *win = nullptr) {
   const int lane = lane_id();
+  const uint32_t line_begin = s_begin;
+  const uint32_t sample_base = win ? win->base : 0u;
+  const uint32_t starts_end = win ? win->hi : cend;  // fields starting from here on belong to the next share
+  bool first_is_start = true;
+  if (win) {
+    first_is_start = win->lo == line_begin || a.buf[win->lo - 1u] == '\t';
+    s_begin = win->lo;
+  }
   uint32_t a_nd = 1;
   for (uint32_t t = allele; t >= 10; t /= 10) a_nd++;
   const uint32_t table = (allele <= 9 ? (1u << (2u * allele)) : 0u) | (3u << 28);
-  if (cmap) {  // zero this allele's map, then OR classes in
+  if (cmap && !win) {  // zero this allele's map, then OR classes in
     for (uint32_t i = lane * 4u; i < a.cmap_stride; i += kWave * 4u) *reinterpret_cast<uint32_t *>(cmap + i) = 0u;
     __builtin_amdgcn_s_waitcnt(0);  // stores retired before the atomics below touch the same words
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -332,7 +347,7 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
   constexpr int kGenDepth = 4;
   const uint32_t r0 = s_begin & 3u, lb = s_begin - r0;
   const uint32_t cap_off = (a.cap - 16u) & ~3u;
-  const uint32_t n_chunks = cend > s_begin ? (cend - lb + kChunk - 1u) / kChunk : 0u;
+  const uint32_t n_chunks = starts_end > s_begin ? (starts_end - lb + kChunk - 1u) / kChunk : 0u;
   auto fetch = [&](uint32_t c) -> u32x4 { return ld_stream(a.buf + min(lb + c * kChunk + 16u * lane, cap_off)); };
   u32x4 vb[kGenDepth];
 #pragma unroll
@@ -344,7 +359,7 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
       if (c < n_chunks) {
         const u32x4 v = vb[j];
         const uint32_t off = lb + c * kChunk + 16u * lane;
-        uint32_t valid = low_bits16((int)cend - (int)off);
+        uint32_t valid = low_bits16((int)starts_end - (int)off);
         if (off < s_begin) valid &= ~low_bits16((int)s_begin - (int)off);  // lane 0 of the first chunk
         const uint32_t m = eq_mask16(v, '\t') & valid;
         uint32_t tot;
@@ -352,7 +367,7 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
         // field starts: the byte after each TAB, plus the region start.  The previous lane's last byte comes
         // over one wave_shr DPP move (lane 0: the previous chunk's lane 63)
         uint32_t starts = (m << 1) | ((uint32_t)__builtin_amdgcn_update_dpp((int)prev_last_tab, (int)(m >> 15), 0x138, 0xF, 0xF, false) & 1u);
-        if (c == 0 && lane == 0) starts |= 1u << r0;
+        if (c == 0 && lane == 0 && first_is_start) starts |= 1u << r0;
         starts &= valid & 0xFFFFu;
         // bytes 16..19 of this lane's window: the next lane's first dword (next chunk's for lane 63)
         const uint32_t nx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)vb[(j + 1) % kGenDepth].x);
@@ -361,7 +376,7 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
           const uint32_t k = __ffs(starts) - 1;
           starts &= starts - 1;
           // sample index = TABs before this byte
-          const uint32_t s = tabs_before + pre + __popc(m & ((1u << k) - 1u));
+          const uint32_t s = sample_base + tabs_before + pre + __popc(m & ((1u << k) - 1u));
           // four real bytes c0 c1 c2 c3 of the field, from registers
           const bool in4 = off + k + 4u <= cend;
           const uint32_t i = k >> 2;
@@ -411,11 +426,11 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
     }
   }
   // a field that starts exactly at cend (empty last field) was not visited above
-  if (lane == 0) {
-    const bool empty_last = (cend == s_begin) || (cend > s_begin && a.buf[cend - 1] == '\t');
-    if (empty_last && tabs_before < ns) {
+  if (lane == 0 && starts_end == cend) {
+    const bool empty_last = (cend == line_begin) || (cend > line_begin && a.buf[cend - 1] == '\t');
+    if (empty_last && sample_base + tabs_before < ns) {
       an += 1;  // "" is one non-matching allele token
-      if (dos) dos[tabs_before] = 0;
+      if (dos) dos[sample_base + tabs_before] = 0;
     }
   }
   st->ac = wave_sum(ac);
@@ -464,6 +479,15 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
                gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, false, &st)) {
       n_fields = ns;
       regular = true;
+    } else if (a.wide && a.results[ti].pad == 2u) {
+      // k_gt_wide_general summed the windows of this line
+      const GtResult part = a.results[ti];
+      st.ac = part.ac;
+      st.an = part.an;
+      st.n_het = part.n_het;
+      st.n_hom = part.n_hom;
+      st.n_miss = part.n_miss;
+      n_fields = part.n_fields + 1u;
     } else {
       uint32_t tabs;
       gt_scan_general(a, t.s_begin, t.cend, ns, t.allele, cm, &st, &tabs);
@@ -517,6 +541,98 @@ __global__ __launch_bounds__(kWgThreads) void k_gt_wide(KernelArgs a) {
         if (st.n_hom) atomicAdd(&r->n_hom, st.n_hom);
         if (st.n_miss) atomicAdd(&r->n_miss, st.n_miss);
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ wide lines, fields beyond GT
+// The general scan of a line whose sample region is not the 4-byte grid, split over waves: windows of a.win_bytes of
+// the region.  A field's sample index is the number of TABs before it, so the windows' TAB counts come first
+// (k_tabs_wide, which also zeroes the class maps), and each window of k_gt_wide_general starts from the sum of the
+// counts before it.  Counts are kept per line (the further ALT indices of a line share them) at
+// win_tabs[s_begin / win_bytes + line + w]: consecutive lines cannot collide there.
+__device__ __forceinline__ uint32_t wide_windows(const KernelArgs &a, const GtTask &t) {
+  const uint32_t len = t.cend - t.s_begin;
+  return len ? (len + a.win_bytes - 1u) / a.win_bytes : 1u;
+}
+__device__ __forceinline__ uint32_t wide_slot(const KernelArgs &a, const GtTask &t) { return t.s_begin / a.win_bytes + t.line; }
+// tasks scanned window by window by the two kernels below (the others are k_gt_wide's, or have no scan)
+__device__ __forceinline__ bool wide_general_task(const KernelArgs &a, const GtTask &t) {
+  return t.allele != 0 && t.cend >= t.s_begin && t.cend + 1u - t.s_begin != 4u * a.n_samples &&
+         wide_slot(a, t) + wide_windows(a, t) <= a.win_tabs_cap;
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_tabs_wide(KernelArgs a) {
+  const int lane = lane_id();
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t n_tasks = min(n_lines + a.counters->n_tasks, a.max_tasks);
+  const uint32_t w_max = a.counters->pad[1] / a.win_bytes + 1u;  // pad[1]: the longest sample region (k_head)
+  const unsigned long long n_items = (unsigned long long)n_tasks * w_max;
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  const uint32_t cap_off = (a.cap - 16u) & ~3u;
+  for (unsigned long long it = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); it < n_items; it += stride) {
+    const uint32_t ti = (uint32_t)(it / w_max), w = (uint32_t)(it % w_max);
+    const GtTask t = a.tasks[ti];
+    if (!wide_general_task(a, t)) continue;
+    const uint32_t n_win = wide_windows(a, t);
+    if (w >= n_win) continue;
+    // this window's stretch of the task's class map
+    if (t.cmap_off != BVCF_NO_CMAP) {
+      const uint32_t words = a.cmap_stride / 4u;
+      const uint32_t lo = (uint32_t)((unsigned long long)words * w / n_win), hi = (uint32_t)((unsigned long long)words * (w + 1u) / n_win);
+      uint32_t *cm = reinterpret_cast<uint32_t *>(a.cmap + t.cmap_off);
+      for (uint32_t i = lo + lane; i < hi; i += kWave) cm[i] = 0u;
+    }
+    if (ti >= n_lines) continue;  // a further ALT index: the line's own task counts
+    const uint32_t lo = t.s_begin + w * a.win_bytes, hi = min(lo + a.win_bytes, t.cend);
+    const uint32_t lb = lo & ~3u;
+    uint32_t cnt = 0;
+    for (uint32_t off = lb + 16u * lane; off < hi; off += kChunk) {
+      const u32x4 v = ld_stream(a.buf + min(off, cap_off));
+      uint32_t valid = low_bits16((int)hi - (int)off);
+      if (off < lo) valid &= ~low_bits16((int)lo - (int)off);
+      cnt += __popc(eq_mask16(v, '\t') & valid);
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) a.win_tabs[wide_slot(a, t) + w] = cnt;
+  }
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_gt_wide_general(KernelArgs a) {
+  const int lane = lane_id();
+  const uint32_t ns = a.n_samples;
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t n_tasks = min(n_lines + a.counters->n_tasks, a.max_tasks);
+  const uint32_t w_max = a.counters->pad[1] / a.win_bytes + 1u;
+  const unsigned long long n_items = (unsigned long long)n_tasks * w_max;
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  for (unsigned long long it = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); it < n_items; it += stride) {
+    const uint32_t ti = (uint32_t)(it / w_max), w = (uint32_t)(it % w_max);
+    const GtTask t = a.tasks[ti];
+    if (!wide_general_task(a, t)) continue;
+    const uint32_t n_win = wide_windows(a, t);
+    if (w >= n_win) continue;
+    // TABs of the region before this window
+    const uint32_t slot = wide_slot(a, t);
+    uint32_t before = 0;
+    for (uint32_t j = lane; j < w; j += kWave) before += a.win_tabs[slot + j];
+    ScanWindow win;
+    win.base = wave_sum(before);
+    win.lo = t.s_begin + w * a.win_bytes;
+    win.hi = w + 1u == n_win ? t.cend : win.lo + a.win_bytes;
+    uint8_t *cm = t.cmap_off != BVCF_NO_CMAP ? a.cmap + t.cmap_off : nullptr;
+    GtStats st = {0, 0, 0, 0, 0};
+    uint32_t tabs = 0;
+    gt_scan_general(a, t.s_begin, t.cend, ns, t.allele, cm, &st, &tabs, nullptr, &win);
+    if (lane == 0) {
+      GtResult *r = &a.results[ti];
+      if (st.ac) atomicAdd(&r->ac, st.ac);
+      if (st.an) atomicAdd(&r->an, st.an);
+      if (st.n_het) atomicAdd(&r->n_het, st.n_het);
+      if (st.n_hom) atomicAdd(&r->n_hom, st.n_hom);
+      if (st.n_miss) atomicAdd(&r->n_miss, st.n_miss);
+      if (tabs) atomicAdd(&r->n_fields, tabs);
+      if (w == 0) atomicOr(&r->pad, 2u);  // "summed by windows": k_gt only finishes the result
     }
   }
 }

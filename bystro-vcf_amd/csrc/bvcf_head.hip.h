@@ -99,6 +99,8 @@ __device__ inline void put_task(const KernelArgs &a, uint32_t ti, uint32_t line,
     t.cmap_off = cmap_off;
     t.pad[0] = t.pad[1] = t.pad[2] = 0;
     a.tasks[ti] = t;
+    // (wide lines: the longest sample region bounds the windows per task of the split scans)
+    if (a.wide && allele != 0 && cend >= s_begin) atomicMax(&a.counters->pad[1], cend - s_begin);
   }
 }
 

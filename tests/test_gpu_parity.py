@@ -19,6 +19,7 @@ def bvcf_path(request, monkeypatch):
     monkeypatch.setenv("BVCF_PATH", "2" if request.param == "streaming" else "1")
     if request.param == "census-wide":
         monkeypatch.setenv("BVCF_WIDE", "1")
+        monkeypatch.setenv("BVCF_WIDE_WIN", "1000")  # the general scan of one line in 1000-byte shares
     return request.param
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -193,6 +194,28 @@ def test_many_samples_split_scan(bv, n_samples, monkeypatch):
     assert ctx.path() == 1
     ctx.close()
     both(bv, vcf, {"allow": ""})
+
+
+def test_many_samples_split_general_scan(bv, monkeypatch):
+    """>= 32 768 samples with sub-fields beyond GT: the general scan of one line runs as 64 KiB shares over several
+    waves, each starting from the TAB count of the shares before it"""
+    import random
+    monkeypatch.delenv("BVCF_WIDE", raising=False)
+    monkeypatch.delenv("BVCF_WIDE_WIN", raising=False)
+    ns = 33000
+    rng = random.Random(5)
+    rows = [vcfgen.header(ns)]
+    for k in range(10):
+        rows.append(vcfgen.gen_line(rng, ns, 2000 + 13 * k, fmt_extra=True, weird=0.02 if k % 2 else 0.0,
+                                    filters=("PASS", ".")))
+    # a line whose fields are long enough for a field to span a whole share, and one with empty trailing fields
+    gts = ["0/1:" + "7" * rng.randint(1, 90000) if i == 17 else rng.choice(["0/0:1", "0/1:22", "./.:0", "1/1:3"]) for i in range(ns)]
+    rows.append("\t".join(["chr9", "777", ".", "C", "A", ".", "PASS", ".", "GT:X"] + gts) + "\n")
+    gts = [rng.choice(["0|0:5", "1|0:6", "1:1", "."]) for _ in range(ns - 2)] + ["", ""]
+    rows.append("\t".join(["chr9", "778", ".", "C", "A,T", ".", "PASS", ".", "GT:X"] + gts) + "\n")
+    vcf = "".join(rows).encode()
+    both(bv, vcf, {"allow": ""})
+    both(bv, vcf, {"allow": "", "keepInfo": True}, max_batch_bytes=4 << 20)
 
 
 @pytest.mark.parametrize("n_samples", [300, 512, 1030])

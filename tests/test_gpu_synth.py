@@ -15,6 +15,7 @@ def bvcf_path(request, monkeypatch):
     monkeypatch.setenv("BVCF_PATH", "2" if request.param == "streaming" else "1")
     if request.param == "census-wide":
         monkeypatch.setenv("BVCF_WIDE", "1")
+        monkeypatch.setenv("BVCF_WIDE_WIN", "1000")  # the general scan of one line in 1000-byte shares
     return request.param
 
 
