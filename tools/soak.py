@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential soak (not part of the test suite): many random VCF shapes through the HIP path and the
-oracle, both device paths, TSV + log + dosage rows compared.  usage: python tools/soak.py [n_cases] [seed0]"""
+oracle, both device paths and the split scans of very wide lines, TSV + log + dosage rows compared.  usage: python tools/soak.py [n_cases] [seed0]"""
 import os
 import random
 import sys
@@ -28,8 +28,14 @@ for i in range(n_cases):
     cfg = rng.choice([{"allow": ""}, {}, {"keepId": True, "keepInfo": True, "keepPos": True, "exclude": "q10"}])
     rc_o, out_o, log_o, n_o = orc.run(vcf, cfg)
     want_dos = orc.run_dosage(vcf, cfg) if ns else []
-    for path in ("1", "2"):
-        os.environ["BVCF_PATH"] = path
+    for path in ("1", "2", "wide"):
+        # "wide": the census path with the scans of one line split over waves, as for cohorts of >= 32 768 samples
+        os.environ["BVCF_PATH"] = "1" if path == "wide" else path
+        os.environ.pop("BVCF_WIDE", None)
+        os.environ.pop("BVCF_WIDE_WIN", None)
+        if path == "wide":
+            os.environ["BVCF_WIDE"] = "1"
+            os.environ["BVCF_WIDE_WIN"] = str(rng.choice([64, 100, 777, 1024, 4096, 65536]))
         with tempfile.TemporaryDirectory() as td:
             c = dict(cfg)
             if ns:
@@ -48,5 +54,5 @@ for i in range(n_cases):
                 i, seed0 + i, path, ns, n_lines, weird, fmt_extra, eol, cfg), flush=True)
     if i % 20 == 19:
         print("%d cases done, %d mismatches" % (i + 1, bad), flush=True)
-print("soak: %d cases x 2 paths, %d mismatches" % (n_cases, bad))
+print("soak: %d cases x 3 modes, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)
