@@ -408,7 +408,11 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   c->cmap_stride = ((c->n_samples + 3) / 4 + 15) & ~15u;
   c->dosage_stride = p->want_dosage && c->n_samples ? ((c->n_samples + 15) & ~15u) : 0u;
   const uint64_t min_line = std::max<uint64_t>(48, 2ull * p->n_header_fields);
-  c->max_lines = p->max_lines ? p->max_lines : c->p.max_batch_bytes / min_line + 4096;
+  // (the slack is for short lines -- comments, junk -- between the records; every listed line owns a class-map slot
+  // on the census path, so for very wide cohorts the slack is what 32 MiB of maps can hold: a batch that needs more
+  // grows the reservation, BVCF_E_CAPACITY)
+  const uint64_t slack = std::min<uint64_t>(4096, std::max<uint64_t>(64, (32ull << 20) / std::max<uint32_t>(c->cmap_stride, 1u)));
+  c->max_lines = p->max_lines ? p->max_lines : c->p.max_batch_bytes / min_line + slack;
   c->max_alleles = p->max_alleles ? p->max_alleles : 2 * c->max_lines + 1024;
   if (c->max_alleles < c->max_lines + 64) c->max_alleles = c->max_lines + 64;  // slot i belongs to line i
   c->max_cmap = p->cmap_bytes ? p->cmap_bytes : (c->max_lines + c->max_lines / 2) * (uint64_t)c->cmap_stride + (1ull << 20);

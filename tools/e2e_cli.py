@@ -2,7 +2,7 @@
 """End-to-end CLI timing: synthetic rows -> file -> bystro-vcf (HIP) -> /dev/null, with the stage times of
 BVCF_TIMING, and (optionally) an md5 comparison with the oracle CLI on the same file.
 
-    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH] [--bgzf]
+    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH] [--bgzf] [--samples=N]
 
 Needs a GPU box.  The file is written to /dev/shm when it fits there, else /tmp, and removed afterwards.
 """
@@ -56,7 +56,8 @@ def main():
     rows = int(args[0]) if args else 400_000
     profile = args[1] if len(args) > 1 else "c3"
     check = "--check" in sys.argv
-    cfg = bg.make_cfg(profile)
+    over = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--samples=")]
+    cfg = bg.make_cfg(profile, **({"n_samples": over[0]} if over else {}))
     base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     path = os.path.join(base, "bvcf_e2e_%d.vcf" % os.getpid())
     keep = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--keep=")]
@@ -67,8 +68,9 @@ def main():
         if not (keep and os.path.exists(path)):
             with open(path, "wb") as f:
                 f.write(bg.header(cfg))
-                for first in range(0, rows, 25_000):
-                    f.write(bg.rows_host(cfg, first, min(25_000, rows - first)))
+                step = max(1, min(25_000, (256 << 20) // (4 * max(cfg.n_samples, 1) + 200)))  # ~256 MB at a time
+                for first in range(0, rows, step):
+                    f.write(bg.rows_host(cfg, first, min(step, rows - first)))
         size = os.path.getsize(path)
         text_path = path
         if "--bgzf" in sys.argv:
