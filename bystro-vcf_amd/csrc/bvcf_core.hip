@@ -317,6 +317,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     if (ev_gt1) hipEventRecord(ev_gt1, st);
     hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
     if (a.dosage) hipLaunchKernelGGL(k_dosage, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
+    if (a.dosage && c->wide && a.win_tabs) hipLaunchKernelGGL(k_dosage_wide, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
   } else {
     if (ev_gt0) hipEventRecord(ev_gt0, st);
     if (ev_gt1) hipEventRecord(ev_gt1, st);

@@ -583,7 +583,8 @@ __global__ __launch_bounds__(kWgThreads) void k_tabs_wide(KernelArgs a) {
       uint32_t *cm = reinterpret_cast<uint32_t *>(a.cmap + t.cmap_off);
       for (uint32_t i = lo + lane; i < hi; i += kWave) cm[i] = 0u;
     }
-    if (ti >= n_lines) continue;  // a further ALT index: the line's own task counts
+    if (ti >= n_lines) continue;  // a further ALT index: the line's own task counts (k_head always gives an evaluated
+                                  // line its ALT #1 task on this path: the scan also settles the field count)
     const uint32_t lo = t.s_begin + w * a.win_bytes, hi = min(lo + a.win_bytes, t.cend);
     const uint32_t lb = lo & ~3u;
     uint32_t cnt = 0;
@@ -641,11 +642,15 @@ __global__ __launch_bounds__(kWgThreads) void k_gt_wide_general(KernelArgs a) {
 // --dosageOutput (main.go:306-342,576-584): the int8 row of every alleles[] slot that holds a record.  Runs after
 // k_finish, only when the ctx asks for it; every field goes through the general scan, which knows the allele
 // count of any ploidy (the 2-bit class of the label path cannot tell "1" from "1|1").
-__global__ __launch_bounds__(kWgThreads) void k_dosage(KernelArgs a) {
+template <bool share_of_row>
+__device__ __forceinline__ void k_dosage_body(const KernelArgs &a) {
   const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
   const uint32_t n_alleles = min(n_lines + a.counters->n_alleles, a.max_alleles);
   const uint32_t stride = gridDim.x * kWavesPerWg;
-  for (uint32_t k = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); k < n_alleles; k += stride) {
+  const uint32_t w_max = share_of_row ? a.counters->pad[1] / a.win_bytes + 1u : 1u;
+  const unsigned long long n_items = (unsigned long long)n_alleles * w_max;
+  for (unsigned long long it = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); it < n_items; it += stride) {
+    const uint32_t k = (uint32_t)(it / w_max), w = (uint32_t)(it % w_max);
     const bvcf_allele r = a.alleles[k];
     const uint32_t li = k < n_lines ? k : r.line;
     if (li >= n_lines) continue;
@@ -656,6 +661,7 @@ __global__ __launch_bounds__(kWgThreads) void k_dosage(KernelArgs a) {
     int8_t *row = a.dosage + (size_t)k * a.dosage_stride;
     const int lane = lane_id();
     if (r.cmap_off != BVCF_NO_CMAP && r.gt_task < a.max_tasks && a.results[r.gt_task].regular) {
+      if (share_of_row) continue;
       // the scan that produced this allele's class map was the regular one: the row is the map, 2 bits -> int8
       const uint8_t *cm = a.cmap + r.cmap_off;
       const uint32_t n_bytes = (a.n_samples + 3u) / 4u;
@@ -677,10 +683,38 @@ __global__ __launch_bounds__(kWgThreads) void k_dosage(KernelArgs a) {
       }
       continue;
     }
+    GtTask t;  // the line's sample region, as put_task described it
+    t.line = li;
+    t.allele = r.alt_idx + 1u;
+    t.s_begin = L.off + L.fend[8] + 1u;
+    t.cend = L.off + L.len;
+    if (a.wide && wide_general_task(a, t)) {
+      // split over waves like the scan that counted it; the TAB counts per share are still in win_tabs
+      if (!share_of_row) continue;
+    } else if (share_of_row) {
+      continue;
+    }
     GtStats st;
     uint32_t tabs;
-    gt_scan_general(a, L.off + L.fend[8] + 1u, L.off + L.len, a.n_samples, r.alt_idx + 1u, nullptr, &st, &tabs, row);
+    if (!share_of_row) {
+      gt_scan_general(a, t.s_begin, t.cend, a.n_samples, t.allele, nullptr, &st, &tabs, row);
+      continue;
+    }
+    const uint32_t n_win = wide_windows(a, t);
+    if (w >= n_win) continue;
+    const uint32_t slot = wide_slot(a, t);
+    uint32_t before = 0;
+    for (uint32_t j = lane; j < w; j += kWave) before += a.win_tabs[slot + j];
+    ScanWindow win;
+    win.base = wave_sum(before);
+    win.lo = t.s_begin + w * a.win_bytes;
+    win.hi = w + 1u == n_win ? t.cend : win.lo + a.win_bytes;
+    gt_scan_general(a, t.s_begin, t.cend, a.n_samples, t.allele, nullptr, &st, &tabs, row, &win);
   }
 }
+
+__global__ __launch_bounds__(kWgThreads) void k_dosage(KernelArgs a) { k_dosage_body<false>(a); }
+// wide lines with fields beyond GT: one wave per (output allele, share of the line), see k_gt_wide_general
+__global__ __launch_bounds__(kWgThreads) void k_dosage_wide(KernelArgs a) { k_dosage_body<true>(a); }
 
 }  // namespace bvcf_dev
