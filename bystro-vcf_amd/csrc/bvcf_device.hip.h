@@ -10,8 +10,14 @@
 //                                                                (main.go:535-545, 723-1038)
 //   k_gt           one wavefront per task: the per-sample GT byte scan -> ac/an/het/hom/missing
 //                  and the 2-bit class map.  THE HBM-bound kernel.   (main.go:1042-1194)
+//   (from 32 768 samples up, in front of k_gt: the scans of one line split over waves --
+//    k_gt_wide          one wave per (task, window of 16 384 samples) of a regular region
+//    k_tabs_wide        TABs per 64 KiB share of an irregular region (a field's sample index = TABs before it)
+//    k_gt_wide_general  one wave per (task, share): the general scan of the fields that start in the share
+//    k_gt then adds up, or rescans a task whose regular windows met an irregular field)
 //   k_finish       field-count verdict per line, scan results into the allele records
 //   k_dosage       (bvcf_params.want_dosage) one wave per output allele: the int8 dosage row
+//                  (k_dosage_wide: per share, for the lines k_gt_wide_general scanned)
 //                                                                (main.go:1069-1178)
 //
 // Streaming variant for files with samples (KernelArgs.fused): the census, its scans, the scatter
