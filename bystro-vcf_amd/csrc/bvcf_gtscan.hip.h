@@ -205,7 +205,7 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
       if (acc.n_sp + cnt <= BVCF_CMAP_SPARSE_MAX) {
         const uint32_t at = acc.n_sp + __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
         if (byte) sp[at] = ((c * 64u + (uint32_t)lane) << 8) | byte;
-        acc.n_sp += cnt;
+        acc.n_sp = bcast0(acc.n_sp + cnt);  // (kept provably wave-uniform: the tests on it stay scalar branches)
       } else {
         // too many for the list: from here on the line is a map.  Replay the entries into the zeroed stage.
         zero_stage(stage, n_chunks);
@@ -215,7 +215,7 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        acc.n_sp = kDenseMode;
+        acc.n_sp = bcast0(kDenseMode);
       }
     }
     if (cmap && (!sp || acc.n_sp >= kDenseMode)) stage[(c % kStageChunks) * 64u + lane] = (uint8_t)byte;  // the stage starts zeroed

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           hv = head_at(hvc_ok ? peB + 1u : sA);
           STAMP(1);
           // ---- scan A, re-issuing each register for B
-          const uint32_t cmA = map_slot();
+          const uint32_t cmA = bcast0(map_slot());  // (wave-uniform by construction; tell the compiler)
           uint8_t *cm = cmA != BVCF_NO_CMAP ? a.cmap + cmA : nullptr;
           // the class map starts as a sparse list (nothing to zero) when a list fits the map's slot
 #ifdef BVCF_EXP_NO_SPARSE
