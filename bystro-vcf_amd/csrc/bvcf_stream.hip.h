@@ -147,7 +147,9 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   uint8_t *stage = s_stage[threadIdx.x >> 6];
   uint32_t *sparse = s_sparse[threadIdx.x >> 6];
   const int lane = lane_id();
-  const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  // (threadIdx.x >> 6 is the same in all 64 lanes, which the compiler cannot know: without the broadcast everything
+  // derived from the wave index -- tile numbers, run bounds, class-map slots -- lives in vector registers)
+  const uint32_t wave = bcast0(blockIdx.x * kWavesPerWg + (threadIdx.x >> 6));
   const uint32_t n_waves = gridDim.x * kWavesPerWg;
   const uint32_t ns = a.n_samples;
   const uint32_t nb = a.nbytes;
