@@ -154,6 +154,13 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) 
 
 __device__ __forceinline__ uint32_t bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// The wave's index inside its workgroup / in the grid, as values the compiler knows to be wave-uniform: threadIdx.x >> 6
+// is the same in all 64 lanes, but only a readfirstlane tells the compiler so -- without it everything derived from
+// the index (task numbers, tile bounds, the task descriptor loaded with it) lives in vector registers and every test
+// on it is compiled as a divergent branch.
+__device__ __forceinline__ uint32_t wave_in_wg() { return bcast0(threadIdx.x >> 6); }
+__device__ __forceinline__ uint32_t wave_in_grid() { return blockIdx.x * kWavesPerWg + wave_in_wg(); }
+
 // 16 bytes at buf+off for this lane (any alignment); zeros if the window leaves [0, cap)
 __device__ __forceinline__ u32x4 load16(const uint8_t *buf, uint32_t off, uint32_t cap) {
   u32x4 v = {0u, 0u, 0u, 0u};

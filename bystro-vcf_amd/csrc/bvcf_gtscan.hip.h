@@ -445,7 +445,7 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
 
 __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
-  uint8_t *stage = s_stage[threadIdx.x >> 6];
+  uint8_t *stage = s_stage[wave_in_wg()];
   const int lane = lane_id();
   const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
   const uint32_t n_tasks = min(n_lines + a.counters->n_tasks, a.max_tasks);
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
   const uint32_t ns = a.n_samples;
   // streaming path: ALT #1 of every regular line is already scanned; only the slots past n_lines
   // (further ALT indices, and lines k_stream merely delimited) hold tasks
-  uint32_t ti = (a.fused ? n_lines : 0u) + blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  uint32_t ti = (a.fused ? n_lines : 0u) + wave_in_grid();
   GtTask nxt = GtTask{};
   if (ti < n_tasks) nxt = a.tasks[ti];
   for (; ti < n_tasks; ti += stride) {
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
 // not regular, rescans the task with the general scan.
 __global__ __launch_bounds__(kWgThreads) void k_gt_wide(KernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
-  uint8_t *stage = s_stage[threadIdx.x >> 6];
+  uint8_t *stage = s_stage[wave_in_wg()];
   const int lane = lane_id();
   const uint32_t ns = a.n_samples;
   const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt_wide(KernelArgs a) {
   const uint32_t n_win = (n_chunks + kStageChunks - 1u) / kStageChunks;
   const unsigned long long n_items = (unsigned long long)n_tasks * n_win;
   const uint32_t stride = gridDim.x * kWavesPerWg;
-  for (unsigned long long it = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); it < n_items; it += stride) {
+  for (unsigned long long it = wave_in_grid(); it < n_items; it += stride) {
     const uint32_t ti = (uint32_t)(it / n_win), w = (uint32_t)(it % n_win);
     const GtTask t = a.tasks[ti];
     if (t.allele == 0 || t.cend + 1u - t.s_begin != 4u * ns) continue;  // k_gt's general scan
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(kWgThreads) void k_tabs_wide(KernelArgs a) {
   const unsigned long long n_items = (unsigned long long)n_tasks * w_max;
   const uint32_t stride = gridDim.x * kWavesPerWg;
   const uint32_t cap_off = (a.cap - 16u) & ~3u;
-  for (unsigned long long it = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); it < n_items; it += stride) {
+  for (unsigned long long it = wave_in_grid(); it < n_items; it += stride) {
     const uint32_t ti = (uint32_t)(it / w_max), w = (uint32_t)(it % w_max);
     const GtTask t = a.tasks[ti];
     if (!wide_general_task(a, t)) continue;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt_wide_general(KernelArgs a) {
   const uint32_t w_max = a.counters->pad[1] / a.win_bytes + 1u;
   const unsigned long long n_items = (unsigned long long)n_tasks * w_max;
   const uint32_t stride = gridDim.x * kWavesPerWg;
-  for (unsigned long long it = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); it < n_items; it += stride) {
+  for (unsigned long long it = wave_in_grid(); it < n_items; it += stride) {
     const uint32_t ti = (uint32_t)(it / w_max), w = (uint32_t)(it % w_max);
     const GtTask t = a.tasks[ti];
     if (!wide_general_task(a, t)) continue;
@@ -649,7 +649,7 @@ __device__ __forceinline__ void k_dosage_body(const KernelArgs &a) {
   const uint32_t stride = gridDim.x * kWavesPerWg;
   const uint32_t w_max = share_of_row ? a.counters->pad[1] / a.win_bytes + 1u : 1u;
   const unsigned long long n_items = (unsigned long long)n_alleles * w_max;
-  for (unsigned long long it = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); it < n_items; it += stride) {
+  for (unsigned long long it = wave_in_grid(); it < n_items; it += stride) {
     const uint32_t k = (uint32_t)(it / w_max), w = (uint32_t)(it % w_max);
     const bvcf_allele r = a.alleles[k];
     const uint32_t li = k < n_lines ? k : r.line;

@@ -11,7 +11,7 @@ namespace bvcf_dev {
 // newline census: a wave takes 4 consecutive 1 KiB chunks per step so that 4 KiB are in flight
 __global__ __launch_bounds__(kWgThreads) void k_count_eol(KernelArgs a, uint32_t n_chunks) {
   const int lane = lane_id();
-  const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  const uint32_t wave = wave_in_grid();
   const uint32_t stride = gridDim.x * kWavesPerWg * 4u;
   const uint32_t last_off = a.cap - 16u;
   for (uint32_t c0 = wave * 4u; c0 < n_chunks; c0 += stride) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(1024) void k_scan_top(KernelArgs a, uint32_t n_grou
 // once (one per lane) and revisits only the chunks that hold a terminator.
 __global__ __launch_bounds__(kWgThreads) void k_scatter_eol(KernelArgs a, uint32_t n_chunks) {
   const int lane = lane_id();
-  const uint32_t wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  const uint32_t wave = wave_in_grid();
   const uint32_t stride = gridDim.x * kWavesPerWg * kWave;
   for (uint32_t c0 = wave * kWave; c0 < n_chunks; c0 += stride) {
     const uint32_t c = c0 + lane;

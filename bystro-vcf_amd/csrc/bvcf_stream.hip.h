@@ -136,20 +136,20 @@ __device__ unsigned int g_wave_hw[2][32768];
 __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
 #ifdef BVCF_EXP_TIMES
   if ((threadIdx.x & 63) == 0) {
-    g_wave_t[0][blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)] = wall_clock64();
-    g_wave_hw[0][blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
-    g_wave_hw[1][blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    g_wave_t[0][wave_in_grid()] = wall_clock64();
+    g_wave_hw[0][wave_in_grid()] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    g_wave_hw[1][wave_in_grid()] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
   }
   unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
 #endif
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
   __shared__ uint32_t s_sparse[kWavesPerWg][kSparseWords];
-  uint8_t *stage = s_stage[threadIdx.x >> 6];
-  uint32_t *sparse = s_sparse[threadIdx.x >> 6];
+  uint8_t *stage = s_stage[wave_in_wg()];
+  uint32_t *sparse = s_sparse[wave_in_wg()];
   const int lane = lane_id();
   // (threadIdx.x >> 6 is the same in all 64 lanes, which the compiler cannot know: without the broadcast everything
   // derived from the wave index -- tile numbers, run bounds, class-map slots -- lives in vector registers)
-  const uint32_t wave = bcast0(blockIdx.x * kWavesPerWg + (threadIdx.x >> 6));
+  const uint32_t wave = wave_in_grid();
   const uint32_t n_waves = gridDim.x * kWavesPerWg;
   const uint32_t ns = a.n_samples;
   const uint32_t nb = a.nbytes;
