@@ -111,7 +111,9 @@ typedef struct {
   uint32_t max_alleles;       /* slots of alleles[] (>= max_lines); 0 = 2 * max_lines + 1024 */
   uint64_t cmap_bytes;        /* class-map arena, one map per (line, ALT index); 0 = 1.5 maps per line */
   uint32_t n_slots;           /* batches in flight (0 = 2) */
-  uint32_t path;              /* 0 = choose; 1 = census path (separate newline census, every line listed);
+  uint32_t path;              /* 0 = choose (streaming for 256 .. BVCF_WIDE_SAMPLES header fields, census otherwise);
+                                 1 = census path (separate newline census, every line listed; from
+                                 BVCF_WIDE_SAMPLES samples up the genotype scan of one line is split over waves);
                                  2 = streaming path when there are samples (lines found and ALT #1 scanned
                                  in one pass; only lines with the right field count are listed) */
 } bvcf_params;
