@@ -578,6 +578,25 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_d
   p.exclude_filter = R.cfg->exclude_filter;
   p.max_batch_bytes = R.max_batch;
   p.n_slots = R.n_slots;
+  // The library sizes its result arrays for the shortest line that could pass (48 bytes for a sites-only file:
+  // 1.4 M lines per 64 MiB batch, a gigabyte of pinned result memory over three slots).  The first block says how
+  // long the lines of this file are: reserve for lines half that long; a batch that needs more grows the
+  // reservation (BVCF_E_CAPACITY, bvcf_reserve).
+  if (data && n_data) {
+    const size_t look = std::min<size_t>(n_data, 4u << 20);
+    size_t n_eol = 0;
+    for (const uint8_t *q = data, *e = data + look; (q = (const uint8_t *)memchr(q, R.pre.eol_byte, (size_t)(e - q))); q++) n_eol++;
+    if (n_eol >= 16) {
+      const uint64_t avg = look / n_eol;
+      const uint64_t floor_len = std::max<uint64_t>(48, 2ull * R.pre.header.size());  // the library's own bound
+      const uint64_t per_line = std::max<uint64_t>(floor_len, avg / 2);
+      // (the slack for short lines between the records, as the library computes it: what 32 MiB of class maps hold)
+      const uint64_t ns = R.pre.header.size() > 9 ? R.pre.header.size() - 9 : 0;
+      const uint64_t stride = std::max<uint64_t>(16, ((ns + 3) / 4 + 15) & ~15ull);
+      const uint64_t slack = std::min<uint64_t>(4096, std::max<uint64_t>(64, (32ull << 20) / stride));
+      p.max_lines = (uint32_t)std::min<uint64_t>(R.max_batch / per_line + slack, 0x7FFFFFFFu);
+    }
+  }
   p.path = data ? choose_path(R, data, n_data) : 0;
   int rc = bvcf_create(&R.ctx, &p);
   if (rc) {
@@ -884,7 +903,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   if (!c) return BVCF_E_ARG;
   const bool timing = getenv("BVCF_TIMING") != nullptr;
   const double t_start = now_s();
-  double t_wait_read = 0, t_gpu = 0, t_fmt = 0, t_fmt_wait = 0, t_init = 0, t_ctx = 0;
+  double t_wait_read = 0, t_gpu = 0, t_fmt = 0, t_fmt_wait = 0, t_init = 0, t_ctx = 0, t_submit = 0, t_handoff = 0;
   std::string msg;
   Run R;
   R.cfg = c;
@@ -1145,7 +1164,9 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     j.res = res;
     outstanding.emplace_back(n_jobs, n_collects - 1);
     n_jobs++;
+    const double th = now_s();
     fmt_q.push(j);
+    t_handoff += now_s() - th;
     if (dosage_failed.load()) fail("dosage matrix: write failed", BVCF_E_FATAL);
     if (write_failed.load()) fail("write failed", BVCF_E_FATAL);
   };
@@ -1181,7 +1202,9 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       // keep one block ahead of the one being formatted
       if (in_flight.size() >= 2) finish_oldest();
       if (!done) {
+        const double ts = now_s();
         int r = bvcf_submit(R.ctx, b.buf + b.start, b.nb, seq++);
+        t_submit += now_s() - ts;
         if (r)
           fail(std::string("bvcf_submit: ") + bvcf_last_error(R.ctx), r);
         else
@@ -1251,9 +1274,10 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   free_bufs();
   if (timing)
     dprintf(fd_err,
-            "[bvcf timing] init %.3f (pinned buffers %.3f, ctx %.3f) wait-for-reader %.3f gpu(wait) %.3f wait-for-formatter %.3f (formatter busy %.3f) "
+            "[bvcf timing] init %.3f (pinned buffers %.3f, ctx %.3f) wait-for-reader %.3f submit %.3f gpu(wait) %.3f "
+            "wait-for-formatter %.3f+%.3f (formatter busy %.3f) "
             "teardown %.3f total %.3f s\n",
-            t_init, t_pinned, t_ctx, t_wait_read, t_gpu, t_fmt_wait, t_fmt, now_s() - t_end0, now_s() - t_start);
+            t_init, t_pinned, t_ctx, t_wait_read, t_submit, t_gpu, t_fmt_wait, t_handoff, t_fmt, now_s() - t_end0, now_s() - t_start);
   if (n_lines_in) *n_lines_in = lines_in;
   return rc;
 }
