@@ -2,7 +2,7 @@
 """End-to-end CLI timing: synthetic rows -> file -> bystro-vcf (HIP) -> /dev/null, with the stage times of
 BVCF_TIMING, and (optionally) an md5 comparison with the oracle CLI on the same file.
 
-    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH] [--bgzf] [--samples=N]
+    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH] [--bgzf] [--samples=N] [--pipe]
 
 Needs a GPU box.  The file is written to /dev/shm when it fits there, else /tmp, and removed afterwards.
 """
@@ -87,7 +87,12 @@ def main():
         for it in range(runs[0] if runs else 3):
             t0 = time.perf_counter()
             with open(path, "rb") as f, open("/dev/null", "wb") as out:
-                p = subprocess.run([CLI] + extra, stdin=f, stdout=out, stderr=subprocess.PIPE, env=env)
+                if "--pipe" in sys.argv:  # stdin is a pipe, as in `pigz -dc in.vcf.gz | bystro-vcf`
+                    cat = subprocess.Popen(["cat", path], stdout=subprocess.PIPE)
+                    p = subprocess.run([CLI] + extra, stdin=cat.stdout, stdout=out, stderr=subprocess.PIPE, env=env)
+                    cat.wait()
+                else:
+                    p = subprocess.run([CLI] + extra, stdin=f, stdout=out, stderr=subprocess.PIPE, env=env)
             dt = time.perf_counter() - t0
             tl = [l for l in p.stderr.decode().splitlines() if "timing" in l]
             print("run %d: rc %d, %.3f s wall = %.2f M variants/s, %.1f GB/s   %s" %
