@@ -166,8 +166,9 @@ typedef struct {
   uint32_t pad;
 } bvcf_err;
 
-/* a collected batch.  All pointers are library-owned pinned host memory, valid until the next
- * bvcf_collect / bvcf_destroy on the same ctx. */
+/* a collected batch.  All pointers are library-owned pinned host memory of the slot the batch ran in.  Collects fill
+ * the ctx's n_slots slots in turn, so the pointers stay valid until the n_slots-th following bvcf_collect on the same
+ * ctx (with n_slots = 1: the next one), or bvcf_reserve / bvcf_destroy. */
 typedef struct {
   uint64_t batch_seq;
   int32_t status;            /* BVCF_OK or BVCF_E_CAPACITY (then only need_* are meaningful) */
