@@ -27,7 +27,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DEVICE_PAD = 64
 NO_CMAP = 0xFFFFFFFF
 
@@ -37,11 +37,14 @@ SITE_NAMES = ["SNP", "INS", "DEL", "MNP", "MULTIALLELIC"]
 ALT_BASE, ALT_INS, ALT_DEL = 0, 1, 2
 CLS_NONE, CLS_HET, CLS_HOM, CLS_MISSING = 0, 1, 2, 3
 
+# the measurement hooks of include/bvcf_bench.h (not part of the drop-in ABI)
+BENCH_EXPORTS = ["bvcf_bench_device", "bvcf_bench_device_slots"]
+
 # every symbol include/bvcf.h declares
 EXPORTS = [
     "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_alloc_pinned",
-    "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_bench_device", "bvcf_bench_device_slots", "bvcf_counters", "bvcf_sum_counters",
-    "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_free",
+    "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_counters", "bvcf_sum_counters",
+    "bvcf_allreduce_counters", "bvcf_device_count", "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_free",
     "bvcf_arrow_open", "bvcf_arrow_append", "bvcf_arrow_close",
 ]
 
@@ -63,7 +66,8 @@ class Config(C.Structure):
         ("keep_pos", C.c_uint8), ("keep_qual", C.c_uint8), ("normalize_header", C.c_uint8),
         ("reserved", C.c_uint8 * 3), ("device", C.c_int32), ("n_format_threads", C.c_uint32),
         ("max_batch_bytes", C.c_uint64), ("sample_list_path", C.c_char_p),
-        ("dosage_path", C.c_char_p), ("no_out", C.c_uint8), ("reserved3", C.c_uint8 * 7),
+        ("dosage_path", C.c_char_p), ("no_out", C.c_uint8), ("reserved3", C.c_uint8 * 3),
+        ("n_devices", C.c_uint32), ("devices", C.POINTER(C.c_int32)),
     ]
 
 
@@ -109,6 +113,9 @@ lib.bvcf_bench_device_slots.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POI
                                         C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
 lib.bvcf_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 lib.bvcf_path.argtypes = [C.c_void_p]
+lib.bvcf_sum_counters.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_uint64)]
+lib.bvcf_allreduce_counters.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+lib.bvcf_device_count.restype = C.c_int
 lib.bvcf_config_defaults.argtypes = [C.POINTER(Config)]
 lib.bvcf_config_defaults.restype = None
 lib.bvcf_string_header.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t]
@@ -154,6 +161,11 @@ def make_config(cfg=None, device=0, max_batch_bytes=0, n_format_threads=0):
         keep.append(str(cfg["dosageOutput"]).encode())
         c.dosage_path = keep[-1]
     c.no_out = int(cfg.get("noOut", False))
+    if cfg.get("devices"):  # bvcf_run_fd only: the device list the blocks are dealt to
+        arr = (C.c_int32 * len(cfg["devices"]))(*cfg["devices"])
+        keep.append(arr)
+        c.devices = arr
+        c.n_devices = len(cfg["devices"])
     c._keep = keep
     return c
 
@@ -178,6 +190,25 @@ def run_buffer(vcf_bytes, cfg=None, device=0, max_batch_bytes=0, n_format_thread
     lib.bvcf_free(out)
     lib.bvcf_free(log)
     return rc, o, e, n_lines.value
+
+
+def run_fd(fd_in, fd_out, fd_err, cfg=None, device=0, max_batch_bytes=0):
+    """bvcf_run_fd over open file descriptors -> (rc, n data lines)"""
+    c = make_config(cfg, device, max_batch_bytes)
+    n_lines = C.c_uint64()
+    rc = lib.bvcf_run_fd(C.byref(c), fd_in, fd_out, fd_err, C.byref(n_lines))
+    return rc, n_lines.value
+
+
+def allreduce_counters(ctxs):
+    """the final count gather over a list of Ctx -> (totals[8], used_rccl)"""
+    arr = (C.c_void_p * len(ctxs))(*[x.h for x in ctxs])
+    out = (C.c_uint64 * 8)()
+    used = C.c_int(0)
+    rc = lib.bvcf_allreduce_counters(arr, len(ctxs), out, C.byref(used))
+    if rc:
+        raise BvcfError(rc, lib.bvcf_last_error(ctxs[0].h).decode())
+    return list(out), bool(used.value)
 
 
 def decompress(data, n_threads=0):

@@ -4,7 +4,10 @@
 // block) + the five-kernel chain + D2H of the 24-byte counter block, all on the slot's stream;
 // collect = wait, size check, D2H of exactly the used parts of the result arrays.
 #include "bvcf_device.hip.h"
+#include "../../include/bvcf_bench.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so.1 is dlopen'ed by bvcf_allreduce_counters
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -370,7 +373,8 @@ const char *bvcf_last_error(const bvcf_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 void *bvcf_alloc_pinned(size_t nbytes) {
   void *p = nullptr;
-  if (hipHostMalloc(&p, nbytes ? nbytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  // portable: blocks are handed to the ctx of whichever device they are dealt to (bvcf_run_fd)
+  if (hipHostMalloc(&p, nbytes ? nbytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
   return p;
 }
 
@@ -650,6 +654,97 @@ int bvcf_sum_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8]) {
     for (int k = 0; k < 8; k++) out[k] += ctxs[i]->totals[k];
   }
   return BVCF_OK;
+}
+
+int bvcf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// The final count gather.  One process drives all ctxs, so the communicator is built with
+// ncclCommInitAll and the n all-reduces are issued as one group.
+int bvcf_allreduce_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8], int *used_rccl) {
+  if (used_rccl) *used_rccl = 0;
+  if (!ctxs || n < 0 || !out) return BVCF_E_ARG;
+  for (int i = 0; i < n; i++)
+    if (!ctxs[i]) return BVCF_E_ARG;
+  bool distinct = true;
+  for (int i = 0; i < n && distinct; i++)
+    for (int j = 0; j < i; j++)
+      if (ctxs[i]->device == ctxs[j]->device) distinct = false;
+  const char *force = getenv("BVCF_RCCL");
+  const bool want = distinct && (n >= 2 || (n == 1 && force && *force == '1'));
+  if (!want) return bvcf_sum_counters(ctxs, n, out);
+
+  bvcf_ctx *c0 = ctxs[0];
+  // dlopen by SONAME: a process that already holds an RCCL (torch ships its own copy) gets that one
+  static void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) {
+    c0->err = std::string("dlopen librccl.so.1: ") + dlerror();
+    return BVCF_E_HIP;
+  }
+  auto p_init = (decltype(&ncclCommInitAll))dlsym(lib, "ncclCommInitAll");
+  auto p_destroy = (decltype(&ncclCommDestroy))dlsym(lib, "ncclCommDestroy");
+  auto p_allreduce = (decltype(&ncclAllReduce))dlsym(lib, "ncclAllReduce");
+  auto p_gstart = (decltype(&ncclGroupStart))dlsym(lib, "ncclGroupStart");
+  auto p_gend = (decltype(&ncclGroupEnd))dlsym(lib, "ncclGroupEnd");
+  auto p_errstr = (decltype(&ncclGetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!p_init || !p_destroy || !p_allreduce || !p_gstart || !p_gend || !p_errstr) {
+    c0->err = "librccl.so.1 lacks an expected symbol";
+    return BVCF_E_HIP;
+  }
+  std::vector<int> devs(n);
+  std::vector<ncclComm_t> comms(n, nullptr);
+  std::vector<uint64_t *> d_buf(n, nullptr);
+  for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
+  int rc = BVCF_OK;
+  auto nccl_fail = [&](ncclResult_t r, const char *what) {
+    c0->err = std::string(what) + ": " + p_errstr(r);
+    rc = BVCF_E_HIP;
+  };
+  ncclResult_t r = p_init(comms.data(), n, devs.data());
+  if (r != ncclSuccess) {
+    nccl_fail(r, "ncclCommInitAll");
+    return rc;
+  }
+  for (int i = 0; i < n && rc == BVCF_OK; i++) {
+    if (hipSetDevice(devs[i]) != hipSuccess || hipMalloc(&d_buf[i], 8 * sizeof(uint64_t)) != hipSuccess ||
+        hipMemcpy(d_buf[i], ctxs[i]->totals, 8 * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
+      c0->err = "bvcf_allreduce_counters: counter upload failed";
+      rc = BVCF_E_HIP;
+    }
+  }
+  if (rc == BVCF_OK) {
+    r = p_gstart();
+    for (int i = 0; i < n && r == ncclSuccess; i++) {
+      hipSetDevice(devs[i]);
+      r = p_allreduce(d_buf[i], d_buf[i], 8, ncclUint64, ncclSum, comms[i], ctxs[i]->slots[0].stream);
+    }
+    const ncclResult_t r2 = p_gend();
+    if (r != ncclSuccess || r2 != ncclSuccess) nccl_fail(r != ncclSuccess ? r : r2, "ncclAllReduce");
+  }
+  for (int i = 0; i < n && rc == BVCF_OK; i++) {
+    hipSetDevice(devs[i]);
+    if (hipStreamSynchronize(ctxs[i]->slots[0].stream) != hipSuccess) {
+      c0->err = "bvcf_allreduce_counters: all-reduce failed";
+      rc = BVCF_E_HIP;
+    }
+  }
+  if (rc == BVCF_OK) {
+    hipSetDevice(devs[0]);
+    if (hipMemcpy(out, d_buf[0], 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) {
+      c0->err = "bvcf_allreduce_counters: counter download failed";
+      rc = BVCF_E_HIP;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    hipSetDevice(devs[i]);
+    if (d_buf[i]) hipFree(d_buf[i]);
+    if (comms[i]) p_destroy(comms[i]);
+  }
+  if (rc == BVCF_OK && used_rccl) *used_rccl = 1;
+  return rc;
 }
 
 int bvcf_bench_device(bvcf_ctx *c, const void *const *dblocks, const size_t *nbytes, int n_blocks, int iters,

@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -508,6 +509,7 @@ struct Run {
   bool want_rows = true;        // !noOut
   std::unique_ptr<WorkPool> pool;  // TSV assembly workers (n_threads of them, this thread included)
   uint32_t n_slots = 2;            // result slots of the ctx
+  bvcf_params params;              // what every ctx of the run is created with (prepare_run), bar the device
 };
 
 // Which device path suits this file: the streaming path shines when sample fields are the bare
@@ -554,7 +556,9 @@ int write_sample_list(const Run &R) {
   return close(fd);
 }
 
-int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_data = 0) {
+// What every ctx of the run shares: the sample list file, the ctx parameters (R.params), the name arena, the ratio
+// strings, the formatter's worker pool, the dosage file.  Once per run, after the header is known.
+int prepare_run(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_data = 0) {
   if (R.pre.header.size() < 8) {
     // the reference indexes record[6] / record[7] unguarded: out of contract
     *msg = "Malformed header: fewer than 8 fields";
@@ -564,7 +568,7 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_d
     *msg = "Couldn't write sample list file";
     return BVCF_E_FATAL;
   }
-  bvcf_params p;
+  bvcf_params &p = R.params;
   memset(&p, 0, sizeof p);
   p.abi_version = BVCF_ABI_VERSION;
   p.device = R.cfg->device;
@@ -598,11 +602,6 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_d
     }
   }
   p.path = data ? choose_path(R, data, n_data) : 0;
-  int rc = bvcf_create(&R.ctx, &p);
-  if (rc) {
-    *msg = std::string("bvcf_create: ") + bvcf_last_error(nullptr);
-    return rc;
-  }
   for (size_t i = 9; i < R.pre.header.size(); i++) {
     R.name_ptr.push_back(R.pre.header[i].data());
     R.name_len.push_back((uint32_t)R.pre.header[i].size());
@@ -628,6 +627,21 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_d
     }
   }
   return BVCF_OK;
+}
+
+// one ctx of the run on `device` (the counterpart of one `go processLines(...)`, main.go:345-347)
+int create_ctx(const Run &R, int device, bvcf_ctx **ctx, std::string *msg) {
+  bvcf_params p = R.params;
+  p.device = device;
+  const int rc = bvcf_create(ctx, &p);
+  if (rc) *msg = std::string("bvcf_create: ") + bvcf_last_error(nullptr);
+  return rc;
+}
+
+int open_ctx(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t n_data = 0) {
+  int rc = prepare_run(R, msg, data, n_data);
+  if (rc == BVCF_OK) rc = create_ctx(R, R.cfg->device, &R.ctx, msg);
+  return rc;
 }
 
 // the Arrow rows of one collected batch, in input order (main.go:576-584): "chrom:pos:ref:alt" + one int8 per sample
@@ -738,6 +752,7 @@ struct Block {
   size_t start = 0, nb = 0;  // lines live in buf[start, start + nb)
   size_t fill = 0;           // bytes read into buf (preamble parsing needs this on the first block)
   bool first = false, last = false, too_long = false, read_error = false;
+  uint64_t seq = 0;          // block number: the order of the output
 };
 
 }  // namespace
@@ -892,24 +907,37 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// The reference's main() + readVcf (main.go:134-217, 241-396) as a five-stage pipeline:
-//   reader thread  fd -> pinned buffers, cut at the last terminator         (main.go:349-380)
-//   this thread    bvcf_submit one block ahead, bvcf_collect the oldest     (processLines' input side)
-//   format thread  TSV assembly of a collected batch on the worker pool     (main.go:566-695)
-//   writer thread  ordered write to fd_out                                  (main.go:524-532,705-711)
-// A collected batch's result arrays stay valid until its slot is collected into again, n_slots batches
-// later, so formatting runs one or two batches behind the device instead of between two submits.
+// The reference's main() + readVcf (main.go:134-217, 241-396) as a pipeline:
+//   reader thread      fd -> pinned buffers, cut at the last terminator                 (main.go:349-380)
+//   this thread        preamble, then deals block k to device worker k % N              (workQueue <- buff, main.go:366)
+//   N device workers   one ctx each: bvcf_submit one block ahead, bvcf_collect the oldest
+//                                                                  (the goroutines of main.go:345-347)
+//   format thread      takes the collected batches in block order, TSV assembly on the worker pool  (main.go:566-695)
+//   writer thread      ordered write to fd_out                                          (main.go:524-532,705-711)
+// A collected batch's result arrays stay valid until its slot is collected into again, n_slots batches later on the
+// same ctx, so formatting runs one or two batches behind the devices instead of between two submits.  The output is
+// the same bytes for any device list: blocks are cut by the reader alone and merged by block number.
 int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_t *n_lines_in) {
   if (!c) return BVCF_E_ARG;
-  const bool timing = getenv("BVCF_TIMING") != nullptr;
+  const char *timing_env = getenv("BVCF_TIMING");
+  const bool timing = timing_env != nullptr;
+  const bool timing_json = timing && strcmp(timing_env, "json") == 0;
   const double t_start = now_s();
-  double t_wait_read = 0, t_gpu = 0, t_fmt = 0, t_fmt_wait = 0, t_init = 0, t_ctx = 0, t_submit = 0, t_handoff = 0;
+  double t_wait_read = 0, t_fmt = 0, t_init = 0, t_prepare = 0, t_deal = 0;
   std::string msg;
   Run R;
   R.cfg = c;
   R.n_slots = 3;  // two batches on the device, one more being formatted
   R.max_batch = c->max_batch_bytes ? c->max_batch_bytes : (64ull << 20);
-  uint64_t lines_in = 0;
+  std::atomic<uint64_t> lines_in{0};
+
+  // the devices of the run
+  std::vector<int> dev_list;
+  if (c->n_devices && c->devices)
+    dev_list.assign(c->devices, c->devices + c->n_devices);
+  else
+    dev_list.push_back(c->device);
+  const size_t n_dev = dev_list.size();
 
   // fmt.Fprintln(writer, stringHeader(config)), main.go:196-200
   if (!c->no_out) {
@@ -923,11 +951,12 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   }
 
   const size_t cap = R.max_batch;
-  constexpr int kBufs = 6;  // being read into, two on the device, up to two with the formatter, one spare
+  // being read into, two on each device, up to two with the formatter, one spare
+  const int kBufs = (int)std::min<size_t>(2 * n_dev + 4, 64);
   // Pinning memory costs about 25 ms per 64 MiB: only the first buffer is allocated before the reader starts, the
   // others follow in the background while the first block is read and the ctx is created, and stop at end of input
-  // (a small file never pays for six).
-  uint8_t *bufs[kBufs] = {nullptr};
+  // (a small file never pays for all of them).
+  std::vector<uint8_t *> bufs((size_t)kBufs, nullptr);
   bufs[0] = (uint8_t *)bvcf_alloc_pinned(cap);
   const double t_pinned = now_s() - t_start;
   if (!bufs[0]) {
@@ -936,8 +965,8 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     return BVCF_E_NODEV;
   }
 
-  Channel<uint8_t *> free_q(64);
-  Channel<Block> ready_q(kBufs);
+  Channel<uint8_t *> free_q(256);
+  Channel<Block> ready_q((size_t)kBufs);
   typedef std::vector<std::string> Parts;
   Channel<Parts *> write_q(4);
   free_q.push(bufs[0]);
@@ -963,7 +992,6 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     for (auto &t : th) t.join();
   };
   std::atomic<uint8_t> eol_byte{'\n'};
-  std::atomic<bool> eol_known{false};
 
   // ---- reader: whole lines per block; the partial last line is carried into the next buffer
   std::string source_err;
@@ -1008,7 +1036,6 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
           }
         }
         eol_byte.store(e);
-        eol_known.store(true);
         first = false;
       }
       const uint8_t *lastp = fill ? (const uint8_t *)memrchr(b.buf, eol_byte.load(), fill) : nullptr;
@@ -1034,12 +1061,14 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   std::atomic<bool> write_failed{false};
   std::mutex spare_mu;
   std::vector<Parts *> spares;
+  double t_last_write = 0;
   std::thread writer([&]() {
     for (;;) {
       Parts *ps = write_q.pop();
       if (!ps) break;
       for (const std::string &s : *ps)
         if (!s.empty() && !write_failed.load() && write_all(fd_out, s.data(), s.size())) write_failed.store(true);
+      t_last_write = now_s();
       std::lock_guard<std::mutex> lk(spare_mu);
       if (spares.size() < 4)
         spares.push_back(ps);
@@ -1048,21 +1077,182 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     }
   });
 
-  // ---- formatter: collected batches in order
+  // ---- first error wins; everything then drains
+  std::mutex fail_mu;
+  int rc = BVCF_OK;
+  std::string log;
+  std::atomic<bool> failed{false};
+  auto fail = [&](const std::string &m, int code) {
+    std::lock_guard<std::mutex> lk(fail_mu);
+    if (rc == BVCF_OK) {
+      rc = code;
+      log.append(m + "\n");
+    }
+    failed.store(true);
+  };
+
+  // ---- device workers -> formatter: collected batches, taken in block order
   struct FmtJob {
     Block b;
     bvcf_result res;
-    bool stop = false;
+    uint32_t worker = 0;
   };
-  Channel<FmtJob> fmt_q(1);
-  std::mutex fmt_mu;
-  std::condition_variable fmt_cv;
-  uint64_t fmt_done = 0;  // jobs finished (under fmt_mu)
+  struct Reorder {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::map<uint64_t, FmtJob> held;
+    uint64_t next = 0;
+    bool closed = false;
+    void put(uint64_t seq, const FmtJob &j) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        held.emplace(seq, j);
+      }
+      cv.notify_all();
+    }
+    // the job of block `next`; false once closed and that block is not coming
+    bool take(FmtJob *j) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return closed || held.count(next); });
+      auto it = held.find(next);
+      if (it == held.end()) return false;
+      *j = it->second;
+      held.erase(it);
+      next++;
+      return true;
+    }
+    void close() {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        closed = true;
+      }
+      cv.notify_all();
+    }
+  } reorder;
+
+  struct DevWorker {
+    uint32_t idx = 0;
+    int device = 0;
+    bvcf_ctx *ctx = nullptr;
+    Channel<Block> q{3};  // blocks dealt to this device; buf == nullptr ends the worker
+    std::thread th;
+    bool started = false;
+    // slots: jobs of this worker the formatter has finished
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t fmt_done = 0;
+    // timing
+    double t_ctx = 0, t_submit = 0, t_gpu = 0, t_fmt_wait = 0, t_first_submit = 0;
+    uint64_t n_blocks = 0, n_bytes = 0;
+  };
+  std::vector<std::unique_ptr<DevWorker>> workers;
+  for (size_t d = 0; d < n_dev; d++) {
+    workers.emplace_back(new DevWorker());
+    workers.back()->idx = (uint32_t)d;
+    workers.back()->device = dev_list[d];
+  }
   std::atomic<bool> dosage_failed{false};
+
+  auto worker_main = [&](DevWorker *W) {
+    std::deque<Block> in_flight;  // submitted, not yet collected (oldest first)
+    // Collect number q of the ctx lands in result slot q % n_slots, whose arrays the formatter may still be
+    // reading for the batch collected n_slots collects ago.
+    uint64_t n_collects = 0, n_jobs = 0;
+    std::deque<std::pair<uint64_t, uint64_t>> outstanding;  // (job number, collect number) of jobs not known finished
+    auto wait_formatted = [&](uint64_t n) {
+      const double t0 = now_s();
+      std::unique_lock<std::mutex> lk(W->mu);
+      W->cv.wait(lk, [&] { return W->fmt_done >= n || failed.load(); });
+      W->t_fmt_wait += now_s() - t0;
+    };
+    auto slot_is_free = [&]() {
+      uint64_t need = 0;
+      while (!outstanding.empty() && outstanding.front().second + R.n_slots <= n_collects) {
+        need = outstanding.front().first + 1;
+        outstanding.pop_front();
+      }
+      if (need) wait_formatted(need);
+    };
+    std::string wmsg;
+    auto finish_oldest = [&]() {
+      Block b = in_flight.front();
+      bvcf_result res;
+      slot_is_free();
+      if (failed.load()) return;
+      const double t0 = now_s();
+      int r = bvcf_collect(W->ctx, &res);
+      n_collects++;
+      if (r == BVCF_E_CAPACITY) {
+        // drop what is in flight here, let the formatter finish with the arrays that are about to be reallocated,
+        // grow, resubmit everything still queued on this device
+        wait_formatted(n_jobs);
+        outstanding.clear();
+        for (size_t k = 1; k < in_flight.size(); k++) {
+          bvcf_result tmp;
+          bvcf_collect(W->ctx, &tmp);
+          n_collects++;
+        }
+        r = bvcf_reserve(W->ctx, res.need_lines + res.need_lines / 4 + 64, res.need_alleles + res.need_alleles / 4 + 64,
+                         res.need_cmap_bytes + res.need_cmap_bytes / 4 + 4096);
+        for (size_t k = 0; k < in_flight.size() && r == BVCF_OK; k++)
+          r = bvcf_submit(W->ctx, in_flight[k].buf + in_flight[k].start, in_flight[k].nb, in_flight[k].seq);
+        if (r == BVCF_OK) {
+          r = bvcf_collect(W->ctx, &res);
+          n_collects++;
+        }
+      }
+      W->t_gpu += now_s() - t0;
+      if (r != BVCF_OK) {
+        fail(std::string("bvcf: ") + bvcf_last_error(W->ctx), r);
+        return;
+      }
+      in_flight.pop_front();
+      lines_in.fetch_add(res.n_lines_seen);
+      FmtJob j;
+      j.b = b;
+      j.res = res;
+      j.worker = W->idx;
+      outstanding.emplace_back(n_jobs, n_collects - 1);
+      n_jobs++;
+      reorder.put(b.seq, j);
+    };
+    for (;;) {
+      Block b = W->q.pop();
+      if (!b.buf) break;
+      if (failed.load()) continue;  // (the buffers are released at shutdown)
+      if (!W->ctx) {
+        const double tc = now_s();
+        const int r = create_ctx(R, W->device, &W->ctx, &wmsg);
+        W->t_ctx = now_s() - tc;
+        if (r) {
+          fail(wmsg, r);
+          continue;
+        }
+      }
+      // keep one block ahead of the one being collected
+      if (in_flight.size() >= 2) finish_oldest();
+      if (failed.load()) continue;
+      const double ts = now_s();
+      const int r = bvcf_submit(W->ctx, b.buf + b.start, b.nb, b.seq);
+      if (!W->n_blocks) W->t_first_submit = now_s() - t_start;
+      W->t_submit += now_s() - ts;
+      if (r) {
+        fail(std::string("bvcf_submit: ") + bvcf_last_error(W->ctx), r);
+        continue;
+      }
+      W->n_blocks++;
+      W->n_bytes += b.nb;
+      in_flight.push_back(b);
+    }
+    while (!failed.load() && !in_flight.empty()) finish_oldest();
+    if (failed.load()) reorder.close();  // a block of this worker may never arrive: do not let the formatter wait for it
+  };
+
+  // ---- formatter: collected batches in block order
   std::thread formatter([&]() {
     for (;;) {
-      FmtJob j = fmt_q.pop();
-      if (j.stop) break;
+      FmtJob j;
+      if (!reorder.take(&j)) break;
       const double t0 = now_s();
       Parts *ps = nullptr;
       {
@@ -1080,97 +1270,29 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
         format_parts(c, &j.res, text, *R.names, R.ratios.get(), R.pool.get(), *ps);
       else
         for (auto &q : *ps) q.clear();
-      if (append_dosage(R, &j.res, text)) dosage_failed.store(true);
+      if (append_dosage(R, &j.res, text)) {
+        dosage_failed.store(true);
+        fail("dosage matrix: write failed", BVCF_E_FATAL);
+      }
       t_fmt += now_s() - t0;
       write_q.push(ps);
       if (!jlog.empty()) write_all(fd_err, jlog.data(), jlog.size());
       free_q.push(j.b.buf);
+      DevWorker *W = workers[j.worker].get();
       {
-        std::lock_guard<std::mutex> lk(fmt_mu);
-        fmt_done++;
+        std::lock_guard<std::mutex> lk(W->mu);
+        W->fmt_done++;
       }
-      fmt_cv.notify_all();
+      W->cv.notify_all();
+      if (write_failed.load()) fail("write failed", BVCF_E_FATAL);
     }
+    // after a failure nobody may keep waiting for a slot
+    for (auto &W : workers) W->cv.notify_all();
   });
-  auto wait_formatted = [&](uint64_t n_jobs) {
-    const double t0 = now_s();
-    std::unique_lock<std::mutex> lk(fmt_mu);
-    fmt_cv.wait(lk, [&] { return fmt_done >= n_jobs; });
-    t_fmt_wait += now_s() - t0;
-  };
 
-  int rc = BVCF_OK;
+  // ---- this thread: preamble, then deal the blocks
   bool have_pre = false, done = false;
-  std::string log;
-  std::deque<Block> in_flight;  // submitted, not yet collected (oldest first)
   uint64_t seq = 0;
-
-  auto fail = [&](const std::string &m, int code) {
-    if (rc == BVCF_OK) {
-      rc = code;
-      log.append(m + "\n");
-    }
-    done = true;
-  };
-
-  // collect the oldest in-flight block and hand it to the formatter; grows the reservation on demand.
-  // Collect number q of the ctx lands in result slot q % n_slots, whose arrays the formatter may still be
-  // reading for the batch collected n_slots collects ago.
-  uint64_t n_collects = 0, n_jobs = 0;
-  std::deque<std::pair<uint64_t, uint64_t>> outstanding;  // (job number, collect number) of jobs not known finished
-  auto slot_is_free = [&]() {
-    uint64_t need = 0;
-    while (!outstanding.empty() && outstanding.front().second + R.n_slots <= n_collects) {
-      need = outstanding.front().first + 1;
-      outstanding.pop_front();
-    }
-    if (need) wait_formatted(need);
-  };
-  auto finish_oldest = [&]() {
-    Block b = in_flight.front();
-    bvcf_result res;
-    slot_is_free();
-    double t0 = now_s();
-    int r = bvcf_collect(R.ctx, &res);
-    n_collects++;
-    if (r == BVCF_E_CAPACITY) {
-      // drop what is in flight, let the formatter finish with the arrays that are about to be reallocated,
-      // grow, resubmit everything still queued on the device side
-      wait_formatted(n_jobs);
-      outstanding.clear();
-      for (size_t k = 1; k < in_flight.size(); k++) {
-        bvcf_result tmp;
-        bvcf_collect(R.ctx, &tmp);
-        n_collects++;
-      }
-      r = bvcf_reserve(R.ctx, res.need_lines + res.need_lines / 4 + 64, res.need_alleles + res.need_alleles / 4 + 64,
-                       res.need_cmap_bytes + res.need_cmap_bytes / 4 + 4096);
-      for (size_t k = 0; k < in_flight.size() && r == BVCF_OK; k++)
-        r = bvcf_submit(R.ctx, in_flight[k].buf + in_flight[k].start, in_flight[k].nb, seq++);
-      if (r == BVCF_OK) {
-        r = bvcf_collect(R.ctx, &res);
-        n_collects++;
-      }
-    }
-    t_gpu += now_s() - t0;
-    if (r != BVCF_OK) {
-      fail(std::string("bvcf: ") + bvcf_last_error(R.ctx), r);
-      return;
-    }
-    in_flight.pop_front();
-    lines_in += res.n_lines_seen;
-    FmtJob j;
-    j.b = b;
-    j.res = res;
-    outstanding.emplace_back(n_jobs, n_collects - 1);
-    n_jobs++;
-    const double th = now_s();
-    fmt_q.push(j);
-    t_handoff += now_s() - th;
-    if (dosage_failed.load()) fail("dosage matrix: write failed", BVCF_E_FATAL);
-    if (write_failed.load()) fail("write failed", BVCF_E_FATAL);
-  };
-
   t_init = now_s() - t_start;
   while (!done) {
     double t0 = now_s();
@@ -1178,50 +1300,53 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     t_wait_read += now_s() - t0;
     if (b.read_error) fail(source_err.empty() ? std::string("read error") : source_err, BVCF_E_FATAL);
     if (b.too_long) fail("a line is longer than max_batch_bytes", BVCF_E_TOO_BIG);
-    if (!done && b.buf && !have_pre) {
+    if (!failed.load() && b.buf && !have_pre) {
       t0 = now_s();
       int pr = parse_preamble(b.buf, b.fill, true, c->normalize_header, &R.pre, &msg);
       if (pr != 0) {
         fail(msg, BVCF_E_FATAL);
       } else {
         have_pre = true;
-        const double tc = now_s();
-        int r = open_ctx(R, &msg, b.buf + R.pre.data_off, b.fill > R.pre.data_off ? b.fill - R.pre.data_off : 0);
-        t_ctx = now_s() - tc;
+        int r = prepare_run(R, &msg, b.buf + R.pre.data_off, b.fill > R.pre.data_off ? b.fill - R.pre.data_off : 0);
         if (r) fail(msg, r);
-        if (!done && R.pre.header.size() == 9) {
+        if (!failed.load() && R.pre.header.size() == 9) {
           const char *m = "Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n";
           write_all(fd_err, m, strlen(m));
         }
         b.start = R.pre.data_off;
         b.nb = b.nb > b.start ? b.nb - b.start : 0;
       }
-      t_init += now_s() - t0;
+      t_prepare = now_s() - t0;
+      t_init += t_prepare;
     }
-    if (!done && b.buf && b.nb) {
-      // keep one block ahead of the one being formatted
-      if (in_flight.size() >= 2) finish_oldest();
-      if (!done) {
-        const double ts = now_s();
-        int r = bvcf_submit(R.ctx, b.buf + b.start, b.nb, seq++);
-        t_submit += now_s() - ts;
-        if (r)
-          fail(std::string("bvcf_submit: ") + bvcf_last_error(R.ctx), r);
-        else
-          in_flight.push_back(b);
+    if (!failed.load() && b.buf && b.nb) {
+      DevWorker *W = workers[seq % n_dev].get();
+      if (!W->started) {
+        W->started = true;
+        W->th = std::thread(worker_main, W);
       }
+      b.seq = seq++;
+      t0 = now_s();
+      W->q.push(b);
+      t_deal += now_s() - t0;
     } else if (b.buf) {
       free_q.push(b.buf);
     }
-    if (b.last) {
-      while (!done && !in_flight.empty()) finish_oldest();
-      if (alloc_failed.load()) fail("cannot allocate pinned host memory", BVCF_E_NOMEM);
-      if (!have_pre && rc == BVCF_OK) fail("EOF", BVCF_E_FATAL);
-      done = true;
-    }
+    if (b.last || failed.load()) done = true;
   }
 
   // ---- shut down
+  for (auto &W : workers)
+    if (W->started) {
+      Block end;
+      W->q.push(end);
+    }
+  for (auto &W : workers)
+    if (W->started) W->th.join();
+  if (alloc_failed.load()) fail("cannot allocate pinned host memory", BVCF_E_NOMEM);
+  if (!have_pre && !failed.load()) fail("EOF", BVCF_E_FATAL);
+  reorder.close();
+  formatter.join();
   stop.store(true);
   stop_alloc.store(true);
   allocator.join();
@@ -1230,7 +1355,6 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   std::thread drain([&]() {
     for (;;) {
       Block b = ready_q.pop();
-      if (b.last && !b.buf) break;
       if (b.last) break;
     }
   });
@@ -1241,44 +1365,87 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     ready_q.push(end);
   }
   drain.join();
-  {
-    FmtJob end;
-    end.stop = true;
-    fmt_q.push(end);
-  }
-  formatter.join();
   write_q.push(nullptr);
   writer.join();
   for (Parts *ps : spares) delete ps;
-  if (rc == BVCF_OK && dosage_failed.load()) {
-    log.append("dosage matrix: write failed\n");
-    rc = BVCF_E_FATAL;
-  }
-  if (rc == BVCF_OK && write_failed.load()) {
-    log.append("write failed\n");
-    rc = BVCF_E_FATAL;
-  }
-  if (close_dosage(R) && rc == BVCF_OK) {
-    log.append("dosage matrix: write failed\n");
-    rc = BVCF_E_FATAL;
-  }
+  if (write_failed.load()) fail("write failed", BVCF_E_FATAL);
+  if (close_dosage(R)) fail("dosage matrix: write failed", BVCF_E_FATAL);
   if (!log.empty()) write_all(fd_err, log.data(), log.size());
   const double t_end0 = now_s();
-  if (R.ctx) {
-    // collect anything left after a failure so the ctx can be destroyed
-    bvcf_result tmp;
-    while (bvcf_collect(R.ctx, &tmp) != BVCF_E_EMPTY) {
-    }
-    bvcf_destroy(R.ctx);
+
+  // the final count gather: one RCCL all-reduce over the devices that took part (host sum for one device)
+  uint64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int used_rccl = 0;
+  {
+    std::vector<bvcf_ctx *> live;
+    for (auto &W : workers)
+      if (W->ctx) {
+        bvcf_result tmp;  // collect anything left after a failure so the ctx can be destroyed
+        while (bvcf_collect(W->ctx, &tmp) != BVCF_E_EMPTY) {
+        }
+        live.push_back(W->ctx);
+      }
+    if (!live.empty() && rc == BVCF_OK && bvcf_allreduce_counters(live.data(), (int)live.size(), totals, &used_rccl) != BVCF_OK)
+      bvcf_sum_counters(live.data(), (int)live.size(), totals);  // the summary is informational: never fail the run on it
+    for (bvcf_ctx *x : live) bvcf_destroy(x);
   }
   free_bufs();
-  if (timing)
-    dprintf(fd_err,
-            "[bvcf timing] init %.3f (pinned buffers %.3f, ctx %.3f) wait-for-reader %.3f submit %.3f gpu(wait) %.3f "
-            "wait-for-formatter %.3f+%.3f (formatter busy %.3f) "
-            "teardown %.3f total %.3f s\n",
-            t_init, t_pinned, t_ctx, t_wait_read, t_submit, t_gpu, t_fmt_wait, t_handoff, t_fmt, now_s() - t_end0, now_s() - t_start);
-  if (n_lines_in) *n_lines_in = lines_in;
+  if (timing) {
+    const double t_total = now_s() - t_start;
+    double t_ctx = 0, t_gpu = 0, t_submit = 0, t_fmt_wait = 0, t_first = 0;
+    size_t used = 0;
+    for (auto &W : workers) {
+      if (!W->n_blocks) continue;
+      used++;
+      t_ctx = std::max(t_ctx, W->t_ctx);
+      t_gpu = std::max(t_gpu, W->t_gpu);
+      t_submit = std::max(t_submit, W->t_submit);
+      t_fmt_wait = std::max(t_fmt_wait, W->t_fmt_wait);
+      if (W->idx == 0) t_first = W->t_first_submit;
+    }
+    const double t_steady = t_last_write > t_start + t_first ? t_last_write - t_start - t_first : 0.0;
+    if (timing_json) {
+      std::string j = "[bvcf timing-json] {";
+      char tmp[256];
+      auto num = [&](const char *k, double v, bool comma = true) {
+        j.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "\"%s\": %.6f%s", k, v, comma ? ", " : ""));
+      };
+      num("total_s", t_total);
+      num("init_s", t_init);
+      num("pinned_first_buffer_s", t_pinned);
+      num("prepare_s", t_prepare);
+      num("ctx_create_max_s", t_ctx);
+      num("first_submit_at_s", t_first);
+      num("last_write_at_s", t_last_write > t_start ? t_last_write - t_start : 0.0);
+      num("steady_s", t_steady);
+      num("wait_for_reader_s", t_wait_read);
+      num("deal_wait_s", t_deal);
+      num("submit_max_s", t_submit);
+      num("gpu_wait_max_s", t_gpu);
+      num("wait_for_formatter_max_s", t_fmt_wait);
+      num("formatter_busy_s", t_fmt);
+      num("teardown_s", now_s() - t_end0);
+      j.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "\"lines_in\": %llu, \"devices_used\": %zu, \"count_gather\": \"%s\", ",
+                                     (unsigned long long)lines_in.load(), used, used_rccl ? "rccl" : "host"));
+      j.append("\"devices\": [");
+      for (size_t d = 0; d < n_dev; d++)
+        j.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "%s{\"device\": %d, \"blocks\": %llu, \"bytes\": %llu, \"gpu_wait_s\": %.6f}",
+                                       d ? ", " : "", workers[d]->device, (unsigned long long)workers[d]->n_blocks,
+                                       (unsigned long long)workers[d]->n_bytes, workers[d]->t_gpu));
+      j.append("], \"counters\": [");
+      for (int k = 0; k < 8; k++) j.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "%s%llu", k ? ", " : "", (unsigned long long)totals[k]));
+      j.append("]}\n");
+      write_all(fd_err, j.data(), j.size());
+    } else {
+      dprintf(fd_err,
+              "[bvcf timing] init %.3f (pinned buffer %.3f, prepare %.3f, ctx %.3f) wait-for-reader %.3f deal %.3f submit %.3f "
+              "gpu(wait) %.3f wait-for-formatter %.3f (formatter busy %.3f) teardown %.3f total %.3f s; steady %.3f s; "
+              "%zu of %zu device(s), count gather: %s\n",
+              t_init, t_pinned, t_prepare, t_ctx, t_wait_read, t_deal, t_submit, t_gpu, t_fmt_wait, t_fmt, now_s() - t_end0,
+              t_total, t_steady, used, n_dev, used_rccl ? "rccl" : "host");
+    }
+  }
+  if (n_lines_in) *n_lines_in = lines_in.load();
   return rc;
 }
 

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/bvcf.h"
 
@@ -20,7 +21,7 @@ struct Cli {
   std::string in, out, err, dosage, sample, fam, empty = "!", delim = ";", cpu_profile;
   std::string allow = "PASS,.", exclude;
   bool no_out = false, keep_id = false, keep_qual = false, keep_pos = false, keep_info = false;
-  int device = 0;
+  std::string devices = "all";  // extension: "all" or a comma-separated list of HIP device ordinals
   unsigned long long batch_mb = 0;
 };
 
@@ -87,8 +88,9 @@ int parse(int argc, char **argv, Cli &c) {
         done = true;
       }
     if (done) continue;
-    // extensions of this build (not in the reference)
-    if (name == "device" || name == "batchMB") {
+    // extensions of this build (not in the reference): the devices the blocks are dealt to (the
+    // counterpart of the reference's NumCPU workers), the block size
+    if (name == "devices" || name == "device" || name == "batchMB") {
       if (!has_val) {
         if (i + 1 >= argc) {
           fprintf(stderr, "flag needs an argument: -%s\n", name.c_str());
@@ -96,10 +98,10 @@ int parse(int argc, char **argv, Cli &c) {
         }
         val = argv[++i];
       }
-      if (name == "device")
-        c.device = atoi(val.c_str());
-      else
+      if (name == "batchMB")
         c.batch_mb = strtoull(val.c_str(), nullptr, 10);
+      else
+        c.devices = val;
       continue;
     }
     fprintf(stderr, "flag provided but not defined: -%s\n", name.c_str());
@@ -156,7 +158,35 @@ int main(int argc, char **argv) {
   cfg.keep_info = c.keep_info;
   cfg.keep_pos = c.keep_pos;
   cfg.keep_qual = c.keep_qual;
-  cfg.device = c.device;
+  // --devices all (default): every visible HIP device; a device only gets a ctx once a block is dealt to it
+  std::vector<int32_t> devs;
+  if (c.devices == "all") {
+    const int n = bvcf_device_count();
+    for (int d = 0; d < n; d++) devs.push_back(d);
+  } else {
+    const char *p = c.devices.c_str();
+    while (*p) {
+      char *e = nullptr;
+      const long d = strtol(p, &e, 10);
+      if (e == p || d < 0) {
+        dprintf(fd_err, "invalid value \"%s\" for flag -devices\n", c.devices.c_str());
+        return 2;
+      }
+      devs.push_back((int32_t)d);
+      p = *e == ',' ? e + 1 : e;
+      if (*e && *e != ',') {
+        dprintf(fd_err, "invalid value \"%s\" for flag -devices\n", c.devices.c_str());
+        return 2;
+      }
+    }
+  }
+  if (devs.empty()) {
+    // no device: bvcf_run_fd reports it (there is no CPU path)
+    devs.push_back(0);
+  }
+  cfg.device = devs[0];
+  cfg.devices = devs.data();
+  cfg.n_devices = (uint32_t)devs.size();
   if (c.batch_mb) cfg.max_batch_bytes = c.batch_mb << 20;
   cfg.sample_list_path = c.sample.c_str();
   cfg.dosage_path = c.dosage.c_str();  // main.go:89

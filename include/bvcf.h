@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BVCF_ABI_VERSION 3
+#define BVCF_ABI_VERSION 4
 
 typedef enum {
   BVCF_OK = 0,
@@ -218,30 +218,23 @@ int bvcf_submit(bvcf_ctx *ctx, const uint8_t *block, size_t nbytes, uint64_t bat
 int bvcf_submit_device(bvcf_ctx *ctx, const void *dblock, size_t nbytes, uint64_t batch_seq);
 /* blocks until the oldest submitted batch is done */
 int bvcf_collect(bvcf_ctx *ctx, bvcf_result *r);
-/* device-resident variant used by benchmarks: runs the kernel chain `iters` times back to back, step i
- * on resident block i % n_blocks (each owning BVCF_DEVICE_PAD bytes past its nbytes), leaving the
- * results in device memory.  HIP events on the launch stream give, per step, the time of the whole
- * chain (chain_ms[i]) and of its dominant kernel (gt_ms[i]): k_gt on the census path, k_stream on the
- * streaming path.  counts receives
- * {lines, alleles, errs, class-map bytes, tasks} of the last step.  Returns after the last step
- * has finished. */
 /* 1 = census path, 2 = streaming path (see bvcf_params.path) */
 int bvcf_path(const bvcf_ctx *ctx);
-
-int bvcf_bench_device(bvcf_ctx *ctx, const void *const *dblocks, const size_t *nbytes, int n_blocks, int iters,
-                      float *chain_ms, float *gt_ms, uint64_t counts[5]);
-/* the same with batch i on slot i % slots_in_use (0 = every slot of the ctx, which is what bvcf_bench_device does):
- * 1 times the chains strictly one after the other, 2 lets consecutive batches overlap as bvcf_submit would */
-int bvcf_bench_device_slots(bvcf_ctx *ctx, const void *const *device_blocks, const size_t *nbytes, int n_blocks, int iters,
-                            uint32_t slots_in_use, float *chain_ms, float *scan_ms, uint64_t counts[5]);
 
 /* running totals since bvcf_create: {lines_in, lines_ok, alleles_out, alleles_ac0, errs,
  * bytes_in, cmap_bytes, kernel_ns} */
 int bvcf_counters(bvcf_ctx *ctx, uint64_t out[8]);
-/* the run summary over several ctxs (one per GPU) driven by one process: element-wise sum of their counters.  The
- * totals live on the host, so this is a host-side sum; one-process-per-GPU deployments gather them with one
- * RCCL all-reduce instead (bench.py does, through torch.distributed) -- the only collective the path has. */
+/* the run summary over several ctxs driven by one process: element-wise sum of their counters, on the host */
 int bvcf_sum_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8]);
+/* the same sum as the final count gather of a multi-GPU run (the only collective the path has): when
+ * the n ctxs sit on n distinct devices (n >= 2) each ctx's totals are uploaded to its device and summed with one
+ * RCCL ncclAllReduce(ncclSum, uint64[8]) over xGMI (single process, ncclCommInitAll; librccl.so.1 is dlopen'ed at
+ * the first call), and out is read back from ctxs[0]'s device.  With one ctx, or ctxs that share a device (RCCL
+ * has one rank per device), the sum is formed on the host as bvcf_sum_counters does.  *used_rccl (optional)
+ * says which of the two happened.  BVCF_RCCL=1 in the environment forces the RCCL path for n == 1 too. */
+int bvcf_allreduce_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8], int *used_rccl);
+/* HIP devices visible to the process (0 when there is none or no runtime) */
+int bvcf_device_count(void);
 
 /* ---- host side of the path: header, TSV assembly, whole-stream driver ---- */
 
@@ -260,7 +253,13 @@ typedef struct {
   const char *sample_list_path; /* --sample: write the sample names, one per line (main.go:398-445); NULL/"" = no */
   const char *dosage_path;      /* --dosageOutput: Arrow IPC file of the dosage matrix (main.go:306-342); NULL/"" = no */
   uint8_t no_out;               /* --noOut: no TSV rows and no header line (main.go:196-208,502) */
-  uint8_t reserved3[7];
+  uint8_t reserved3[3];
+  /* bvcf_run_fd: the HIP devices the blocks of the stream are dealt to, round-robin in input order (the
+   * counterpart of the reference's NumCPU workers, main.go:345-347).  One ctx and one host thread per entry; an
+   * ordinal may repeat (two ctxs sharing a device).  n_devices == 0: the single device `device`.  A device only
+   * gets a ctx once a block is dealt to it, so a short stream does not pay for the devices it does not reach. */
+  uint32_t n_devices;
+  const int32_t *devices;
 } bvcf_config;
 
 void bvcf_config_defaults(bvcf_config *c); /* setup() defaults, main.go:84-99 */
@@ -283,7 +282,11 @@ int bvcf_run_buffer(const bvcf_config *c, const uint8_t *vcf, size_t n, char **o
                     char **log, size_t *n_log, uint64_t *n_lines_in);
 
 /* the same over file descriptors (the CLI): reads fd_in to EOF, writes header + rows to fd_out and
- * log lines to fd_err */
+ * log lines to fd_err.  With bvcf_config.n_devices > 1 the blocks are dealt round-robin to one ctx per device and the
+ * results merged by block number, so the output is the same bytes in the same order for any device list; the
+ * per-ctx counters are summed at the end with bvcf_allreduce_counters.
+ * Environment: BVCF_TIMING=1 adds one "[bvcf timing] ..." line to fd_err, BVCF_TIMING=json one JSON object
+ * "[bvcf timing-json] {...}" (stage times in seconds, the devices used, the summed counters). */
 int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_t *n_lines_in);
 
 /* the byte source in front of bvcf_run_fd on its own: copies fd_in to fd_out, inflating gzip (streaming)

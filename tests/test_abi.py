@@ -23,6 +23,12 @@ def test_exports_every_declared_symbol(bv):
     assert declared == set(bv.EXPORTS), declared ^ set(bv.EXPORTS)
     for name in declared:
         assert hasattr(bv.lib, name), name
+    # the measurement hooks live in their own header, outside the drop-in ABI
+    bench = open(os.path.join(ROOT, "include", "bvcf_bench.h")).read()
+    hooks = set(re.findall(r"\b(bvcf_[a-z_0-9]+)\s*\(", bench))
+    assert hooks == set(bv.BENCH_EXPORTS) and not (hooks & declared)
+    for name in hooks:
+        assert hasattr(bv.lib, name), name
 
 
 def test_struct_layouts_match_header(bv, tmp_path):

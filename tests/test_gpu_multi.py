@@ -1,0 +1,168 @@
+"""More than one ctx in one process: bvcf_run_fd deals the blocks of a stream round-robin to one ctx per
+entry of the device list and merges by block number -- the output must be the same bytes in the same order for any
+list.  The GPU box has one device, so the lists repeat ordinal 0: two or three ctxs alive on it at once."""
+import json
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import vcfgen
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "bystro-vcf_amd", "bystro-vcf")
+
+
+@pytest.fixture(scope="module")
+def bv():
+    import bystro_vcf_amd as b
+    return b
+
+
+def _cli(args, data, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([EXE] + args, input=data, capture_output=True, timeout=600, env=e)
+
+
+def _timing(stderr):
+    for ln in stderr.decode().splitlines():
+        if ln.startswith("[bvcf timing-json] "):
+            return json.loads(ln[len("[bvcf timing-json] "):])
+    return None
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0"])
+def test_cli_device_lists_give_identical_output(bv, golden_1kg, devices):
+    """200 MB of real 1000-Genomes lines in 8 MiB blocks (25 of them) dealt to 1, 2 and 3 ctxs: rows == oracle rows
+    in input order, and the run summary accounts for every block and line"""
+    vcf, want_sorted, hdr = golden_1kg
+    p = _cli(["--batchMB", "8", "--devices", devices], vcf, {"BVCF_TIMING": "json"})
+    assert p.returncode == 0, p.stderr[-400:]
+    rows = p.stdout.split(b"\n")
+    assert rows[0] == hdr and rows[-1] == b""
+    rc_o, out_o, log_o, n_o = orc.run(vcf)
+    assert rows[1:-1] == out_o.split(b"\n")[:-1]          # same bytes, same order
+    assert sorted(rows[1:-1]) == want_sorted               # and the reference's own golden output
+    t = _timing(p.stderr)
+    assert t is not None
+    log_lines = [ln for ln in p.stderr.decode().splitlines() if not ln.startswith("[bvcf timing")]
+    assert "\n".join(log_lines) + "\n" == log_o
+    n_dev = len(devices.split(","))
+    assert len(t["devices"]) == n_dev and t["devices_used"] == n_dev
+    blocks = [d["blocks"] for d in t["devices"]]
+    assert sum(blocks) >= 24 and max(blocks) - min(blocks) <= 1   # round-robin
+    assert t["lines_in"] == n_o == t["counters"][0]
+    assert t["counters"][5] == sum(d["bytes"] for d in t["devices"])
+    assert t["count_gather"] == "host"  # ctxs that share a device: RCCL has one rank per device
+
+
+def test_cli_devices_flags_and_small_input(bv):
+    vcf = vcfgen.gen_vcf(61, 500, 40, weird=0.02)
+    want = (bv.string_header() + "\n").encode() + orc.run(vcf)[1]
+    for args in (["--devices", "all"], ["--devices=0"], ["--device", "0"], ["--devices", "0,0,0,0"]):
+        p = _cli(args, vcf, {"BVCF_TIMING": "json"})
+        assert p.returncode == 0 and p.stdout == want, args
+        assert _timing(p.stderr)["devices_used"] == 1  # one block: only the first ctx is ever created
+    assert _cli(["--devices", "x"], vcf).returncode == 2
+    assert _cli(["--devices", "99"], vcf).returncode == 1  # no such device: fatal, never a CPU path
+
+
+def test_capacity_growth_with_two_ctxs(bv):
+    """short junk lines between the records exceed the first reservation on both ctxs (see
+    test_cli_many_batches_with_capacity_growth): each grows its own, the merge keeps input order"""
+    import random
+    rng = random.Random(78)
+    ns = 300
+    rows = [vcfgen.header(ns)]
+    pos = 1000
+    for k in range(16000):
+        pos += rng.randint(1, 40)
+        if k % 3 == 0:
+            gts = ["0|1" if rng.random() < 0.02 else ("1|1" if rng.random() < 0.01 else "0|0") for _ in range(ns)]
+            rows.append("\t".join(["chr2", str(pos), ".", "C", "T", ".", "PASS", ".", "GT"] + gts) + "\n")
+        else:
+            rows.extend(["chr2\t%d\t.\tA\tG\n" % pos] * (200 if k % 50 == 1 else 2))
+    vcf = "".join(rows).encode()
+    rc_o, out_o, log_o, _ = orc.run(vcf)
+    p = _cli(["--batchMB", "1", "--devices", "0,0"], vcf)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert p.stdout == (bv.string_header() + "\n").encode() + out_o
+    assert p.stderr.decode() == log_o
+
+
+def test_two_ctxs_driven_from_two_threads(bv):
+    """the ABI's promise (include/bvcf.h): distinct ctxs are independent and may be driven from different host
+    threads.  Two ctxs on device 0, each fed its own blocks concurrently, both paths; results == a lone ctx's."""
+    blocks = [vcfgen.gen_vcf(70 + i, 400, 2504 if i % 2 else 300, weird=0.02) for i in range(4)]
+
+    def body(vcf):
+        return vcf[vcf.index(b"\n", vcf.index(b"#CHROM")) + 1:]
+
+    def n_hdr(vcf):
+        i = vcf.index(b"#CHROM")
+        return vcf[i:vcf.index(b"\n", i)].count(b"\t") + 1
+
+    def key(b):
+        L = b.lines[["off", "len", "n_rec", "status", "site_type", "n_fields"]]
+        slots = [s for i in range(len(b.lines)) for s in b.record_slots(i)]
+        A = b.alleles[slots][["pos", "alt_idx", "alt_len", "ac", "an", "n_het", "n_hom", "n_miss", "ref", "alt_base", "kind", "trtv"]]
+        cls = [b.classes(b.alleles[s]).tobytes() for s in slots if int(b.alleles[s]["cmap_off"]) != bv.NO_CMAP]
+        return L.tobytes(), A.tobytes(), cls
+
+    want = {}
+    for i, vcf in enumerate(blocks):
+        ctx = bv.Ctx(n_hdr(vcf), allow="")
+        want[i] = key(ctx.process(body(vcf)))
+        ctx.close()
+
+    got, errs = {}, []
+
+    def run(ids, path):
+        try:
+            for rep in range(3):
+                for i in ids:
+                    ctx = bv.Ctx(n_hdr(blocks[i]), allow="", path=path)
+                    got[(i, path, rep)] = key(ctx.process(body(blocks[i])))
+                    ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=([0, 1], 1)), threading.Thread(target=run, args=([2, 3], 2)),
+          threading.Thread(target=run, args=([1, 2], 0))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for (i, path, rep), k in got.items():
+        assert k == want[i], (i, path, rep)
+
+
+def test_count_gather_over_rccl(bv, monkeypatch):
+    """the path's one collective: ncclAllReduce(sum) of the uint64[8] counters.  One device here, so the RCCL leg is
+    forced for a single rank (BVCF_RCCL=1) and must return that ctx's own totals; two ctxs on one device fall to the
+    host sum (RCCL has one rank per device) and must add up."""
+    vcf = vcfgen.gen_vcf(90, 600, 64, weird=0.02)
+    body = vcf[vcf.index(b"\n", vcf.index(b"#CHROM")) + 1:]
+    a, b = bv.Ctx(9 + 64, allow=""), bv.Ctx(9 + 64, allow="")
+    try:
+        a.process(body)
+        b.process(body)
+        b.process(body)
+        ca, cb = a.counters(), b.counters()
+        n = body.count(b"\n")
+        assert ca[0] == n and cb[0] == 2 * n
+        tot, used = bv.allreduce_counters([a, b])
+        assert not used and tot == [x + y for x, y in zip(ca, cb)]
+        monkeypatch.setenv("BVCF_RCCL", "1")
+        tot1, used1 = bv.allreduce_counters([b])
+        assert used1 and tot1 == cb
+    finally:
+        a.close()
+        b.close()
