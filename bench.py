@@ -4,24 +4,39 @@
     python bench.py --gpus N --steps K --warmup W            (N == 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  A step = one pass of the whole kernel chain (line index, head/getAlleles,
-genotype scan, finish) over one resident batch of `--rows` synthetic rows (BASELINE.json configs[2]:
-2 504 samples, biallelic SNPs, ~10 164 B/row).  `--blocks` distinct batches are generated on the
-device before timing and visited round-robin, each far larger than the 256 MiB Infinity Cache, so
-every step streams its text from HBM.  Batches are dealt to `--slots` result slots (default 2, the
-library's default), each with its own HIP stream, exactly as bvcf_submit deals them: the short
-latency-bound kernels that end one batch's chain overlap the next batch's scan.  Records are independent: rank r owns its own rows (weak
+One process per GPU.  A STEP = one pass of the whole kernel chain (line index, head/getAlleles, genotype scan,
+finish) over the rank's whole resident set: `--blocks` blocks of `--rows` synthetic rows each (BASELINE.json
+configs[2]: 2 504 samples, biallelic SNPs, ~10 166 B/row; by default 8 x 311 296 rows = 2.49 M rows = 25.3 GB of text
+per step, so the 20 steps of the driver's run visit 49.8 M rows -- eight times the 6.2 M rows of configs[2] -- in
+about 0.1 s).  A block is what one bvcf_submit takes (< 4 GiB: offsets are 32-bit); the blocks are generated on the
+device before timing and visited in order, 25 GB between two visits of the same byte (the Infinity Cache holds
+256 MiB), so every launch streams its text from HBM.  Blocks are dealt to `--slots` result slots (default 2, the
+library's default), each with its own HIP stream, exactly as bvcf_submit deals them: the short latency-bound kernels
+that end one block's chain overlap the next block's scan.  Records are independent: rank r owns its own rows (weak
 scaling), no collective in the data path; the per-rank variant counts are summed over RCCL at the end.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_stream on the streaming
-path, k_gt on the census path): achieved = algorithmic text bytes per launch / its mean HIP-event
-duration inside the timed region.  `cpu_baseline` (rank 0, N == 1 only) times the CPU oracle — the C restatement of the
-reference algorithm, kind "port" — on a bounded sample of the same row model.
+Prints ONE JSON line (rank 0):
+  roofline      the dominant kernel (k_stream on the streaming path, k_gt on the census path, k_sites on sites-only
+                input).  achieved / frac: algorithmic text bytes per launch / its mean HIP-event duration with ONE
+                block at a time (the kernel alone on the GPU; a pass right after the timed region).  chain_frac:
+                the same bytes / the timed region's time per block (ms_per_step / blocks) / peak -- what the whole
+                chain sustains with two blocks in flight.  in_timed_region_*: the kernel's HIP-event duration inside
+                the timed region, where it shares the CUs with the previous block's tail kernels (longer than the
+                time per block: two launches overlap; informational).
+  e2e           (rank 0, N == 1) the CLI end to end: `bystro-vcf --in <file in /dev/shm> > /dev/null` over
+                >= 1 M rows of the same stream (the first blocks of the resident set, copied back to the host), wall
+                and steady-state variants/s, the BVCF_TIMING stage split, and the md5 of its output against the
+                oracle CLI's on a prefix of the file.  PCIe-inclusive: never `value`.
+  cpu_baseline  (rank 0, N == 1) the CPU oracle -- the C restatement of the reference algorithm, kind "port" -- over
+                the same file with all host cores and with 4 threads (the README's box has 4 cores).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -30,34 +45,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+CLI = os.path.join(ROOT, "bystro-vcf_amd", "bystro-vcf")
+ORACLE = os.path.join(ROOT, "oracle", "bvcf_oracle")
 
-
-def cpu_baseline(profile, rows_total=400_000, chunk=25_000):
-    """the oracle (oracle/bvcf_oracle.c), all host cores, on a bounded sample of the same rows"""
-    import benchgen as bg
-    import oracle_lib as orc
-
-    cfg = bg.make_cfg(profile)
-    hdr = bg.header(cfg)
-    cores = os.cpu_count() or 1
-    elapsed, rows, out_rows = 0.0, 0, 0
-    for first in range(0, rows_total, chunk):
-        vcf = hdr + bg.rows_host(cfg, 10_000_000 + first, chunk)
-        t0 = time.perf_counter()
-        rc, out, _, n = orc.run(vcf, None, n_threads=cores)
-        elapsed += time.perf_counter() - t0
-        assert rc == 0 and n == chunk
-        rows += n
-        out_rows += out.count(b"\n")
-    return {
-        "value": rows / elapsed, "unit": "variants/s", "cores": cores, "kind": "port",
-        "sample": "%d rows of the same synthetic %s stream (%d-row chunks), oracle/bvcf_oracle.c with %d worker "
-                  "threads over 64-line batches, output discarded; %.1f s wall" % (rows, profile, chunk, cores, elapsed),
-    }
+# per profile: rows per block, resident blocks (a step visits all of them)
+SHAPES = {"c2": (1_000_000, 8), "c3": (311_296, 8), "c4": (262_144, 8), "c5": (98_304, 8)}
+WORKLOADS = {"c2": "BASELINE configs[1]: sites-only, biallelic SNPs, 0 samples",
+             "c3": "BASELINE configs[2]: 1KG-Phase3 chr1-shaped, 2504 samples, biallelic SNPs",
+             "c4": "BASELINE configs[3]: 2504 samples, 20% multiallelic + 15% indels",
+             "c5": "not a BASELINE config: 2504 samples with GT:DP:GQ fields (general scan path)"}
 
 
 def rank_blocks(rank, n_blocks, rows):
-    """first row of each resident batch of `rank`: rank r owns rows [r*B*R, (r+1)*B*R) — disjoint
+    """first row of each resident block of `rank`: rank r owns rows [r*B*R, (r+1)*B*R) — disjoint
     shards, no data-path collective (records are independent, main.go:534-698)"""
     return [(rank * n_blocks + b) * rows for b in range(n_blocks)]
 
@@ -74,27 +74,134 @@ def reduce_over_ranks(elapsed, n_variants, device, world):
     return float(t_el.item()), float(n_var.item())
 
 
+def _md5_stdout(cmd, stdin_path=None):
+    h = hashlib.md5()
+    with open(stdin_path or os.devnull, "rb") as f:
+        p = subprocess.Popen(cmd, stdin=f, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        for chunk in iter(lambda: p.stdout.read(1 << 24), b""):
+            h.update(chunk)
+        p.wait()
+    return p.returncode, h.hexdigest()
+
+
+def write_e2e_file(header, blocks, sizes, want_rows, rows_per_block):
+    """header + the first blocks of the resident set (device -> host) into /dev/shm (page cache if it does not fit)"""
+    n_blk = max(1, min(len(blocks), -(-want_rows // rows_per_block)))
+    need = len(header) + sum(sizes[:n_blk])
+    base = "/dev/shm"
+    try:
+        st = os.statvfs(base)
+        if st.f_bavail * st.f_frsize < need * 1.15:
+            base = "/tmp"
+    except OSError:
+        base = "/tmp"
+    path = os.path.join(base, "bvcf_bench_e2e_%d.vcf" % os.getpid())
+    with open(path, "wb") as f:
+        f.write(header)
+        for t, nb in zip(blocks[:n_blk], sizes[:n_blk]):
+            step = 1 << 30
+            for off in range(0, nb, step):
+                f.write(memoryview(t[off:min(off + step, nb)].cpu().numpy()))
+    return path, n_blk * rows_per_block, need, base
+
+
+def e2e_leg(path, rows, nbytes, where, prefix_path, prefix_rows, devices, runs=2):
+    """the CLI over the file, wall clock around the process; BVCF_TIMING=json gives the stage split"""
+    env = dict(os.environ, BVCF_TIMING="json")
+    best = None
+    walls = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        with open(os.devnull, "wb") as out:
+            p = subprocess.run([CLI, "--in", path, "--devices", devices], stdout=out, stderr=subprocess.PIPE, env=env)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": "CLI rc %d: %s" % (p.returncode, p.stderr[-300:].decode(errors="replace"))}
+        stages = None
+        for ln in p.stderr.decode(errors="replace").splitlines():
+            if ln.startswith("[bvcf timing-json] "):
+                stages = json.loads(ln[len("[bvcf timing-json] "):])
+        walls.append(wall)
+        if best is None or wall < best[0]:
+            best = (wall, stages)
+    wall, stages = best
+    out = {
+        "input": "%d rows, %.2f GB of the same synthetic stream in %s -> bystro-vcf --in --devices %s (HIP) -> /dev/null" % (
+            rows, nbytes / 1e9, where, devices),
+        "devices": devices,
+        "rows": rows, "bytes": nbytes, "runs_wall_s": walls, "wall_s": wall,
+        "variants_per_s": rows / wall, "variants_per_min": rows / wall * 60, "text_GBps": nbytes / wall / 1e9,
+        "stages": stages,
+    }
+    if stages and stages.get("steady_s"):
+        # from the first block's submit to the last byte written: the run without process / HIP start-up and teardown
+        out["steady_variants_per_s"] = rows / stages["steady_s"]
+        out["steady_variants_per_min"] = rows / stages["steady_s"] * 60
+        out["steady_text_GBps"] = nbytes / stages["steady_s"] / 1e9
+        assert stages["lines_in"] == rows, (stages["lines_in"], rows)
+    if not prefix_path:
+        return out
+    # parity on a prefix of the same stream: md5 of the CLI's stdout == md5 of the oracle CLI's
+    rc_g, m_g = _md5_stdout([CLI, "--in", prefix_path, "--devices", devices])
+    rc_o, m_o = _md5_stdout([ORACLE, "--in", prefix_path, "--threads", str(min(os.cpu_count() or 1, 64))])
+    out["md5_check"] = {"rows": prefix_rows, "hip": m_g, "oracle": m_o, "equal": rc_g == 0 and rc_o == 0 and m_g == m_o}
+    return out
+
+
+def cpu_baseline(path, rows, profile):
+    """oracle/bvcf_oracle (the CLI of the C restatement: N workers over 64-line batches, split-then-scan, per-allele
+    rescan) over the e2e file, output to /dev/null as in README.md:49: all host cores, and 4 threads"""
+    cores = os.cpu_count() or 1
+
+    def run(threads):
+        t0 = time.perf_counter()
+        with open(os.devnull, "wb") as out:
+            p = subprocess.run([ORACLE, "--in", path, "--threads", str(threads), "--timing"], stdout=out, stderr=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        m = re.search(r"\[oracle timing\] rows (\d+) threads (\d+) read ([\d.]+) process ([\d.]+) write ([\d.]+)", p.stderr.decode(errors="replace"))
+        assert p.returncode == 0 and m and int(m.group(1)) == rows, p.stderr[-300:]
+        return {"threads": threads, "process_s": float(m.group(4)), "read_s": float(m.group(3)), "write_s": float(m.group(5)),
+                "wall_s": wall, "variants_per_s": rows / float(m.group(4))}
+
+    full, four = run(cores), run(4)
+    return {
+        "value": full["variants_per_s"], "unit": "variants/s", "cores": cores, "kind": "port",
+        "sample": "%d rows of the same synthetic %s stream (the e2e file), oracle/bvcf_oracle with %d worker threads over 64-line "
+                  "batches, output to /dev/null; rate = rows / readVcf time (%.2f s), input already in memory (reading it took %.2f s)"
+                  % (rows, profile, cores, full["process_s"], full["read_s"]),
+        "threads_4": {"value": four["variants_per_s"], "unit": "variants/s", "cores": 4, "process_s": four["process_s"],
+                      "wall_s": four["wall_s"]},
+        "all_cores": full,
+        "published_reference": "README.md:44-52: 6.2 M variants in 2 m 45 s on a 4-core i3.2xlarge = 37.6 k variants/s (Go, pigz-bound)",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=131072, help="rows per step per GPU")
-    ap.add_argument("--blocks", type=int, default=4, help="distinct resident batches per GPU")
+    ap.add_argument("--rows", type=int, default=0, help="rows per block per GPU (0 = the profile's default)")
+    ap.add_argument("--blocks", type=int, default=0, help="resident blocks per GPU; a step visits all of them (0 = default)")
     ap.add_argument("--profile", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--samples", type=int, default=0, help="experiment: another sample count for the profile (e.g. 100000 with --rows 640)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-rows", type=int, default=1_200_000, help="rows of the end-to-end / cpu_baseline file (rounded up to whole blocks)")
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
     ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
     ap.add_argument("--path", type=int, default=0, help="0 choose, 1 census path, 2 streaming path")
     ap.add_argument("--slots", type=int, default=2,
-                    help="batches in flight per GPU: batch i runs on slot i %% slots, each slot on its own HIP stream, as "
-                         "bvcf_submit deals them (bvcf_params.n_slots, library default 2); 1 = strictly one batch after "
+                    help="blocks in flight per GPU: block i runs on slot i %% slots, each slot on its own HIP stream, as "
+                         "bvcf_submit deals them (bvcf_params.n_slots, library default 2); 1 = strictly one block after "
                          "the other")
     ap.add_argument("--golden", action="store_true",
                     help="experiment: real 1000-Genomes lines (tests/golden/1kg_chr1_20klines.vcf.gz, 19 747 rows "
                          "replicated to --rows) instead of the synthetic model")
     args = ap.parse_args()
+    d_rows, d_blocks = SHAPES[args.profile]
+    args.rows = args.rows or d_rows
+    args.blocks = args.blocks or d_blocks
 
     import torch
     import torch.distributed as dist
@@ -116,7 +223,7 @@ def main():
         args.path = 1  # FORMAT is not plain GT: the host driver (choose_path) sends such files down the census path
     cfg = bg.make_cfg(args.profile, align16=int(args.align16), **({"n_samples": args.samples} if args.samples else {}))
     ns = cfg.n_samples
-    # ---- synthetic batches, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)
+    # ---- synthetic blocks, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)
     blocks, sizes = [], []
     if args.golden:
         import gzip
@@ -145,7 +252,7 @@ def main():
     n_alt_cap = args.rows * (4 if args.profile == "c4" or args.golden else 1) + 1024
     ctx = bv.Ctx(bg.n_header_fields(cfg), device=local_rank, max_batch_bytes=max_bytes, n_slots=max(1, args.slots),
                  max_lines=args.rows + 16, max_alleles=n_alt_cap,
-                 cmap_bytes=(n_alt_cap + 16 * 8192) * stride + 4096,  # + the slack of the streaming path's per-wave slot ranges
+                 cmap_bytes=min((n_alt_cap + 16 * 8192) * stride + 4096, 0xFFFFFF00),  # + the slack of the streaming path's per-wave slot ranges
                  path=args.path,
                  want_class_maps=not args.no_class_maps)
     ptrs = [t.data_ptr() for t in blocks]
@@ -154,43 +261,46 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # ---- warm-up, then exactly K timed steps between barrier + synchronize on both sides
+    # ---- warm-up, then exactly K timed steps between barrier + synchronize on both sides; a step = every block once
+    n_launch = args.steps * args.blocks
     if args.warmup:
-        ctx.bench_device(ptrs, sizes, args.warmup)
+        ctx.bench_device(ptrs, sizes, args.warmup * args.blocks)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    chain_ms, gt_ms, counts = ctx.bench_device(ptrs, sizes, args.steps)
+    chain_ms, gt_ms, counts = ctx.bench_device(ptrs, sizes, n_launch)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
 
     assert counts[0] == args.rows, counts
     # the final count gather over RCCL/xGMI (and the slowest rank's clock)
-    elapsed, total_variants = reduce_over_ranks(elapsed, args.rows * args.steps, "cuda", world)
-    # outside the timed region (rank 0): the same chain strictly one batch after the other, for the dominant
+    elapsed, total_variants = reduce_over_ranks(elapsed, args.rows * n_launch, "cuda", world)
+    # outside the timed region (rank 0): the same chain strictly one block after the other, for the dominant
     # kernel's duration when it has the GPU to itself
-    alone_ms = None
-    if rank == 0 and args.slots > 1:
-        _, alone, _ = ctx.bench_device(ptrs, sizes, max(4, min(args.steps, 8)), slots=1)
+    alone_ms, alone_chain_ms = None, None
+    if rank == 0:
+        a_chain, alone, _ = ctx.bench_device(ptrs, sizes, max(args.blocks, 8), slots=1)
         alone_ms = sum(alone) / len(alone)
+        alone_chain_ms = sum(a_chain) / len(a_chain)
 
     if rank == 0:
-        mean_bytes = sum(sizes[i % args.blocks] for i in range(args.steps)) / args.steps
+        mean_bytes = sum(sizes) / len(sizes)
         gt_mean_ms = sum(gt_ms) / len(gt_ms)
         chain_mean_ms = sum(chain_ms) / len(chain_ms)
-        # algorithmic bytes of one launch of the dominant kernel.  Census path, k_gt: the GT text of
-        # every row (4 bytes per sample).  Streaming path, k_stream: every byte of every row (it is
-        # also the pass that finds the lines).
+        ms_per_block = elapsed / n_launch * 1e3
+        # algorithmic bytes of one launch of the dominant kernel.  Census path with samples, k_gt: the GT text of
+        # every row (4 bytes per sample).  Streaming path, k_stream, and sites-only input, k_sites: every byte of
+        # every row (it is also the pass that finds the lines).
         streaming = ctx.path() == 2
-        kernel = "k_stream" if streaming else "k_gt"
-        gt_bytes = int(mean_bytes) if streaming else args.rows * 4 * ns
-        achieved = gt_bytes / (gt_mean_ms * 1e-3) / 1e9 if ns else None
+        kernel = "k_stream" if streaming else ("k_gt" if ns else "k_sites")
+        alg_bytes = int(mean_bytes) if (streaming or not ns) else args.rows * 4 * ns
+        achieved = alg_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms else None
         pmc = None
         try:
             with open(os.path.join(ROOT, "profiles", "k_gt_hbm_traffic.json")) as f:
-                pmc = json.load(f).get(args.profile, {}).get("k_stream_traffic_bytes_per_launch_per_row" if ctx.path() == 2 else "traffic_bytes_per_launch_per_row")
+                pmc = json.load(f).get(args.profile, {}).get("k_stream_traffic_bytes_per_launch_per_row" if streaming else "traffic_bytes_per_launch_per_row")
         except OSError:
             pass
         line = {
@@ -207,36 +317,62 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": {"c2": "BASELINE configs[1]: sites-only, 1M biallelic SNPs, 0 samples",
-                             "c3": "BASELINE configs[2]: 1KG-Phase3 chr1-shaped, 2504 samples, biallelic SNPs",
-                             "c4": "BASELINE configs[3]: 2504 samples, 20% multiallelic + 15% indels",
-                             "c5": "not a BASELINE config: 2504 samples with GT:DP:GQ fields (general scan path)"}[args.profile],
-                "rows_per_step_per_gpu": args.rows, "resident_batches_per_gpu": args.blocks,
-                "bytes_per_row": mean_bytes / args.rows, "n_samples": ns,
+                "workload": WORKLOADS[args.profile],
+                "rows_per_step_per_gpu": args.rows * args.blocks, "rows_per_block": args.rows,
+                "resident_blocks_per_gpu": args.blocks, "rows_in_timed_region": int(total_variants),
+                "bytes_per_row": mean_bytes / args.rows, "bytes_per_step_per_gpu": sum(sizes), "n_samples": ns,
                 "flags": "default (--allowFilter PASS,.), class maps on", "input": "resident in HBM",
-                "batches_in_flight": args.slots,
+                "blocks_in_flight": args.slots,
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": (pmc * args.rows) if pmc else None,
-                "algorithmic_bytes_per_launch": gt_bytes, "mean_launch_ms": gt_mean_ms,
-                # (informational, measured after the timed region) the same kernel with one batch at a time: in the
-                # timed region the end of the previous batch's chain shares the GPU with it
-                "mean_launch_ms_one_batch_at_a_time": alone_ms,
-                "frac_one_batch_at_a_time": (gt_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if alone_ms and ns else None,
-                "note": ("with --slots > 1 a launch shares the GPU with the kernels that end the previous batch's chain, so "
-                         "its duration (mean_launch_ms, achieved, frac) is longer than the step time would suggest; "
-                         "*_one_batch_at_a_time is the same kernel with the GPU to itself") if args.slots > 1 else None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "mean_launch_ms": alone_ms,
+                "how": "HIP events around the kernel on its launch stream, one block at a time (the kernel alone on the GPU), "
+                       "%d launches right after the timed region" % max(args.blocks, 8),
+                # what the whole chain sustains inside the timed region: bytes per block / wall time per block
+                "chain_frac": mean_bytes / (ms_per_block * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "chain_GBps": mean_bytes / (ms_per_block * 1e-3) / 1e9,
+                "ms_per_block": ms_per_block,
+                "chain_ms_one_block_at_a_time": alone_chain_ms,
+                # informational: the kernel's duration inside the timed region, where it shares the CUs with the
+                # previous block's tail kernels -- two launches overlap, so this is longer than ms_per_block
+                "in_timed_region_mean_launch_ms": gt_mean_ms,
+                "in_timed_region_chain_latency_ms": chain_mean_ms,
             },
-            # one batch's kernel chain from its first to its last kernel (HIP events): a latency -- with more than one
-            # batch in flight consecutive chains overlap, and the step time is ms_per_step
-            "chain": {"mean_ms": chain_mean_ms},
-            "text_GBps": mean_bytes * world / (elapsed / args.steps) / 1e9,
+            "text_GBps": sum(sizes) * world / (elapsed / args.steps) / 1e9,
             "variants_per_min": total_variants / elapsed * 60,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.profile)
+        want_host_legs = world == 1 and not args.golden and not (args.no_e2e and args.no_cpu_baseline)
+        if want_host_legs:
+            path = prefix = None
+            try:
+                hdr = bg.header(cfg)
+                path, f_rows, f_bytes, where = write_e2e_file(hdr, blocks, sizes, args.e2e_rows, args.rows)
+                if not args.no_e2e:
+                    # prefix of the same stream for the md5 check: rows [first, first + n) of block 0
+                    p_rows = min(args.rows, 65_536 if ns else 1_000_000)
+                    pt, pn = bg.rows_device(cfg, rank_blocks(rank, args.blocks, args.rows)[0], p_rows, pad=bv.DEVICE_PAD)
+                    prefix = path + ".prefix"
+                    with open(prefix, "wb") as f:
+                        f.write(hdr)
+                        f.write(memoryview(pt[:pn].cpu().numpy()))
+                    del pt
+                    line["e2e"] = e2e_leg(path, f_rows, f_bytes, where, prefix, p_rows, str(local_rank))
+                    n_vis = torch.cuda.device_count()
+                    if n_vis > 1:
+                        # (not part of `value`, which is this rank's GPU alone) the same file dealt block by block to every
+                        # visible device by the one CLI process
+                        line["e2e_all_devices"] = e2e_leg(path, f_rows, f_bytes, where, None, 0,
+                                                          ",".join(str(d) for d in range(n_vis)), runs=2)
+                if not args.no_cpu_baseline:
+                    line["cpu_baseline"] = cpu_baseline(path, f_rows, args.profile)
+            finally:
+                for q in (path, prefix):
+                    if q and os.path.exists(q):
+                        os.unlink(q)
         print(json.dumps(line))
     ctx.close()
     if world > 1:

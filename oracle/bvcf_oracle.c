@@ -22,6 +22,7 @@
 #include <errno.h>
 #include <limits.h>
 #include <pthread.h>
+#include <time.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1057,9 +1058,10 @@ int main(int argc, char **argv) {
   orc_config cfg;
   orc_config_defaults(&cfg);
   const char *in_path = NULL, *threads = NULL, *raw = NULL;
+  int timing = 0; /* --timing: one "[oracle timing] ..." line on stderr (bench.py's cpu_baseline leg) */
   for (int i = 1; i < argc; i++) {
     if (flag_bool(argv[i], "keepId", &cfg.keep_id) || flag_bool(argv[i], "keepInfo", &cfg.keep_info) ||
-        flag_bool(argv[i], "keepPos", &cfg.keep_pos))
+        flag_bool(argv[i], "keepPos", &cfg.keep_pos) || flag_bool(argv[i], "timing", &timing))
       continue;
     if (flag_str(argc, argv, &i, "emptyField", &cfg.empty_field) ||
         flag_str(argc, argv, &i, "fieldDelimiter", &cfg.field_delimiter) ||
@@ -1079,6 +1081,8 @@ int main(int argc, char **argv) {
     perror(in_path);
     return 1;
   }
+  struct timespec ts0, ts1, ts2, ts3;
+  clock_gettime(CLOCK_MONOTONIC, &ts0);
   orc_buf in;
   orc_buf_init(&in);
   for (;;) {
@@ -1092,9 +1096,21 @@ int main(int argc, char **argv) {
   orc_buf_init(&err);
   orc_string_header(&cfg, &out);
   buf_putc(&out, '\n');
-  int rv = orc_read_vcf(&cfg, in.data ? in.data : "", in.len, &out, &err, NULL);
+  uint64_t n_rows = 0;
+  clock_gettime(CLOCK_MONOTONIC, &ts1);
+  int rv = orc_read_vcf(&cfg, in.data ? in.data : "", in.len, &out, &err, &n_rows);
+  clock_gettime(CLOCK_MONOTONIC, &ts2);
   fwrite(out.data, 1, out.len, stdout);
   if (err.len) fwrite(err.data, 1, err.len, stderr);
+  clock_gettime(CLOCK_MONOTONIC, &ts3);
+  if (timing) {
+    /* read = input into memory; process = readVcf (line delivery + the workers, main.go:241-396); write = output */
+    fprintf(stderr, "[oracle timing] rows %llu threads %d read %.3f process %.3f write %.3f s\n", (unsigned long long)n_rows,
+            cfg.n_threads > 1 ? cfg.n_threads : 1,
+            (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec),
+            (double)(ts2.tv_sec - ts1.tv_sec) + 1e-9 * (double)(ts2.tv_nsec - ts1.tv_nsec),
+            (double)(ts3.tv_sec - ts2.tv_sec) + 1e-9 * (double)(ts3.tv_nsec - ts2.tv_nsec));
+  }
   orc_buf_free(&in);
   orc_buf_free(&out);
   orc_buf_free(&err);

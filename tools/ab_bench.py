@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of two libbvcf builds (not a test): alternates BVCF_LIB between the given .so files
 and prints per-build medians of the dominant kernel and of the chain.
-usage: python tests/ab_bench.py libA.so libB.so [rounds] [-- extra bench.py args]"""
+usage: python tools/ab_bench.py libA.so libB.so [rounds] [-- extra bench.py args]"""
 import json
 import os
 import statistics
@@ -20,10 +20,10 @@ res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ, BVCF_LIB=os.path.abspath(l))
-        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2",
-                                       "--no-cpu-baseline", "--slots", "1"] + extra, env=env, stderr=subprocess.DEVNULL)
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
+                                       "--no-cpu-baseline", "--no-e2e", "--slots", "1", "--blocks", "4"] + extra, env=env, stderr=subprocess.DEVNULL)
         d = json.loads(out.decode().strip().splitlines()[-1])
-        res[l].append((d["roofline"]["mean_launch_ms"], d["chain"]["mean_ms"]))
+        res[l].append((d["roofline"]["mean_launch_ms"], d["roofline"]["chain_ms_one_block_at_a_time"]))
 for l in libs:
     k = [x[0] for x in res[l]]
     c = [x[1] for x in res[l]]

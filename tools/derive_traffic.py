@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """profiles/k_gt_hbm_traffic.json from the four FETCH_SIZE / WRITE_SIZE rocprofv3 csv files.
-usage: python tools/derive_traffic.py <dir with pmc_{fetch,write}_size_{streaming,census}.csv> > profiles/k_gt_hbm_traffic.json"""
+usage: python tools/derive_traffic.py <dir with pmc_{fetch,write}_size_{streaming,census}.csv> [rows per dispatch] > profiles/k_gt_hbm_traffic.json"""
 import csv, json, sys, collections
 
 d = sys.argv[1]
-rows = 131072
+rows = int(sys.argv[2]) if len(sys.argv) > 2 else 311296  # rows per dispatch (bench.py SHAPES["c3"])
 raw = collections.defaultdict(dict)
 for ctr, tagc in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     for path, kernels in (("streaming", ("k_stream",)), ("census", ("k_gt", "k_count_eol"))):
@@ -17,7 +17,7 @@ for ctr, tagc in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             raw[k][ctr] = sum(v) / len(v)
 out = {
     "_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with nothing but --output-format csv) on "
-                "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --path {1,2}` (c3, 131072 rows per dispatch), "
+                "`python bench.py --steps 1 --warmup 0 --blocks 3 --no-cpu-baseline --no-e2e --path {1,2}` (c3, %d rows per dispatch), " % rows +
                 "tools/refresh_profiles.sh + tools/derive_traffic.py. Raw counters are KiB per dispatch, mean over dispatches. "
                 "gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly half of a 16 B/lane streaming read, "
                 "so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact.",
