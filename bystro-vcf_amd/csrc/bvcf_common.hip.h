@@ -215,9 +215,11 @@ __device__ __forceinline__ uint32_t eq_mask16(u32x4 v, uint32_t c) {
   return (lo >> 7) | (hi << 1);
 }
 
-// bits [0, n) of a 16-bit mask, n may be <= 0 or >= 16
-__device__ __forceinline__ uint32_t low_bits16(int n) {
-  return n <= 0 ? 0u : (n >= 16 ? 0xFFFFu : ((1u << n) - 1u));
+// bits [0, end - off) of a 16-bit mask for two byte offsets in any order, over the whole 32-bit range (blocks reach
+// past 2 GiB: a signed difference would wrap)
+__device__ __forceinline__ uint32_t bits_until(uint32_t end, uint32_t off) {
+  const uint32_t n = min(end - min(end, off), 16u);
+  return (1u << n) - 1u;
 }
 
 

@@ -79,6 +79,10 @@ namespace {
 
 thread_local std::string g_create_err;
 
+// Offsets into a block are 32-bit; the kernels read up to a few KiB past the last line (clamped loads, tile
+// rounding), so a block stays a megabyte short of 4 GiB.
+constexpr uint64_t kMaxBlockBytes = 0xFFF00000ull;
+
 #define HIP_TRY(ctx, expr)                                                               \
   do {                                                                                   \
     hipError_t e_ = (expr);                                                              \
@@ -329,7 +333,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
 
 int submit_common(bvcf_ctx *c, const uint8_t *host_block, const void *dev_block, size_t nbytes, uint64_t seq) {
   if (!c) return BVCF_E_ARG;
-  if (nbytes > c->p.max_batch_bytes || nbytes >= 0xFFFFFF00ull) {
+  if (nbytes > c->p.max_batch_bytes || nbytes >= kMaxBlockBytes) {
     c->err = "block larger than max_batch_bytes";
     return BVCF_E_TOO_BIG;
   }
@@ -407,6 +411,7 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   c->p = *p;
   c->device = p->device;
   if (!c->p.max_batch_bytes) c->p.max_batch_bytes = 64ull << 20;
+  if (c->p.max_batch_bytes >= kMaxBlockBytes) c->p.max_batch_bytes = kMaxBlockBytes - 1;
   if (!c->p.n_slots) c->p.n_slots = 2;
   if (!c->p.eol_byte) c->p.eol_byte = '\n';
   c->n_samples = p->n_header_fields > 9 ? p->n_header_fields - 9 : 0;
@@ -429,7 +434,7 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   c->tile_bytes = 64u << 10;  // (8-64 KiB measure alike now that the runs are balanced)
   if (const char *e = getenv("BVCF_TILE_KB")) {
     const unsigned kb = (unsigned)atoi(e);
-    if (kb >= 4 && kb <= (1u << 20)) c->tile_bytes = kb << 10;
+    if (kb >= 4 && kb <= 1024) c->tile_bytes = kb << 10;
   }
   uint32_t path = p->path;
   if (const char *e = getenv("BVCF_PATH")) path = (uint32_t)atoi(e);  // test / tuning override
@@ -760,7 +765,7 @@ int bvcf_bench_device_slots(bvcf_ctx *c, const void *const *dblocks, const size_
     return BVCF_E_BUSY;
   }
   for (int b = 0; b < n_blocks; b++)
-    if (!dblocks[b] || nbytes[b] > c->p.max_batch_bytes || nbytes[b] >= 0xFFFFFF00ull) return BVCF_E_TOO_BIG;
+    if (!dblocks[b] || nbytes[b] > c->p.max_batch_bytes || nbytes[b] >= kMaxBlockBytes) return BVCF_E_TOO_BIG;
   HIP_TRY(c, hipSetDevice(c->device));
   // Batch i runs on slot i % n_use, each slot on its own stream, exactly as bvcf_submit deals them: with two
   // slots the short latency-bound kernels that end one batch's chain overlap the next batch's scan.

@@ -359,8 +359,8 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
       if (c < n_chunks) {
         const u32x4 v = vb[j];
         const uint32_t off = lb + c * kChunk + 16u * lane;
-        uint32_t valid = low_bits16((int)starts_end - (int)off);
-        if (off < s_begin) valid &= ~low_bits16((int)s_begin - (int)off);  // lane 0 of the first chunk
+        uint32_t valid = bits_until(starts_end, off);
+        if (off < s_begin) valid &= ~bits_until(s_begin, off);  // lane 0 of the first chunk
         const uint32_t m = eq_mask16(v, '\t') & valid;
         uint32_t tot;
         const uint32_t pre = wave_excl_scan(__popc(m), &tot);
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(kWgThreads) void k_tabs_wide(KernelArgs a) {
     uint32_t cnt = 0;
     for (uint32_t off = lb + 16u * lane; off < hi; off += kChunk) {
       const u32x4 v = ld_stream(a.buf + min(off, cap_off));
-      uint32_t valid = low_bits16((int)hi - (int)off);
-      if (off < lo) valid &= ~low_bits16((int)lo - (int)off);
+      uint32_t valid = bits_until(hi, off);
+      if (off < lo) valid &= ~bits_until(lo, off);
       cnt += __popc(eq_mask16(v, '\t') & valid);
     }
     cnt = wave_sum(cnt);

@@ -208,7 +208,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
           row[2] = v.z;
           row[3] = v.w;
         }
-        uint32_t m = eq_mask16(v, '\t') & low_bits16((int)cend - (int)off);
+        uint32_t m = eq_mask16(v, '\t') & bits_until(cend, off);
         uint32_t tot;
         uint32_t rk = found + group_excl_scan(__popc(m), &tot);
         while (m && rk < need) {
@@ -226,7 +226,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         for (; base < cend; base += kWindow) {
           const uint32_t off = base + 16u * gl;
           u32x4 v = load16(a.buf, off, a.cap);
-          extra += __popc(eq_mask16(v, '\t') & low_bits16((int)cend - (int)off));
+          extra += __popc(eq_mask16(v, '\t') & bits_until(cend, off));
         }
         extra = group_sum(extra);
       }

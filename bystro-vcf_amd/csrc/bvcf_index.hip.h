@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kWgThreads) void k_count_eol(KernelArgs a, uint32_t
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const uint32_t off = (c0 + q) * kChunk + 16u * lane;
-      cnt[q] = __popc(eq_mask16(v[q], a.eol_byte) & low_bits16((int)a.nbytes - (int)off));
+      cnt[q] = __popc(eq_mask16(v[q], a.eol_byte) & bits_until(a.nbytes, off));
     }
     // two 16-bit sums per register: a chunk holds at most 1024 terminators
     const uint32_t s01 = wave_sum(cnt[0] | (cnt[1] << 16));
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scatter_eol(KernelArgs a, uint32
       uint32_t idx = lane_value(mine, src);
       const uint32_t off = cc * kChunk + 16u * lane;
       u32x4 v = load16(a.buf, off, a.cap);
-      uint32_t m = eq_mask16(v, a.eol_byte) & low_bits16((int)a.nbytes - (int)off);
+      uint32_t m = eq_mask16(v, a.eol_byte) & bits_until(a.nbytes, off);
       uint32_t tot;
       idx += wave_excl_scan(__popc(m), &tot);
       while (m) {

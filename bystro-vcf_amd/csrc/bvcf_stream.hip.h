@@ -25,8 +25,8 @@ __device__ inline uint32_t find_eol(const KernelArgs &a, uint32_t from, uint32_t
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const uint32_t off = base + q * kChunk + 16u * lane;
-      uint32_t m = eq_mask16(v[q], a.eol_byte) & low_bits16((int)limit - (int)off);
-      if (off < from) m &= ~low_bits16((int)from - (int)off);  // the up to 3 bytes before `from`
+      uint32_t m = eq_mask16(v[q], a.eol_byte) & bits_until(limit, off);
+      if (off < from) m &= ~bits_until(from, off);  // the up to 3 bytes before `from`
       const unsigned long long b = __ballot(m != 0);
       if (b) {
         const int src = __ffsll((long long)b) - 1;
@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t head_window(const KernelArgs &a, u32x4 v, ui
   const int lane = lane_id();
   const uint32_t need = 9;
   const uint32_t off = base + 16u * lane;
-  uint32_t valid = low_bits16((int)a.nbytes - (int)off);
+  uint32_t valid = bits_until(a.nbytes, off);
   if ((uint32_t)lane >= n_lanes) valid = 0;
   const uint32_t me = eq_mask16(v, a.eol_byte) & valid;
   uint32_t mt = eq_mask16(v, '\t') & valid;
@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t head_window(const KernelArgs &a, u32x4 v, ui
   if (be) {
     const int src = __ffsll((long long)be) - 1;
     eol_here = lane_value(off + __ffs(me) - 1, src);
-    mt &= low_bits16((int)eol_here - (int)off);  // TABs of this line only
+    mt &= bits_until(eol_here, off);  // TABs of this line only
   }
   uint32_t tot;
   const uint32_t cnt = __popc(mt);
@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t head_window16(const KernelArgs &a, u32x4 v, 
   const uint32_t base = start & ~3u;
   if (lane == 0) v.x &= 0xFFFFFFFFu << (8u * (start & 3u));
   const uint32_t off = base + 16u * lane;
-  uint32_t valid = low_bits16((int)a.nbytes - (int)off);
+  uint32_t valid = bits_until(a.nbytes, off);
   if (lane >= 16) valid = 0;
   const uint32_t e4 = a.eol_byte * 0x01010101u;
   const uint32_t eol_any = (zero_bytes(v.x ^ e4) | zero_bytes(v.y ^ e4) | zero_bytes(v.z ^ e4) | zero_bytes(v.w ^ e4));

@@ -106,7 +106,7 @@ typedef struct {
   uint8_t reserved0[1];
   const char *allow_filter;   /* --allowFilter text; NULL, "" or "*" = allow all (main.go:98,108-114) */
   const char *exclude_filter; /* --excludeFilter text; NULL or "" = none (main.go:99,117-123) */
-  uint64_t max_batch_bytes;   /* largest block bvcf_submit accepts (0 = 64 MiB) */
+  uint64_t max_batch_bytes;   /* largest block bvcf_submit accepts (0 = 64 MiB; below 4 GiB - 1 MiB: offsets are 32-bit) */
   uint32_t max_lines;         /* 0 = derived from max_batch_bytes and n_header_fields */
   uint32_t max_alleles;       /* slots of alleles[] (>= max_lines); 0 = 2 * max_lines + 1024 */
   uint64_t cmap_bytes;        /* class-map arena, one map per (line, ALT index); 0 = 1.5 maps per line */

@@ -143,3 +143,39 @@ def test_full_size_properties_c4(mods):
         info = lines[i].split(b"\t")[7]
         got = [(r["ac"], r["an"], r["alt_idx"]) for r in b.records(i) if r["ac"] > 0]
         assert sorted((a, n, k) for (_, _, a, n, k) in want.get(info, [])) == sorted((int(a), int(n), int(k)) for a, n, k in got)
+
+
+def test_block_past_2_gib(mods, bvcf_path):
+    """one block of 311 296 rows (3.16 GB, bench.py's block): byte offsets above 2^31 -- the line index, the head
+    windows and the scans compare offsets as unsigned 32-bit values, a signed difference would wrap there.  Size-
+    independent properties over every row, and oracle spot checks on rows from both sides of the 2 GiB mark."""
+    if bvcf_path == "census-wide":
+        pytest.skip("same kernels as census at this sample count")
+    bg, bv = mods
+    cfg = bg.make_cfg("c3")
+    rows = 311_296
+    t, nbytes = bg.rows_device(cfg, 31_000_000, rows, pad=bv.DEVICE_PAD)
+    assert nbytes > (1 << 31) + (1 << 29)
+    stride = ((cfg.n_samples + 3) // 4 + 15) & ~15
+    ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=1, max_lines=rows + 16,
+                 max_alleles=rows + 1024, cmap_bytes=(rows + 1024 + 16 * 8192) * stride)
+    ctx.submit_device(t.data_ptr(), nbytes)
+    b = ctx.collect()
+    ctx.close()
+    assert len(b.lines) == rows and b.n_lines_seen == rows and (b.lines["status"] == bv.LINE_OK).all()
+    off = b.lines["off"].astype(np.int64)
+    ln = b.lines["len"].astype(np.int64)
+    assert off[0] == 0 and (off[1:] == off[:-1] + ln[:-1] + 1).all() and off[-1] + ln[-1] + 1 == nbytes
+    assert (b.lines["n_fields"] == bg.n_header_fields(cfg)).all() and (b.lines["n_rec"] == 1).all()
+    al = b.alleles[:rows]
+    assert (al["an"] == 2 * cfg.n_samples).all() and (al["n_miss"] == 0).all()
+    assert (al["ac"] == al["n_het"] + 2 * al["n_hom"]).all() and (al["ac"] > 0).all()
+    pick = [0, rows // 3, int(np.searchsorted(off, 1 << 31)) - 1, int(np.searchsorted(off, 1 << 31)), rows - 1]
+    text = b"".join(bytes(t[int(off[i]):int(off[i] + ln[i] + 1)].cpu().numpy()) for i in pick)
+    rc, out, _, _ = orc.run(bg.header(cfg) + text)
+    orows = [r.split(b"\t") for r in out.split(b"\n") if r]
+    assert len(orows) == len(pick)
+    for i, r in zip(pick, orows):
+        assert int(r[12]) == al["ac"][i] and int(r[13]) == al["an"][i] and int(r[1]) >= 0
+        cls = b.classes(al[i])
+        assert (cls == 1).sum() == al["n_het"][i] and (cls == 2).sum() == al["n_hom"][i]
