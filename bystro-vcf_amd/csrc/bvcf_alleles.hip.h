@@ -16,11 +16,12 @@ struct Span {
 // (k_head), everything else falls through to HBM.
 struct Bytes {
   const uint8_t *g;          // the block
-  const uint8_t *lds;        // copy of block bytes [lo, lo + n)
+  const uint8_t *lds;        // copy of block bytes [lo, lo + n): byte `off` lives at lds[(off - sub) & mask]
   uint32_t lo, n;
+  uint32_t sub = 0, mask = 0xFFFFFFFFu;  // k_head: a flat copy (sub = lo); k_sites: a ring (sub = 0, mask = ring size - 1)
   __device__ __forceinline__ uint8_t operator[](uint32_t off) const {
     const uint32_t d = off - lo;
-    return d < n ? lds[d] : g[off];
+    return d < n ? lds[(off - sub) & mask] : g[off];
   }
 };
 

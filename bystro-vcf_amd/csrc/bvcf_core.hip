@@ -62,6 +62,8 @@ struct bvcf_ctx {
   int gt_grid = 0, stream_grid = 0;
   bool fused = false;
   bool wide = false;  // census path with k_gt_wide in front of k_gt (see kWideSamples)
+  bool sites = false; // no sample columns: k_sites after the census instead of k_scatter_eol + k_head + k_finish
+  int sites_grid = 0;
   uint32_t win_bytes = 64u << 10;  // wide: bytes of a line's sample region per wave of the split general scan
   uint32_t tile_bytes = 0, tile_quota = 0;
   uint32_t n_samples = 0;
@@ -303,6 +305,13 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
   hipLaunchKernelGGL(k_count_eol, dim3(stream_grid ? stream_grid : 1), dim3(kWgThreads), 0, st, a, n_chunks);
   hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, n_chunks);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
+  if (c->sites) {
+    // sites-only input: line records and allele records straight from one pass over the text
+    if (ev_gt0) hipEventRecord(ev_gt0, st);
+    hipLaunchKernelGGL(k_sites, dim3(c->sites_grid), dim3(kSitesThreads), 0, st, a, n_chunks);
+    if (ev_gt1) hipEventRecord(ev_gt1, st);
+    return;
+  }
   hipLaunchKernelGGL(k_scatter_eol, dim3(stream_grid ? stream_grid : 1), dim3(kWgThreads), 0, st, a, n_chunks);
   // (k_head_lean when batches overlap: at 132 registers three of its workgroups fit on a CU beside the kernels of
   // the neighbouring batch; sites-only benchmark with two slots 4.4 -> 4.9 G variants/s, with one slot 3.5 -> 3.4)
@@ -481,6 +490,13 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
     if (w >= 1 && w <= 4) per_cu = w;
   }
   c->stream_grid = c->n_cu * per_cu;
+  // sites-only input takes the fused kernel (BVCF_SITES=0: the census chain with k_head, for A/B and parity tests)
+  c->sites = c->n_samples == 0;
+  if (const char *e = getenv("BVCF_SITES")) c->sites = c->sites && atoi(e) != 0;
+  per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sites, kSitesThreads, 0) != hipSuccess || per_cu < 1)
+    per_cu = 3;
+  c->sites_grid = c->n_cu * per_cu;
   // the streaming kernel gives every wave its own range of class-map slots (two of them slack): room for that
   if (!p->cmap_bytes) {
     c->max_cmap += (uint64_t)c->stream_grid * kWavesPerWg * 2u * c->cmap_stride + c->max_lines / 16 * (uint64_t)c->cmap_stride;

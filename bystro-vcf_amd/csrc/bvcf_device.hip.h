@@ -29,6 +29,11 @@
 //   k_order        tile-local line entries -> input-ordered line_off / line_len / results
 // after which k_head, k_gt (further ALT indices only) and k_finish run as above.
 //
+// Sites-only input (no sample columns): k_count_eol + k_scan_* as above, then ONE pass,
+//   k_sites        a wave walks a run of 8 KiB windows: text ring + TAB bit ring in LDS, line ends into a FIFO, then
+//                  one lane per line for strings.Split / linePasses / getAlleles / trTv and the records
+//                  (replaces k_scatter_eol + k_head + k_finish there)
+//
 // Everything is byte/integer work over the line bytes; no MFMA.  The genotype scans are bound by
 // VALU issue at 57-70 % of the HBM peak.
 // Loads are 16 B per lane, 1 KiB per wave-instruction, from the dword at or before the byte the
@@ -44,3 +49,4 @@
 #include "bvcf_gtscan.hip.h"
 #include "bvcf_stream.hip.h"
 #include "bvcf_head.hip.h"
+#include "bvcf_sites.hip.h"

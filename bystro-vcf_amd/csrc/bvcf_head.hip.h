@@ -263,6 +263,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     hb.g = a.buf;
     hb.lds = reinterpret_cast<const uint8_t *>(&s_head[ll * kHeadRow]);
     hb.lo = ls;
+    hb.sub = ls;
     hb.n = active ? s_staged[ll] : 0u;
 
     uint32_t status = BVCF_LINE_OK;

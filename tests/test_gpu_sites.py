@@ -1,0 +1,155 @@
+"""k_sites, the one-pass kernel for sites-only input (no sample columns; BASELINE configs[1]): lines of every length
+around its 8 KiB windows and 16 KiB ring, runs that start in the middle of a line, rounds of more than 64 lines per
+chunk, and agreement with the census chain it replaces (BVCF_SITES=0: k_scatter_eol + k_head)."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+H8 = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+H9 = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\n"
+
+
+@pytest.fixture(scope="module")
+def bv():
+    import bystro_vcf_amd as b
+    return b
+
+
+def both(bv, vcf, cfg=None, **kw):
+    rc_o, out_o, log_o, n_o = orc.run(vcf, cfg)
+    rc_g, out_g, log_g, n_g = bv.run_buffer(vcf, cfg, **kw)
+    assert (rc_g != 0) == (rc_o != 0), (rc_g, rc_o, log_g)
+    assert n_g == n_o
+    if out_g != out_o:
+        a, b = out_o.split(b"\n"), out_g.split(b"\n")
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert x == y, "row %d differs:\noracle: %r\nhip:    %r" % (i, x[:200], y[:200])
+        assert len(a) == len(b)
+    assert log_g == log_o
+    return out_g
+
+
+def _line(rng, pos, info_len=None, kind=None):
+    ref = rng.choice("ACGT")
+    k = kind if kind is not None else rng.random()
+    if k < 0.6:
+        alt = rng.choice([b for b in "ACGT" if b != ref])
+    elif k < 0.7:
+        alt = ref + "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 12)))
+    elif k < 0.8:
+        ref = ref + "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 12)))
+        alt = ref[0]
+    elif k < 0.9:
+        alt = ",".join(rng.choice("ACGT") + ("" if rng.random() < 0.5 else "AG") for _ in range(rng.randint(2, 4)))
+    elif k < 0.95:
+        alt = rng.choice(["<CN0>", ".", "N", ref, "A,<DEL>", ""])
+    else:
+        ref = "".join(rng.choice("ACGT") for _ in range(5))
+        alt = "".join(rng.choice("ACGT") for _ in range(5))
+    flt = rng.choice(["PASS", "PASS", "PASS", ".", "q10", "LowQual;s50"])
+    n = info_len if info_len is not None else rng.randint(1, 120)
+    info = "AC=%d;" % rng.randint(1, 5000) + "X" * n
+    return "\t".join(["%s" % rng.choice(["1", "chr2", "X", "contig77"]), str(pos), "rs%d" % pos, ref, alt, "100", flt, info])
+
+
+@pytest.mark.parametrize("seed,n_lines", [(1, 3000), (2, 40000)])
+def test_sites_parity_random(bv, seed, n_lines):
+    rng = random.Random(seed)
+    rows, pos = [], 1000
+    for _ in range(n_lines):
+        pos += rng.randint(1, 300)
+        rows.append(_line(rng, pos))
+    vcf = (H8 + "\n".join(rows) + "\n").encode()
+    both(bv, vcf)
+    both(bv, vcf, {"allow": "", "keepId": True, "keepInfo": True, "keepPos": True}, max_batch_bytes=1 << 20)
+
+
+@pytest.mark.parametrize("info_len", [8000, 8100, 8192 - 40, 8192, 16300, 16384, 16500, 40000, 200000])
+def test_sites_long_lines(bv, info_len):
+    """lines about as long as a window (8 KiB) and as the ring (16 KiB), and far longer, between ordinary ones: the
+    start of such a line has left the ring when its terminator arrives (wave-cooperative TAB search, head bytes from
+    memory)"""
+    rng = random.Random(info_len)
+    rows, pos = [], 5
+    for i in range(400):
+        pos += 7
+        rows.append(_line(rng, pos, info_len if i % 23 == 5 else None))
+    vcf = (H8 + "\n".join(rows) + "\n").encode()
+    both(bv, vcf, {"allow": "", "keepInfo": True})
+    both(bv, vcf.replace(b"\n", b"\r\n"), {"allow": ""})
+
+
+@pytest.mark.parametrize("shift", list(range(0, 48, 5)) + [8191, 8192, 8193])
+def test_sites_every_alignment_of_window_boundaries(bv, shift):
+    """a first junk line of `shift` bytes moves every later line against the 8 KiB windows and 1 KiB chunks"""
+    rng = random.Random(99)
+    rows, pos = ["#" + "j" * max(shift - 2, 0)] if shift else [], 10
+    for _ in range(1500):
+        pos += 3
+        rows.append(_line(rng, pos))
+    both(bv, (H8 + "\n".join(rows) + "\n").encode(), {"allow": ""})
+
+
+def test_sites_many_short_lines(bv):
+    """hundreds of terminators per chunk (empty lines, two-byte junk): rounds of 64 lines in the middle of a chunk,
+    FIFO compaction; every one is a listed line that fails the field count"""
+    rng = random.Random(5)
+    rows, pos = [], 10
+    for i in range(6000):
+        pos += 3
+        rows.append(_line(rng, pos))
+        if i % 40 == 7:
+            rows.extend([""] * rng.randint(1, 700))
+        if i % 55 == 9:
+            rows.extend(["x"] * rng.randint(1, 1500))
+    vcf = (H8 + "\n".join(rows) + "\n").encode()
+    both(bv, vcf, {"allow": ""})
+    # unterminated tail (dropped, main.go:354-358) and a body of terminators only
+    both(bv, vcf + b"1\t5\t.\tA\tG\t.\tPASS\t.", {"allow": ""})
+    both(bv, (H8 + "\n" * 5000).encode())
+    both(bv, H8.encode())
+
+
+def test_sites_nine_header_fields(bv):
+    """FORMAT column without samples: 9 header fields, numSamples 0 (main.go:505-509 logs a warning)"""
+    rng = random.Random(11)
+    rows, pos = [], 10
+    for i in range(3000):
+        pos += 3
+        rows.append(_line(rng, pos) + ("\tGT" if i % 7 else ""))
+    out = both(bv, (H9 + "\n".join(rows) + "\n").encode(), {"allow": ""})
+    assert out.count(b"\n") > 1500
+
+
+def test_sites_bench_shape_runs_of_many_windows(bv):
+    """BASELINE configs[1] rows from the bench generator, 300 000 of them (45 MB: several windows per wave, most runs
+    start in the middle of a line), against the oracle; and the census chain it replaces gives the same records"""
+    import benchgen as bg
+    cfg = bg.make_cfg("c2")
+    body = bg.rows_host(cfg, 2_000_000, 300_000)
+    vcf = bg.header(cfg) + body
+    rc_o, out_o, log_o, n_o = orc.run(vcf, None, n_threads=8)
+    rc_g, out_g, log_g, n_g = bv.run_buffer(vcf)
+    assert rc_g == 0 and n_g == n_o == 300_000 and out_g == out_o and log_g == log_o
+    n_hdr = bg.n_header_fields(cfg)
+    ctx = bv.Ctx(n_hdr, max_batch_bytes=len(body))
+    new = ctx.process(body)
+    ctx.close()
+    import os
+    os.environ["BVCF_SITES"] = "0"
+    try:
+        ctx = bv.Ctx(n_hdr, max_batch_bytes=len(body))
+        old = ctx.process(body)
+        ctx.close()
+    finally:
+        del os.environ["BVCF_SITES"]
+    assert len(new.lines) == len(old.lines) == 300_000
+    for f in ("off", "len", "fend", "n_rec", "n_fields", "status", "site_type"):
+        assert (new.lines[f] == old.lines[f]).all(), f
+    for f in ("pos", "line", "alt_idx", "alt_len", "ref", "alt_base", "kind", "site_type", "trtv", "flags"):
+        assert (new.alleles[:300_000][f] == old.alleles[:300_000][f]).all(), f
