@@ -12,21 +12,33 @@ struct Span {
   uint32_t off, len;
 };
 
-// Byte access for the leader lane's serial work: the first windows of the line are staged in LDS
-// (k_head), everything else falls through to HBM.
-struct Bytes {
+// Byte access for the serial per-line work (one lane per line): the head of the line is staged in LDS (k_head: the
+// first windows of the line; k_sites: a text ring), everything else falls through to HBM.
+// The LDS pointer carries its address space: with two generic pointers hipcc merges the two loads into ONE
+// flat_load_ubyte of a selected address -- a flat load waits on vmcnt as well as lgkmcnt, i.e. every byte of the
+// serial work then waits for the text prefetches and the record stores in flight.
+typedef const __attribute__((address_space(3))) uint8_t *lds_bytes_t;
+__device__ __forceinline__ lds_bytes_t as_lds(const void *p) { return (lds_bytes_t)p; }
+
+// kFallback = false: every byte asked for is known to be in the LDS copy (k_sites: a line that lies in the ring)
+template <bool kFallback>
+struct BytesT {
   const uint8_t *g;          // the block
-  const uint8_t *lds;        // copy of block bytes [lo, lo + n): byte `off` lives at lds[(off - sub) & mask]
+  lds_bytes_t lds;           // copy of block bytes [lo, lo + n): byte `off` lives at lds[(off - sub) & mask]
   uint32_t lo, n;
   uint32_t sub = 0, mask = 0xFFFFFFFFu;  // k_head: a flat copy (sub = lo); k_sites: a ring (sub = 0, mask = ring size - 1)
   __device__ __forceinline__ uint8_t operator[](uint32_t off) const {
+    if (!kFallback) return lds[(off - sub) & mask];
     const uint32_t d = off - lo;
-    return d < n ? lds[(off - sub) & mask] : g[off];
+    if (d < n) return lds[(off - sub) & mask];
+    return g[off];
   }
 };
+typedef BytesT<true> Bytes;
 
 // strconv.Atoi on buf[s.off .. +len): optional sign, digits, must fit int64 (main.go:752,824)
-__device__ inline bool go_atoi(const Bytes &buf, Span s, long long *out) {
+template <class B>
+__device__ inline bool go_atoi(const B &buf, Span s, long long *out) {
   if (s.len == 0) return false;
   uint32_t i = 0;
   bool neg = false;
@@ -69,13 +81,15 @@ struct GtStats {
 };
 
 // lane-0 state of one line's getAlleles evaluation
-struct AlleleCtx {
-  Bytes buf;
+template <class B>
+struct AlleleCtxT {
+  B buf;
   Span chrom, pos, ref, alt;
   long long int_pos;   // intPos, main.go:767
   bool pos_bad;        // Atoi failed: the ALT loop is over (main.go:826-829)
   uint32_t line;
 };
+typedef AlleleCtxT<Bytes> AlleleCtx;
 
 // what one ALT token yields
 struct AlleleEval {
@@ -91,8 +105,9 @@ struct AlleleEval {
 };
 
 // The single-ALT-byte path, main.go:735-765.  t is the whole ALT field (1 byte).
-__device__ inline void eval_single(AlleleCtx &c, AlleleEval &e) {
-  const Bytes &b = c.buf;
+template <class B>
+__device__ inline void eval_single(AlleleCtxT<B> &c, AlleleEval &e) {
+  const B &b = c.buf;
   e = AlleleEval{};
   const uint8_t a0 = b[c.alt.off];
   if (a0 != 'A' && a0 != 'C' && a0 != 'G' && a0 != 'T') {
@@ -129,8 +144,9 @@ __device__ inline void eval_single(AlleleCtx &c, AlleleEval &e) {
 }
 
 // One token of strings.Split(alt, ","), main.go:774-999.  t = token span.
-__device__ inline void eval_token(AlleleCtx &c, Span t, AlleleEval &e) {
-  const Bytes &b = c.buf;
+template <class B>
+__device__ inline void eval_token(AlleleCtxT<B> &c, Span t, AlleleEval &e) {
+  const B &b = c.buf;
   e = AlleleEval{};
   // altIsValid, main.go:456-474 (empty token: Go would panic; invalid here)
   bool valid = t.len > 0;
@@ -234,7 +250,8 @@ __device__ inline void eval_token(AlleleCtx &c, Span t, AlleleEval &e) {
 }
 
 // next token of the ALT field starting at *cursor (relative to alt.off); false when exhausted
-__device__ inline bool next_token(const AlleleCtx &c, uint32_t *cursor, Span *t) {
+template <class B>
+__device__ inline bool next_token(const AlleleCtxT<B> &c, uint32_t *cursor, Span *t) {
   if (*cursor > c.alt.len) return false;
   uint32_t s = *cursor, i = s;
   #pragma nounroll

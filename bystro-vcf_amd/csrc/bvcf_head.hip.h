@@ -42,7 +42,8 @@ __device__ __forceinline__ uint32_t group_excl_scan(uint32_t v, uint32_t *total)
 
 __device__ __forceinline__ uint32_t gbcast0(uint32_t v) { return __shfl(v, 0, kGroup); }
 
-__device__ inline bool filter_in(const Bytes &buf, Span f, const uint16_t *off, const uint16_t *len, uint32_t n,
+template <class B>
+__device__ inline bool filter_in(const B &buf, Span f, const uint16_t *off, const uint16_t *len, uint32_t n,
                                  const uint8_t *text) {
 #pragma nounroll
   for (uint32_t i = 0; i < n; i++) {
@@ -261,7 +262,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     const uint32_t *tab = &s_tab[ll * kTabRow];
     Bytes hb;
     hb.g = a.buf;
-    hb.lds = reinterpret_cast<const uint8_t *>(&s_head[ll * kHeadRow]);
+    hb.lds = as_lds(&s_head[ll * kHeadRow]);
     hb.lo = ls;
     hb.sub = ls;
     hb.n = active ? s_staged[ll] : 0u;

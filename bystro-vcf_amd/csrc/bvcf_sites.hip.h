@@ -5,17 +5,18 @@
 // (strings.Split, main.go:535), the field count and the FILTER gate (linePasses, main.go:447-454), getAlleles
 // (main.go:723-1038) and trTv (main.go:602-606) -- and writes 128 bytes of records.  The census chain spent its time
 // re-reading: k_scatter_eol revisits the chunks for the line starts, k_head re-reads every line head with 16 lanes
-// per line in 16 latency-bound rounds.  Here one wave walks a contiguous run of 8 KiB windows and reads every byte
+// per line in 16 latency-bound rounds.  Here one wave walks a contiguous run of 1 KiB windows and reads every byte
 // ONCE:
-//   * each 1 KiB chunk goes from registers into a 16 KiB text ring in LDS (the current and the previous window);
+//   * each 1 KiB chunk goes from registers into a text ring in LDS (kSitesRing bytes: the last few windows);
 //   * its terminator mask gives the line ends (appended to a FIFO in LDS), its TAB mask goes into a bit ring;
-//   * whenever 64 line ends are pending -- and at the end of a window -- ONE LANE PER LINE walks the TAB bits of its
-//     line (first `need` TABs, total count), runs the gate and getAlleles on the ring bytes and writes the line and
-//     allele records.  A line belongs to the window its terminator is in; its start is the byte after the previous
-//     terminator, which the wave carries along (only the first window of a run searches backwards for it).
+//   * whenever 64 line ends are pending -- or the oldest pending line is about to be overwritten in the ring, or the
+//     run ends -- ONE LANE PER LINE walks the TAB bits of its line (first `need` TABs, total count), runs the gate
+//     and getAlleles on the ring bytes and writes the line and allele records.  A line belongs to the run its
+//     terminator is in; its start is the byte after the previous terminator, which the wave carries along.
 // The line index of the first terminator of a run comes from the census prefix (k_count_eol / k_scan_*), so records
-// land in input order without a second pass.  Lines longer than a window (their start has left the ring) take a
-// wave-cooperative slow path for the TABs and read their head bytes from memory.
+// land in input order without a second pass.  A line whose start is not in the ring -- the first line of every run,
+// and lines longer than the ring's history -- takes a wave-cooperative path for its TABs and gets its first 256
+// bytes staged on their own.
 #pragma once
 
 #include "bvcf_common.hip.h"
@@ -24,18 +25,24 @@
 
 namespace bvcf_dev {
 
-constexpr uint32_t kSitesWin = 8192;                       // bytes per window
-constexpr uint32_t kSitesRing = 2 * kSitesWin;             // text ring per wave: previous + current window
+#ifndef BVCF_SITES_RING
+#define BVCF_SITES_RING 8192
+#endif
+constexpr uint32_t kSitesWin = kChunk;                     // bytes per window (one chunk register, one more in flight)
+constexpr uint32_t kSitesRing = BVCF_SITES_RING;           // text ring per wave: kSitesRing - kSitesWin bytes of history
 constexpr uint32_t kSitesChunks = kSitesWin / kChunk;      // chunk registers per window
 constexpr uint32_t kSitesFifo = 64 + kChunk;               // pending line ends: < 64 carried + one chunk's worth
-constexpr int kSitesWaves = 2;                             // waves per workgroup (43 KiB of LDS: three per CU)
+constexpr uint32_t kSitesLongHead = 256;                   // bytes of a long line's head staged on their own
+constexpr int kSitesWaves = 2;                             // waves per workgroup
 constexpr int kSitesThreads = kSitesWaves * kWave;
+static_assert((kSitesRing & (kSitesRing - 1)) == 0 && kSitesRing >= 2 * kSitesWin && kSitesRing <= 65536, "ring: power of two, u16 offsets");
 
 struct SitesLds {
   uint8_t text[kSitesRing];          // byte at block offset o lives at text[o & (kSitesRing - 1)]
   uint32_t tabs[kSitesRing / 32];    // bit o & (kSitesRing - 1): byte o is a TAB
-  uint16_t fifo[kSitesFifo];         // pending terminators, relative to the current window's start
-  uint32_t long_tab[10];             // slow path: the first 9 TAB offsets and the TAB count of a line longer than the ring
+  uint16_t fifo[kSitesFifo];         // pending terminators: block offset & (kSitesRing - 1)
+  uint8_t long_head[kSitesLongHead]; // the first bytes of a line whose start is not in the ring
+  uint32_t long_tab[10];             // ... its first 9 TAB offsets and its TAB count
 };
 
 // last terminator at a position < limit, or kNone (wave-cooperative, backwards, 1 KiB per step)
@@ -96,53 +103,53 @@ __global__ __launch_bounds__(kSitesThreads) void k_sites(KernelArgs a, uint32_t 
 
   uint32_t w0 = win_lo * kSitesWin;
   // ---- where the first line of the run starts, and its line index
-  uint32_t ps = 0;       // start of the line whose terminator comes next
-  uint32_t ring_lo = w0; // oldest block offset the ring holds
   // terminators before w0 = index of the line the first terminator of the run ends (census prefix of the chunk)
   const uint32_t c_first = w0 / kChunk;
   uint32_t rank = c_first < n_chunks ? a.census[c_first] + a.group_base[c_first / kScanGroup] : 0u;
+  uint32_t ps = 0;  // start of the first pending line (of the line in progress when nothing is pending)
   if (win_lo > 0) {
-    // the previous window goes into the ring (a line that ends in this run may have started there)
-    uint32_t last = kNone;
-#pragma unroll
-    for (uint32_t c = 0; c < kSitesChunks; c++) {
-      const u32x4 v = chunk_load(win_lo - 1u, c);
-      const uint32_t off = w0 - kSitesWin + c * kChunk + 16u * lane;
-      stage(off, v, eq_mask16(v, '\t'));
-      const uint32_t me = eq_mask16(v, a.eol_byte);
-      const unsigned long long b = __ballot(me != 0);
-      if (b) {
-        const int src = 63 - __clzll((long long)b);
-        last = lane_value(off + 31u - (uint32_t)__clz(me), src);
-      }
-    }
-    ring_lo = w0 - kSitesWin;
-    if (last == kNone) last = find_eol_before(a, ring_lo);  // a line longer than a window
+    const uint32_t last = find_eol_before(a, w0);
     ps = last == kNone ? 0u : last + 1u;
   }
-
+  uint32_t ring_lo = w0;     // oldest block offset the ring holds
+  uint32_t staged_end = w0;  // the ring holds [ring_lo, staged_end)
   uint32_t n_pending = 0;
-  // one lane per pending line, lines [0, n) of the FIFO; `staged_end`: the ring holds [ring_lo, staged_end)
-  auto flush = [&](uint32_t n, uint32_t staged_end) {
+
+  // one lane per pending line, lines [0, n) of the FIFO
+  auto flush = [&](uint32_t n) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool active = (uint32_t)lane < n;
     const uint32_t line = rank + (uint32_t)lane;
+    // FIFO entries are ring offsets of bytes in [staged_end - kSitesRing, staged_end)
+    const uint32_t ring_base = staged_end - kSitesRing;
+    auto unring = [&](uint32_t rel) -> uint32_t { return ring_base + ((rel - ring_base) & kRingMask); };
     uint32_t ls = 0, le = 0;
     if (active) {
-      le = w0 + S.fifo[lane];
-      ls = lane == 0 ? ps : w0 + S.fifo[lane - 1] + 1u;
+      le = unring(S.fifo[lane]);
+      ls = lane == 0 ? ps : unring(S.fifo[lane - 1]) + 1u;
     }
     const uint32_t len = active && le + 1u - ls >= a.eol_chars ? le + 1u - ls - a.eol_chars : 0u;  // chomp, main.go:535
     const uint32_t cend = ls + len;
-    // ---- a line whose start has left the ring (only the first pending line can be one): TABs by the whole wave
-    const bool is_long = bcast0((n > 0 && ps < ring_lo) ? 1u : 0u) != 0u;
+    // ---- a line whose start is not in the ring (only the first pending line can be one): its TABs by the whole
+    // wave from memory, its first bytes into a buffer of their own
+    const bool is_long = ps < ring_lo;
     if (is_long) {
       const uint32_t l_ls = ps, l_cend = bcast0(cend);
       uint32_t found = 0;
       for (uint32_t base = l_ls & ~15u; base < l_cend; base += kChunk) {
         const uint32_t off = base + 16u * lane;
         const u32x4 v = *reinterpret_cast<const u32x4_u *>(a.buf + min(off, cap_off));
+        if (base == (l_ls & ~15u) && lane < (int)(kSitesLongHead / 16u + 1u)) {
+          // bytes [l_ls, l_ls + kSitesLongHead) for lane 0's serial work (unaligned: byte-wise placement by the lanes
+          // that hold them)
+#pragma unroll
+          for (uint32_t q = 0; q < 16; q++) {
+            const uint32_t o = off + q;
+            const uint32_t w = q < 4 ? v.x : (q < 8 ? v.y : (q < 12 ? v.z : v.w));
+            if (o >= l_ls && o - l_ls < kSitesLongHead && off <= cap_off) S.long_head[o - l_ls] = (uint8_t)(w >> (8u * (q & 3u)));
+          }
+        }
         uint32_t m = eq_mask16(v, '\t') & bits_until(l_cend, off) & (off <= cap_off ? 0xFFFFu : 0u);
         if (off < l_ls) m &= ~bits_until(l_ls, off);
         uint32_t tot;
@@ -162,48 +169,42 @@ __global__ __launch_bounds__(kSitesThreads) void k_sites(KernelArgs a, uint32_t 
     // ---- strings.Split(row, "\t") from the TAB bits: the first `need` TABs and the count (main.go:535)
     uint32_t tab[9];
     uint32_t found = 0, n_tabs = 0;
-    if (active && !(is_long && lane == 0)) {
-      uint32_t wi = ls >> 5;
-      const uint32_t we = cend >> 5;
-      uint32_t cur = ls < cend ? S.tabs[wi & (kSitesRing / 32 - 1u)] & (0xFFFFFFFFu << (ls & 31u)) : 0u;
-      uint32_t k_next = 0;  // next entry of tab[] to fill
 #pragma unroll
-      for (uint32_t k = 0; k < 9; k++) tab[k] = cend;
-      for (;;) {
-        if (wi == we) cur &= (1u << (cend & 31u)) - 1u;  // bits below cend
-        n_tabs += __popc(cur);
-        // (tab[] is indexed by constants only: a register array)
+    for (uint32_t k = 0; k < 9; k++) tab[k] = cend;
+    if (active && !(is_long && lane == 0)) {
+      if (ls < cend) {
+        const uint32_t we = (cend - 1u) >> 5;  // last word with bytes of the line
+        const uint32_t last_mask = (cend & 31u) ? (1u << (cend & 31u)) - 1u : 0xFFFFFFFFu;
+        auto ldw = [&](uint32_t w) -> uint32_t { return S.tabs[w & (kSitesRing / 32u - 1u)] & (w == we ? last_mask : 0xFFFFFFFFu); };
+        uint32_t wi = ls >> 5;
+        uint32_t cur = ldw(wi) & (0xFFFFFFFFu << (ls & 31u));
 #pragma unroll
         for (uint32_t k = 0; k < 9; k++) {
-          if (k == k_next && cur && k < need) {
-            tab[k] = wi * 32u + (uint32_t)__ffs(cur) - 1u;
-            cur &= cur - 1u;
-            k_next = k + 1u;
+          if (k < need) {
+            while (!cur && wi < we) cur = ldw(++wi);
+            if (cur) {
+              tab[k] = wi * 32u + (uint32_t)__ffs(cur) - 1u;
+              cur &= cur - 1u;
+              found = k + 1u;
+            }
           }
         }
-        if (wi >= we) break;
-        wi++;
-        cur = S.tabs[wi & (kSitesRing / 32 - 1u)];
+        n_tabs = found + __popc(cur);
+        while (wi < we) n_tabs += __popc(ldw(++wi));
       }
-      found = min(n_tabs, need);
     } else if (active) {
-#pragma unroll
-      for (uint32_t k = 0; k < 9; k++) tab[k] = S.long_tab[k];
       n_tabs = S.long_tab[9];
       found = min(n_tabs, need);
-    } else {
 #pragma unroll
-      for (uint32_t k = 0; k < 9; k++) tab[k] = 0;
+      for (uint32_t k = 0; k < 9; k++)
+        if (k < found) tab[k] = S.long_tab[k];
     }
 
-    Bytes hb;
-    hb.g = a.buf;
-    hb.lds = S.text;
-    hb.lo = ring_lo;
-    hb.n = staged_end - ring_lo;
-    hb.sub = 0;
-    hb.mask = kRingMask;
-
+    // ---- the serial work of the round, one lane per line, for the lanes with `on`: once for the lines that lie in
+    // the ring (bytes straight from LDS, no test per byte), once more for a long first line (its staged head, then
+    // memory)
+    auto serial = [&](auto hb, const bool on) {
+    const bool active = on;  // (shadows the round's: the lanes this pass works for)
     uint32_t status = BVCF_LINE_OK;
     uint32_t n_fields = n_tabs + 1u;
     if (active && n_fields != a.n_header) status = BVCF_LINE_FIELDS;  // len(record) == len(header), main.go:449
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kSitesThreads) void k_sites(KernelArgs a, uint32_t 
     };
 
     // ---- gate and what the line will need (as k_head, part 1)
-    AlleleCtx c;
+    AlleleCtxT<decltype(hb)> c;
     uint32_t mode = 0, n_commas = 0, bound = 0;
     if (active && status == BVCF_LINE_OK && a.n_header > 6) {
       const FilterTable *ft = &s_ft;
@@ -348,10 +349,30 @@ __global__ __launch_bounds__(kSitesThreads) void k_sites(KernelArgs a, uint32_t 
       a.lines[line] = L;
       if (!primary_written && line < a.max_alleles) a.alleles[line].gt_task = kNoTask;
     }
+    };  // serial
+    {
+      BytesT<false> ring;
+      ring.g = a.buf;
+      ring.lds = as_lds(S.text);
+      ring.lo = ring_lo;
+      ring.n = staged_end - ring_lo;
+      ring.sub = 0;
+      ring.mask = kRingMask;
+      serial(ring, active && !(is_long && lane == 0));
+    }
+    if (is_long) {
+      BytesT<true> head;
+      head.g = a.buf;
+      head.lds = as_lds(S.long_head);
+      head.lo = ls;
+      head.n = kSitesLongHead;
+      head.sub = ls;
+      head.mask = 0xFFFFFFFFu;
+      serial(head, active && lane == 0);
+    }
 
     // ---- pop
-    const uint32_t last_rel = S.fifo[n - 1];
-    ps = bcast0(w0 + last_rel + 1u);
+    ps = bcast0(unring(S.fifo[n - 1]) + 1u);
     rank += n;
     __builtin_amdgcn_wave_barrier();
     if (n_pending > n) {  // (only after a chunk with more than 64 terminators)
@@ -366,54 +387,64 @@ __global__ __launch_bounds__(kSitesThreads) void k_sites(KernelArgs a, uint32_t 
     n_pending -= n;
   };
 
-  // ---- the run, window by window.  The next window's eight chunks are requested when this one starts and are not
-  // touched before it ends; the chunk loop is a real loop (one copy of the per-line code), so the chunk registers are
-  // picked by a switch over constants.
+  // ---- the run, window by window.  The next window's chunks are requested when this one starts and are not touched
+  // before it ends.  One loop with one copy of the per-line code (flush): each turn either flushes a round of pending
+  // lines or takes the next chunk; the chunk registers are picked by a switch over constants.
   u32x4 cur[kSitesChunks], nxt[kSitesChunks];
 #pragma unroll
   for (uint32_t c = 0; c < kSitesChunks; c++) cur[c] = chunk_load(win_lo, c);
-  for (uint32_t win = win_lo; win < win_hi; win++) {
-    w0 = win * kSitesWin;
-    if (win > win_lo) ring_lo = w0 - kSitesWin;
-    const uint32_t win_next = win + 1u < win_hi ? win + 1u : win;  // (the last window's prefetch is dropped)
-#pragma unroll
-    for (uint32_t c = 0; c < kSitesChunks; c++) nxt[c] = chunk_load(win_next, c);
-#pragma nounroll
-    for (uint32_t c = 0; c < kSitesChunks; c++) {
-      u32x4 v;
-      switch (c) {
-        case 0: v = cur[0]; break;
-        case 1: v = cur[1]; break;
-        case 2: v = cur[2]; break;
-        case 3: v = cur[3]; break;
-        case 4: v = cur[4]; break;
-        case 5: v = cur[5]; break;
-        case 6: v = cur[6]; break;
-        default: v = cur[7]; break;
-      }
-      static_assert(kSitesChunks == 8, "the switch above covers 8 chunks");
-      const uint32_t off = w0 + c * kChunk + 16u * lane;
-      const uint32_t valid = bits_until(nb, off);
-      const uint32_t mt = eq_mask16(v, '\t') & valid;
-      const uint32_t me = eq_mask16(v, a.eol_byte) & valid;
-      stage(off, v, mt);
-      if (__any(me != 0)) {
-        uint32_t tot;
-        uint32_t at = n_pending + wave_excl_scan(__popc(me), &tot);
-        uint32_t m = me;
-        while (m) {
-          S.fifo[at++] = (uint16_t)(c * kChunk + 16u * lane + (uint32_t)__ffs(m) - 1u);
-          m &= m - 1;
-        }
-        n_pending += tot;
-      }
-      // 64 pending line ends make a full round; the end of the window flushes the rest (FIFO entries are relative
-      // to this window)
-      const bool last = c + 1u == kSitesChunks;
-      while (n_pending >= 64u || (last && n_pending)) flush(min(n_pending, 64u), w0 + (c + 1u) * kChunk);
+  uint32_t win = win_lo, c = 0;
+  bool fresh = true;  // window `win` has not been started
+  for (;;) {
+    const bool at_end = win >= win_hi;
+    // a full round; or what is pending when the run ends, or when the window about to be staged overwrites the ring
+    // bytes the oldest pending line still lives in
+    uint32_t n_flush = n_pending >= 64u ? 64u : 0u;
+    if (!n_flush && n_pending) {
+      const uint32_t next_end = win * kSitesWin + kSitesWin;
+      if (at_end || (fresh && next_end >= kSitesRing && ps < next_end - kSitesRing)) n_flush = n_pending;
     }
+    if (n_flush) {
+      flush(n_flush);
+      continue;
+    }
+    if (at_end) break;
+    if (fresh) {
+      w0 = win * kSitesWin;
+      const uint32_t win_next = win + 1u < win_hi ? win + 1u : win;  // (the last window's prefetch is dropped)
 #pragma unroll
-    for (uint32_t c = 0; c < kSitesChunks; c++) cur[c] = nxt[c];
+      for (uint32_t k = 0; k < kSitesChunks; k++) nxt[k] = chunk_load(win_next, k);
+      fresh = false;
+      c = 0;
+    }
+    const u32x4 v = cur[0];
+    static_assert(kSitesChunks == 1, "one chunk per window");
+    const uint32_t off = w0 + c * kChunk + 16u * lane;
+    uint32_t mt = eq_mask16(v, '\t'), me = eq_mask16(v, a.eol_byte);
+    if (w0 + kSitesWin > nb) {  // (wave-uniform: the last window of the block)
+      const uint32_t valid = bits_until(nb, off);
+      mt &= valid;
+      me &= valid;
+    }
+    stage(off, v, mt);
+    staged_end = w0 + (c + 1u) * kChunk;
+    if (staged_end - ring_lo > kSitesRing) ring_lo = staged_end - kSitesRing;
+    if (__any(me != 0)) {
+      uint32_t tot;
+      uint32_t at = n_pending + wave_excl_scan(__popc(me), &tot);
+      uint32_t m = me;
+      while (m) {
+        S.fifo[at++] = (uint16_t)((off + (uint32_t)__ffs(m) - 1u) & kRingMask);
+        m &= m - 1;
+      }
+      n_pending += tot;
+    }
+    if (++c == kSitesChunks) {
+#pragma unroll
+      for (uint32_t k = 0; k < kSitesChunks; k++) cur[k] = nxt[k];
+      win++;
+      fresh = true;
+    }
   }
 }
 
