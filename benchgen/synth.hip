@@ -80,6 +80,9 @@ HD uint32_t fixed_part(const SynthCfg &c, uint64_t r, uint8_t *buf, RowParams *r
   else if (u < 887) k = 11 + (uint32_t)(h2 % 90);
   else if (u < 953) k = 101 + (uint32_t)(h2 % 900);
   else k = 1001 + (uint32_t)(h2 % 4000);
+  // "dense" rows (reserved bit 2): a common variant, AF ~ 0.3 -- ~1 050 heterozygotes and ~225 homozygotes of 2 504
+  // samples, i.e. the longest output rows of the reference's own golden file (20 KB) on every line
+  if (c.reserved & 4u) k = nhap * 3u / 10u + (uint32_t)(h2 % 64);
   if (k > nhap) k = nhap;
   rp->thr = (uint32_t)((((uint64_t)k << 32) / nhap) > 0xFFFFFFFFull ? 0xFFFFFFFFull : (((uint64_t)k << 32) / nhap));
   rp->h0 = (uint32_t)((h3 >> 20) % nhap);

@@ -2,7 +2,7 @@
 """End-to-end CLI timing: synthetic rows -> file -> bystro-vcf (HIP) -> /dev/null, with the stage times of
 BVCF_TIMING, and (optionally) an md5 comparison with the oracle CLI on the same file.
 
-    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH] [--bgzf] [--samples=N] [--pipe]
+    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH] [--bgzf] [--samples=N] [--pipe] [--json] [--devices=LIST] [--threads=N]
 
 Needs a GPU box.  The file is written to /dev/shm when it fits there, else /tmp, and removed afterwards.
 """
@@ -66,11 +66,14 @@ def main():
     try:
         t0 = time.perf_counter()
         if not (keep and os.path.exists(path)):
+            import torch  # rows come from the device generator (the host one is a single thread: 50 MB/s)
             with open(path, "wb") as f:
                 f.write(bg.header(cfg))
-                step = max(1, min(25_000, (256 << 20) // (4 * max(cfg.n_samples, 1) + 200)))  # ~256 MB at a time
+                step = max(1, min(200_000, (2 << 30) // (4 * max(cfg.n_samples, 1) + 200)))  # ~2 GB at a time
                 for first in range(0, rows, step):
-                    f.write(bg.rows_host(cfg, first, min(step, rows - first)))
+                    t, nb = bg.rows_device(cfg, first, min(step, rows - first))
+                    f.write(memoryview(t[:nb].cpu().numpy()))
+                    del t
         size = os.path.getsize(path)
         text_path = path
         if "--bgzf" in sys.argv:
@@ -79,8 +82,11 @@ def main():
             print("bgzf: %.3f GB (%.1f s to compress)" % (os.path.getsize(path + ".gz") / 1e9, time.perf_counter() - t1), flush=True)
             path = path + ".gz"
         print("file: %d rows, %.2f GB in %s (%.1f s to generate)" % (rows, size / 1e9, base, time.perf_counter() - t0), flush=True)
-        env = dict(os.environ, BVCF_TIMING="1")
+        env = dict(os.environ, BVCF_TIMING="json" if "--json" in sys.argv else "1")
         extra = []
+        for a in sys.argv:
+            if a.startswith("--devices="):
+                extra += ["--devices", a.split("=", 1)[1]]
         if "--dosage" in sys.argv:
             extra = ["--dosageOutput", path + ".arrow"]
         runs = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--runs=")]
