@@ -116,12 +116,24 @@ constexpr int kFastGroup = 5;  // chunks per buffer; two buffers => 10 KiB in fl
 
 struct FastAcc {
   uint32_t bad, het, hom, miss;
-  uint32_t n_sp;  // wave-uniform: entries in the sparse class list; > BVCF_CMAP_SPARSE_MAX once the line went dense
+  uint32_t n_sp;  // wave-uniform: entries in the raw list of the line; > BVCF_CMAP_SPARSE_MAX once the line went dense
 };
 
-// the sparse class list of the line being scanned lives behind the wave's stage in LDS
-constexpr uint32_t kSparseWords = 16;  // BVCF_CMAP_SPARSE_MAX entries, padded
+// Most alleles of a cohort file are carried by a handful of samples.  A line therefore starts in LIST MODE: a lane
+// whose four fields are not all the reference genotype only appends them, untouched, to a short list in LDS
+// (RawList: the xor-ed field words and the map byte index) -- no classification, no class-map staging.  When the
+// line ends with at most BVCF_CMAP_SPARSE_MAX such lanes, lanes 0..n-1 classify one entry each (finish_list): the
+// counts, the class list of ALT #1 (BVCF_ALLELE_CMAP_SPARSE) -- and, from the same few entries, the class lists of
+// EVERY further ALT index the samples carry (main.go:549-556 rescans the line once per allele; here a multiallelic
+// line is read once).  A line that outgrows the list is replayed into the LDS stage and continues as a dense map
+// (then further ALT indices are left to k_gt, as are all alleles of irregular lines).
+constexpr uint32_t kSparseWords = 16;  // words of one class list: count + BVCF_CMAP_SPARSE_MAX entries
 constexpr uint32_t kDenseMode = BVCF_CMAP_SPARSE_MAX + 1u;
+constexpr uint32_t kListAlleles = 8;   // ALT indices 1..8 can get a class list from finish_list (3 bits in the entry)
+struct RawList {
+  u32x4 t[kSparseWords];       // entry i: the lane's four field words ^ "0<sep>0<TAB>"
+  uint32_t idx[kSparseWords];  // ... and its class-map byte index (chunk * 64 + lane)
+};
 
 constexpr uint32_t kWideSamples = BVCF_WIDE_SAMPLES;  // from here up the census path splits a line's regular scan over waves (k_gt_wide)
 constexpr uint32_t kStageChunks = 64;                 // class-map bytes staged in LDS per wave:
@@ -152,14 +164,65 @@ __device__ __forceinline__ void flush_stage(const uint8_t *stage, uint8_t *cmap,
   __builtin_amdgcn_wave_barrier();
 }
 
-// one 1 KiB chunk (this lane's 4 fields) of a regular region; class bytes go to the LDS stage
-// sp (optional, lines of <= kStageChunks chunks only): the line starts with a list of its non-zero class bytes
-// (acc.n_sp entries in sp[]) instead of the staged map; the stage is zeroed and the list replayed into it when the
-// list overflows.  Most alleles of a cohort file are carried by a handful of samples: their 64-byte list replaces
-// the LDS staging and the map-sized store.
+// The lane's four fields at once, one byte lane per field.  t[q] = field word ^ "0<sep>0<TAB>" with the frame bytes
+// already checked: byte 0 / byte 2 are the allele characters ^ '0' (0..9 for digits, 0x1E for '.'; below 32 whenever
+// the frame test passes, which makes the carry-free zero-byte test ~((x + 0x7F..) | x) & 0x80.. exact).
+// A = first alleles, B = second alleles of the four fields.
+struct Alleles4 {
+  uint32_t A, B, dA, dB;  // dA / dB: 0x80 in every byte that is '.'
+};
+__device__ __forceinline__ uint32_t zero_b(uint32_t x) { return ~((x + 0x7F7F7F7Fu) | x) & 0x80808080u; }
+__device__ __forceinline__ Alleles4 gather4(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+  const uint32_t p01 = __builtin_amdgcn_perm(t1, t0, 0x06020400u);  // a0 a1 b0 b1
+  const uint32_t p23 = __builtin_amdgcn_perm(t3, t2, 0x06020400u);  // a2 a3 b2 b3
+  Alleles4 g;
+  g.A = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+  g.B = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+  g.dA = zero_b(g.A ^ 0x1E1E1E1Eu);
+  g.dB = zero_b(g.B ^ 0x1E1E1E1Eu);
+  return g;
+}
+// alphabet: every allele byte is a digit (<= 9) or '.'; non-zero = not a regular field
+__device__ __forceinline__ uint32_t alphabet_bad(const Alleles4 &g) {
+  return (((g.A + 0x76767676u) & ~g.dA) | ((g.B + 0x76767676u) & ~g.dB)) & 0x80808080u;
+}
+// class bits of the four fields for the allele whose digit is replicated in ka: LO / HI at bits 7, 15, 23, 31
+// (none 0, het 1, hom 2, missing 3; main.go:1063-1124 on "x<sep>y")
+__device__ __forceinline__ void classes4(const Alleles4 &g, uint32_t ka, uint32_t *LO, uint32_t *HI) {
+  const uint32_t eA = zero_b(g.A ^ ka), eB = zero_b(g.B ^ ka);
+  const uint32_t dm = g.dA | g.dB;
+  *LO = (eA ^ eB) | dm;
+  *HI = (eA & eB) | dm;
+}
+// the four (lo, hi) pairs as one class-map byte: pair i sits at bits 8i+7 and moves to bits 2i, 2i+1
+__device__ __forceinline__ uint32_t class_byte(uint32_t LO, uint32_t HI) {
+  return ((((LO >> 7) | (HI >> 6)) & 0x03030303u) * 0x01041040u) >> 24;
+}
+
+// list mode -> dense: the entries classified for ALT #1 into the zeroed stage, their counts into the lanes that replay
+__device__ __forceinline__ void list_to_stage(const RawList *sp, uint32_t n, uint32_t ka, uint8_t *stage, uint32_t n_chunks,
+                                              FastAcc &acc) {
+  zero_stage(stage, n_chunks);
+  if ((uint32_t)lane_id() < n) {
+    const u32x4 e = sp->t[lane_id()];
+    const Alleles4 g = gather4(e.x, e.y, e.z, e.w);
+    uint32_t LO, HI;
+    classes4(g, ka, &LO, &HI);
+    acc.bad |= alphabet_bad(g);
+    acc.het += __popc(LO & ~HI);
+    acc.hom += __popc(HI & ~LO);
+    acc.miss += __popc(LO & HI);
+    stage[sp->idx[lane_id()] % kStageBytes] = (uint8_t)class_byte(LO, HI);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one 1 KiB chunk (this lane's 4 fields) of a regular region
+// sp (optional, lines of <= kStageChunks chunks only): the line is in list mode while acc.n_sp < kDenseMode
 __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunks, uint32_t ns, uint32_t kref,
                                            uint32_t table, uint8_t *cmap, uint8_t *stage, uint32_t stride,
-                                           uint32_t term_xor, FastAcc &acc, uint32_t *sp = nullptr) {
+                                           uint32_t term_xor, FastAcc &acc, RawList *sp = nullptr) {
   const int lane = lane_id();
   const uint32_t f0 = c * 256u + 4u * lane;  // sample index of the lane's first dword
   uint32_t t[4] = {v.x ^ kref, v.y ^ kref, v.z ^ kref, v.w ^ kref};
@@ -176,62 +239,115 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
       }
     }
   }
-  if (__any((t[0] | t[1] | t[2] | t[3]) != 0)) {
-    // The four fields at once, one byte lane per field.  A = first alleles, B = second alleles (each byte is the
-    // allele character ^ '0': 0..9 for digits, 0x1E for '.'; below 32 whenever the frame test passes, which makes the
-    // carry-free zero-byte test ~((x + 0x7F..) | x) & 0x80.. exact).
-    acc.bad |= (t[0] | t[1] | t[2] | t[3]) & 0xFFE0FFE0u;
-    const uint32_t p01 = __builtin_amdgcn_perm(t[1], t[0], 0x06020400u);  // a0 a1 b0 b1
-    const uint32_t p23 = __builtin_amdgcn_perm(t[3], t[2], 0x06020400u);  // a2 a3 b2 b3
-    const uint32_t A = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-    const uint32_t B = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
-    const uint32_t low = table & 0x0FFFFFFFu;  // digit d -> 1 at bits 2d..2d+1 (k_order's / k_stream's per-allele table): the allele digit
-    const uint32_t ka = low ? (uint32_t)(__builtin_ctz(low) >> 1) * 0x01010101u : 0xFFFFFFFFu;
-    auto zero_b = [](uint32_t x) -> uint32_t { return ~((x + 0x7F7F7F7Fu) | x) & 0x80808080u; };
-    const uint32_t dA = zero_b(A ^ 0x1E1E1E1Eu), dB = zero_b(B ^ 0x1E1E1E1Eu);  // '.'
-    const uint32_t eA = zero_b(A ^ ka), eB = zero_b(B ^ ka);                    // the allele being counted
-    // alphabet: a byte is a digit (<= 9) or '.'
-    acc.bad |= (((A + 0x76767676u) & ~dA) | ((B + 0x76767676u) & ~dB)) & 0x80808080u;
-    const uint32_t dm = dA | dB;
-    const uint32_t LO = (eA ^ eB) | dm, HI = (eA & eB) | dm;  // class bits of the four fields at bits 7, 15, 23, 31
-    acc.het += __popc(LO & ~HI);
-    acc.hom += __popc(HI & ~LO);
-    acc.miss += __popc(LO & HI);
-    // gather the four (lo, hi) pairs into one byte: pair i sits at bits 8i, 8i+1 and moves to 24 + 2i
-    const uint32_t byte = ((((LO >> 7) | (HI >> 6)) & 0x03030303u) * 0x01041040u) >> 24;
-    if (cmap && sp && acc.n_sp < kDenseMode) {
-      const unsigned long long nz = __ballot(byte != 0);
+  const uint32_t tor = t[0] | t[1] | t[2] | t[3];
+  const uint32_t low = table & 0x0FFFFFFFu;  // digit d -> 1 at bits 2d..2d+1: the allele digit
+  const uint32_t ka = low ? (uint32_t)(__builtin_ctz(low) >> 1) * 0x01010101u : 0xFFFFFFFFu;
+  if (__any(tor != 0)) {
+    // frame: separator and TAB bytes as expected, allele bytes within '0'^[0,31]
+    acc.bad |= tor & 0xFFE0FFE0u;
+    bool dense = !(sp && acc.n_sp < kDenseMode);
+    if (!dense) {
+      const unsigned long long nz = __ballot(tor != 0);
       const uint32_t cnt = (uint32_t)__popcll(nz);
       if (acc.n_sp + cnt <= BVCF_CMAP_SPARSE_MAX) {
         const uint32_t at = acc.n_sp + __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
-        if (byte) sp[at] = ((c * 64u + (uint32_t)lane) << 8) | byte;
+        if (tor) {
+          sp->t[at] = u32x4{t[0], t[1], t[2], t[3]};
+          sp->idx[at] = c * 64u + (uint32_t)lane;
+        }
         acc.n_sp = bcast0(acc.n_sp + cnt);  // (kept provably wave-uniform: the tests on it stay scalar branches)
       } else {
-        // too many for the list: from here on the line is a map.  Replay the entries into the zeroed stage.
-        zero_stage(stage, n_chunks);
-        if ((uint32_t)lane < acc.n_sp) {
-          const uint32_t e = sp[lane];
-          stage[e >> 8] = (uint8_t)e;
-        }
+        // too many for the list: from here on the line is a map
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        list_to_stage(sp, acc.n_sp, ka, stage, n_chunks, acc);
         acc.n_sp = bcast0(kDenseMode);
+        dense = true;
       }
     }
-    if (cmap && (!sp || acc.n_sp >= kDenseMode)) stage[(c % kStageChunks) * 64u + lane] = (uint8_t)byte;  // the stage starts zeroed
-  }
-  if (cmap && sp && acc.n_sp < kDenseMode) {
-    if (c + 1 == n_chunks) {  // the list: count, then the entries
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if ((uint32_t)lane <= acc.n_sp)
-        __builtin_nontemporal_store(lane == 0 ? acc.n_sp : sp[lane - 1], reinterpret_cast<uint32_t *>(cmap) + lane);
-      __builtin_amdgcn_wave_barrier();
+    if (dense) {
+      const Alleles4 g = gather4(t[0], t[1], t[2], t[3]);
+      uint32_t LO, HI;
+      classes4(g, ka, &LO, &HI);
+      acc.bad |= alphabet_bad(g);
+      acc.het += __popc(LO & ~HI);
+      acc.hom += __popc(HI & ~LO);
+      acc.miss += __popc(LO & HI);
+      if (cmap) stage[(c % kStageChunks) * 64u + lane] = (uint8_t)class_byte(LO, HI);  // the stage starts zeroed
     }
-  } else if (cmap && ((c % kStageChunks) == kStageChunks - 1u || c + 1 == n_chunks)) {
+  }
+  if (cmap && !(sp && acc.n_sp < kDenseMode) && ((c % kStageChunks) == kStageChunks - 1u || c + 1 == n_chunks)) {
     flush_stage(stage, cmap, c - (c % kStageChunks), ((c % kStageChunks) + 1u) * 64u, stride);
     if (c + 1 != n_chunks) zero_stage(stage, n_chunks - (c + 1u));
   }
+}
+
+// End of a line that stayed in list mode (n = acc.n_sp <= BVCF_CMAP_SPARSE_MAX entries): lane i classifies entry i.
+// Writes the class list of ALT #1 to cmap, and -- when the entries carry allele digits 2..kmax -- the class lists
+// of ALT #2..#kmax to cmap + 64 * (k - 1).  Returns kmax (1: no further allele is carried).  If a list cannot be
+// given (a digit above max_k, i.e. no room in the slot or above kListAlleles) the line is turned into a dense map
+// after all (returns 0): its further ALT indices then go to k_gt.
+__device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc, uint8_t *cmap, uint32_t max_k,
+                                                uint8_t *stage, uint32_t n_chunks, uint32_t stride) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int lane = lane_id();
+  const uint32_t n = acc.n_sp;
+  u32x4 e = {0u, 0u, 0u, 0u};
+  uint32_t idx = 0;
+  if ((uint32_t)lane < n) {
+    e = sp->t[lane];
+    idx = sp->idx[lane];
+  }
+  const Alleles4 g = gather4(e.x, e.y, e.z, e.w);
+  acc.bad |= alphabet_bad(g);
+  uint32_t LO, HI;
+  classes4(g, 0x01010101u, &LO, &HI);
+  acc.het = __popc(LO & ~HI);
+  acc.hom = __popc(HI & ~LO);
+  acc.miss = __popc(LO & HI);
+  const uint32_t byte1 = class_byte(LO, HI);
+  // further alleles: a digit 2..9 in some entry (dots alone, 0x1E, do not count: they are in every list anyway)
+  uint32_t kmax = 1;
+  const uint32_t tor = e.x | e.y | e.z | e.w;
+  if (__any((tor & 0x000E000Eu) != 0)) {
+    // bytes >= 2 that are not dots
+    const uint32_t hi2 = (((g.A + 0x7E7E7E7Eu) & ~g.dA) | ((g.B + 0x7E7E7E7Eu) & ~g.dB)) & 0x80808080u;
+    if (__any(hi2 != 0)) {
+#pragma nounroll
+      for (uint32_t k = 9; k >= 2; k--) {
+        const uint32_t kk = k * 0x01010101u;
+        if (__any((zero_b(g.A ^ kk) | zero_b(g.B ^ kk)) != 0)) {
+          kmax = k;
+          break;
+        }
+      }
+      if (kmax > max_k) {
+        // no list for that allele: the line becomes a dense map (ALT #1) and k_gt scans the others
+        zero_stage(stage, n_chunks);
+        if ((uint32_t)lane < n) stage[idx % kStageBytes] = (uint8_t)byte1;
+        flush_stage(stage, cmap, 0u, n_chunks * 64u, stride);
+        acc.n_sp = bcast0(kDenseMode);
+        return 0u;
+      }
+#pragma nounroll
+      for (uint32_t k = 2; k <= kmax; k++) {
+        uint32_t lo_k, hi_k;
+        classes4(g, k * 0x01010101u, &lo_k, &hi_k);
+        const uint32_t byte_k = class_byte(lo_k, hi_k);
+        const unsigned long long nz = __ballot(byte_k != 0);
+        uint32_t *list = reinterpret_cast<uint32_t *>(cmap + 64u * (k - 1u));
+        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
+        if (byte_k) __builtin_nontemporal_store((idx << 8) | byte_k, list + 1u + at);
+        if (lane == 0) __builtin_nontemporal_store((uint32_t)__popcll(nz), list);
+      }
+    }
+  }
+  // the list of ALT #1: count, then the entries (an entry may carry a zero byte: a lane whose fields only hold
+  // other alleles)
+  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((idx << 8) | byte1), 0x138, 0xF, 0xF, false);  // wave_shr:1
+  if ((uint32_t)lane <= n) __builtin_nontemporal_store(lane == 0 ? n : prev, reinterpret_cast<uint32_t *>(cmap) + lane);
+  return kmax;
 }
 
 // check_term: also require the byte after the last sample to be the line terminator (the caller

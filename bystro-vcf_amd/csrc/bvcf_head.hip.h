@@ -70,9 +70,9 @@ __device__ inline void write_allele(const KernelArgs &a, uint32_t idx, uint32_t 
   r.n_het = 0;
   r.n_hom = 0;
   r.n_miss = 0;
-  // offsets are multiples of 16; k_stream sets bit 0 when the slot holds a sparse list
+  // offsets are multiples of 16; k_stream sets bit 0 when the slot holds a class list (bits 1-3: see finish_list)
   const bool sparse = cmap_off != BVCF_NO_CMAP && (cmap_off & 1u);
-  r.cmap_off = sparse ? cmap_off & ~1u : cmap_off;
+  r.cmap_off = sparse ? cmap_off & ~15u : cmap_off;
   r.ref = ref;
   r.alt_base = alt_base;
   r.kind = e.mnp ? (uint8_t)BVCF_ALT_BASE : e.kind;
@@ -421,8 +421,46 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
           uint32_t task = task0, cm_off = cm0;
           if (ns > 0 && k > 0) {
             task = task_base + tasks_used;
-            cm_off = cmap_of(a, map_base + tasks_used, maps);
-            put_task(a, task, line, k + 1, s_begin, cend, cm_off);
+            // Streaming path, a line k_stream kept as a list of its few non-reference samples: the same entries gave
+            // the class list of every further ALT index they carry (finish_list), so the line is not read again
+            // (the reference rescans it once per allele, main.go:549-556).  The counts come from the list.
+            bool resolved = false;
+            if (a.fused && !deferred && cm0 != BVCF_NO_CMAP && (cm0 & 1u) && task < a.max_tasks) {
+              const uint32_t kmax = ((cm0 >> 1) & 7u) + 1u;
+              const GtResult first = a.results[line];
+              GtResult r;
+              r.ac = 0;
+              r.an = first.an;
+              r.n_het = r.n_hom = 0;
+              r.n_miss = first.n_miss;
+              r.n_fields = first.n_fields;
+              r.regular = 1;
+              r.pad = 0;
+              if (k + 1u <= kmax) {
+                cm_off = ((cm0 & ~15u) + 64u * k) | 1u;
+                const uint32_t *list = reinterpret_cast<const uint32_t *>(a.cmap + (cm_off & ~15u));
+                const uint32_t n = min(list[0], (uint32_t)BVCF_CMAP_SPARSE_MAX);
+#pragma nounroll
+                for (uint32_t i = 0; i < n; i++) {
+                  const uint32_t b = list[1u + i] & 0xFFu, lo = b & 0x55u, hi = (b >> 1) & 0x55u;
+                  r.n_het += __popc(lo & ~hi);
+                  r.n_hom += __popc(hi & ~lo);
+                }
+                r.ac = r.n_het + 2u * r.n_hom;
+                resolved = true;
+              } else if (first.n_miss == 0) {
+                cm_off = BVCF_NO_CMAP;  // nobody carries it and nobody is missing: ac == 0, the row is dropped (main.go:558-560)
+                resolved = true;
+              }
+              if (resolved) {
+                a.results[task] = r;
+                put_task(a, task, line, 0, cend, cend, BVCF_NO_CMAP);  // nothing to scan
+              }
+            }
+            if (!resolved) {
+              cm_off = cmap_of(a, map_base + tasks_used, maps);
+              put_task(a, task, line, k + 1, s_begin, cend, cm_off);
+            }
             tasks_used++;
           }
           if (ns == 0) task = kNoTask;

@@ -143,9 +143,9 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
 #endif
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
-  __shared__ uint32_t s_sparse[kWavesPerWg][kSparseWords];
+  __shared__ __attribute__((aligned(16))) RawList s_sparse[kWavesPerWg];
   uint8_t *stage = s_stage[wave_in_wg()];
-  uint32_t *sparse = s_sparse[wave_in_wg()];
+  RawList *sparse = &s_sparse[wave_in_wg()];
   const int lane = lane_id();
   // (threadIdx.x >> 6 is the same in all 64 lanes, which the compiler cannot know: without the broadcast everything
   // derived from the wave index -- tile numbers, run bounds, class-map slots -- lives in vector registers)
@@ -313,11 +313,11 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           // ---- scan A, re-issuing each register for B
           const uint32_t cmA = bcast0(map_slot());  // (wave-uniform by construction; tell the compiler)
           uint8_t *cm = cmA != BVCF_NO_CMAP ? a.cmap + cmA : nullptr;
-          // the class map starts as a sparse list (nothing to zero) when a list fits the map's slot
+          // the line starts in list mode (nothing to zero, nothing classified per chunk) when a list fits the map's slot
 #ifdef BVCF_EXP_NO_SPARSE
           const bool sparse_ok = false;
 #else
-          const bool sparse_ok = a.cmap_stride >= 4u * kSparseWords;
+          const bool sparse_ok = cm != nullptr && a.cmap_stride >= 4u * kSparseWords;
 #endif
           FastAcc acc = {0, 0, 0, 0, sparse_ok ? 0u : kDenseMode};
           if (cm && !sparse_ok) zero_stage(stage, nc);
@@ -340,6 +340,10 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
             va[g] = chunk_at(s_next, g);
           }
           STAMP(3);
+          // a line that ends in list mode: its few entries classified now, for ALT #1 and every further ALT index
+          uint32_t kmax = 0;
+          if (sparse_ok && acc.n_sp < kDenseMode)
+            kmax = finish_list(sparse, acc, cm, min(kListAlleles, a.cmap_stride / (4u * kSparseWords)), stage, nc, a.cmap_stride);
           if (__any(acc.bad != 0)) {
             // A is not regular after all: B was predicted from a wrong line end.  Leave the
             // pipeline (the loads in flight are simply dropped) and take A the slow way.
@@ -349,8 +353,9 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           }
           finish_stats(acc, &st);
           seen++;
-          // (bit 0 of the offset tells k_head that the slot holds a list, BVCF_ALLELE_CMAP_SPARSE)
-          commit(pA, peA, st, false, cm && acc.n_sp < kDenseMode ? cmA | 1u : cmA);
+          // (offsets are multiples of 16.  Bit 0 tells k_head that the slot holds a list, BVCF_ALLELE_CMAP_SPARSE;
+          // bits 1-3 = kmax - 1: the slot also holds the lists of ALT #2..#kmax, and no sample carries a higher one)
+          commit(pA, peA, st, false, kmax ? cmA | 1u | ((kmax - 1u) << 1) : cmA);
           p = peA + 1u;
           if (!b_ok) {
             s_begin = kNone;  // nothing pending: rediscover from p

@@ -1,0 +1,134 @@
+"""Every ALT index of a multiallelic line from ONE pass (main.go:549-556 rescans per allele): on the streaming path a
+line whose non-reference samples fit the raw list gets the class lists of ALT #2..#8 from the same entries
+(finish_list), k_head takes the counts from the lists; everything else still goes through k_gt.  All cases against the
+oracle, on both device paths."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+import vcfgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["census", "streaming"])
+def bvcf_path(request, monkeypatch):
+    monkeypatch.setenv("BVCF_PATH", "2" if request.param == "streaming" else "1")
+    return request.param
+
+
+@pytest.fixture(scope="module")
+def bv():
+    import bystro_vcf_amd as b
+    return b
+
+
+def both(bv, vcf, cfg=None, **kw):
+    rc_o, out_o, log_o, n_o = orc.run(vcf, cfg)
+    rc_g, out_g, log_g, n_g = bv.run_buffer(vcf, cfg, **kw)
+    assert rc_g == 0 and rc_o == 0 and n_g == n_o
+    if out_g != out_o:
+        a, b = out_o.split(b"\n"), out_g.split(b"\n")
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert x == y, "row %d differs:\noracle: %r\nhip:    %r" % (i, x[:300], y[:300])
+        assert len(a) == len(b)
+    assert log_g == log_o
+    return out_g
+
+
+def _rows(seed, ns, n_lines, sep="|"):
+    """multiallelic lines with 1-9 ALTs: a few carriers of some alleles (list mode), none of others, sometimes many
+    (dense), sometimes missing genotypes, carriers right at the 15 / 16 entry boundary of the list"""
+    rng = random.Random(seed)
+    bases = "ACGT"
+    rows = []
+    pos = 100
+    for li in range(n_lines):
+        pos += rng.randint(1, 50)
+        n_alt = rng.choice([1, 2, 2, 3, 3, 4, 6, 8, 9])
+        ref = rng.choice(bases)
+        alts = []
+        for k in range(n_alt):
+            alts.append(rng.choice([b for b in bases if b != ref]) + ("" if k < 3 else "A" * (k - 2)))
+        gts = [["0", "0"] for _ in range(ns)]
+        mode = li % 7
+        # which alleles have carriers
+        present = [k for k in range(1, n_alt + 1) if rng.random() < 0.7] or [1]
+        if mode in (0, 1, 2):      # a few carriers: stays a list
+            n_car = rng.randint(1, 12)
+        elif mode == 3:            # exactly around the list limit, in distinct 4-sample groups
+            n_car = rng.choice([14, 15, 16, 17])
+        elif mode == 4:            # many carriers: dense map
+            n_car = rng.randint(40, max(41, ns // 3))
+        elif mode == 5:            # nobody carries anything (row dropped) or only the last allele
+            n_car = rng.choice([0, 1])
+            present = [n_alt]
+        else:
+            n_car = rng.randint(1, 8)
+        if mode == 3:
+            groups = rng.sample(range(ns // 4), min(n_car, ns // 4))
+            who = [4 * g + rng.randint(0, 3) for g in groups]
+        else:
+            who = rng.sample(range(ns), min(n_car, ns))
+        for s in who:
+            a = str(rng.choice(present))
+            b = str(rng.choice(present + [0, 0]))
+            gts[s] = [a, b] if rng.random() < 0.5 else [b, a]
+        if mode == 6 or rng.random() < 0.1:   # missing genotypes
+            for s in rng.sample(range(ns), rng.randint(1, 5)):
+                gts[s] = rng.choice([[".", "."], [".", "1"], ["2", "."]])
+        row = ["7", str(pos), "rs%d" % li, ref, ",".join(alts), ".", "PASS", "NA=%d" % n_alt, "GT"]
+        row += [sep.join(g) for g in gts]
+        rows.append("\t".join(row))
+    return rows
+
+
+@pytest.mark.parametrize("seed,ns", [(1, 2504), (2, 2504), (3, 300), (4, 1030), (5, 513), (6, 260)])
+def test_every_alt_index_matches_oracle(bv, seed, ns):
+    """ns = 2504: lists for ALT #2..#8 fit the 640-byte slot; 513 (slot 144 B: lists up to ALT #2), 300 / 260 (slot
+    80 B: no room for a second list, the line falls back to a dense map + k_gt)"""
+    vcf = (vcfgen.header(ns) + "\n".join(_rows(seed, ns, 400, "|" if seed % 2 else "/")) + "\n").encode()
+    out = both(bv, vcf, {"allow": "", "keepInfo": True})
+    assert out.count(b"MULTIALLELIC") > 200
+    both(bv, vcf, {"allow": "", "keepId": True}, max_batch_bytes=1 << 20)
+
+
+def test_device_results_agree_between_paths(bv, monkeypatch, bvcf_path):
+    """record by record: streaming-path counts and class maps of further ALT indices (taken from the lists) == the
+    census path's (scanned by k_gt)"""
+    ns = 2504
+    rows = _rows(11, ns, 300)
+    body = ("\n".join(rows) + "\n").encode()
+    res = {}
+    for path in (1, 2):
+        ctx = bv.Ctx(9 + ns, allow="", path=path)
+        res[path] = ctx.process(body)
+        ctx.close()
+    a, b = res[1], res[2]
+    assert len(a.lines) == len(b.lines) == 300
+    n_cmp = 0
+    for i in range(300):
+        ra, rb = a.records(i), b.records(i)
+        assert len(ra) == len(rb)
+        for x, y in zip(ra, rb):
+            for f in ("alt_idx", "ac", "an", "n_het", "n_hom", "n_miss", "kind", "alt_base"):
+                assert x[f] == y[f], (i, f, int(x[f]), int(y[f]))
+            if x["ac"] > 0:
+                assert int(y["cmap_off"]) != bv.NO_CMAP
+                assert (a.classes(x) == b.classes(y)).all(), (i, int(x["alt_idx"]))
+                n_cmp += 1
+    assert n_cmp > 300
+
+
+def test_dosage_rows_of_multiallelic_lines(bv):
+    """--dosageOutput rows of alleles whose class list came from finish_list (k_dosage expands the list)"""
+    import test_gpu_parity as tp
+    ns = 2504
+    vcf = (vcfgen.header(ns) + "\n".join(_rows(21, ns, 120)) + "\n").encode()
+    got = tp._device_dosage_rows(bv, vcf)
+    want = [d for _, d in orc.run_dosage(vcf, {"allow": ""})]
+    assert len(got) == len(want) > 100
+    for i, (dg, dw) in enumerate(zip(got, want)):
+        assert dg == dw, i
