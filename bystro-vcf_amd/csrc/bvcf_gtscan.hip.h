@@ -128,11 +128,12 @@ struct FastAcc {
 // line is read once).  A line that outgrows the list is replayed into the LDS stage and continues as a dense map
 // (then further ALT indices are left to k_gt, as are all alleles of irregular lines).
 constexpr uint32_t kSparseWords = 16;  // words of one class list: count + BVCF_CMAP_SPARSE_MAX entries
-constexpr uint32_t kDenseMode = BVCF_CMAP_SPARSE_MAX + 1u;
+constexpr uint32_t kRawMax = 63;       // entries a line may collect in list mode: one lane each in finish_list
+constexpr uint32_t kDenseMode = kRawMax + 1u;
 constexpr uint32_t kListAlleles = 8;   // ALT indices 1..8 can get a class list from finish_list (3 bits in the entry)
 struct RawList {
-  u32x4 t[kSparseWords];       // entry i: the lane's four field words ^ "0<sep>0<TAB>"
-  uint32_t idx[kSparseWords];  // ... and its class-map byte index (chunk * 64 + lane)
+  u32x4 t[kRawMax + 1];        // entry i: the lane's four field words ^ "0<sep>0<TAB>"
+  uint32_t idx[kRawMax + 1];   // ... and its class-map byte index (chunk * 64 + lane)
 };
 
 constexpr uint32_t kWideSamples = BVCF_WIDE_SAMPLES;  // from here up the census path splits a line's regular scan over waves (k_gt_wide)
@@ -249,7 +250,7 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
     if (!dense) {
       const unsigned long long nz = __ballot(tor != 0);
       const uint32_t cnt = (uint32_t)__popcll(nz);
-      if (acc.n_sp + cnt <= BVCF_CMAP_SPARSE_MAX) {
+      if (acc.n_sp + cnt <= kRawMax) {
         const uint32_t at = acc.n_sp + __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
         if (tor) {
           sp->t[at] = u32x4{t[0], t[1], t[2], t[3]};
@@ -282,11 +283,12 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
   }
 }
 
-// End of a line that stayed in list mode (n = acc.n_sp <= BVCF_CMAP_SPARSE_MAX entries): lane i classifies entry i.
-// Writes the class list of ALT #1 to cmap, and -- when the entries carry allele digits 2..kmax -- the class lists
-// of ALT #2..#kmax to cmap + 64 * (k - 1).  Returns kmax (1: no further allele is carried).  If a list cannot be
-// given (a digit above max_k, i.e. no room in the slot or above kListAlleles) the line is turned into a dense map
-// after all (returns 0): its further ALT indices then go to k_gt.
+// End of a line that stayed in list mode (n = acc.n_sp <= kRawMax entries): lane i classifies entry i.
+// With at most BVCF_CMAP_SPARSE_MAX entries the class list of ALT #1 goes to cmap, and -- when the entries carry
+// allele digits 2..kmax -- the class lists of ALT #2..#kmax to cmap + 64 * (k - 1); returns kmax (1: no further
+// allele is carried).  Otherwise the entries become the dense map of ALT #1 and 0 is returned: more entries than a
+// list holds, or a digit above max_k (no room in the slot, or above kListAlleles) -- further ALT indices of such a
+// line go to k_gt.
 __device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc, uint8_t *cmap, uint32_t max_k,
                                                 uint8_t *stage, uint32_t n_chunks, uint32_t stride) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -322,26 +324,26 @@ __device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc,
           break;
         }
       }
-      if (kmax > max_k) {
-        // no list for that allele: the line becomes a dense map (ALT #1) and k_gt scans the others
-        zero_stage(stage, n_chunks);
-        if ((uint32_t)lane < n) stage[idx % kStageBytes] = (uint8_t)byte1;
-        flush_stage(stage, cmap, 0u, n_chunks * 64u, stride);
-        acc.n_sp = bcast0(kDenseMode);
-        return 0u;
-      }
-#pragma nounroll
-      for (uint32_t k = 2; k <= kmax; k++) {
-        uint32_t lo_k, hi_k;
-        classes4(g, k * 0x01010101u, &lo_k, &hi_k);
-        const uint32_t byte_k = class_byte(lo_k, hi_k);
-        const unsigned long long nz = __ballot(byte_k != 0);
-        uint32_t *list = reinterpret_cast<uint32_t *>(cmap + 64u * (k - 1u));
-        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
-        if (byte_k) __builtin_nontemporal_store((idx << 8) | byte_k, list + 1u + at);
-        if (lane == 0) __builtin_nontemporal_store((uint32_t)__popcll(nz), list);
-      }
     }
+  }
+  if (n > BVCF_CMAP_SPARSE_MAX || kmax > max_k) {
+    // a dense map of ALT #1 after all (k_gt scans the further ALT indices, if any)
+    zero_stage(stage, n_chunks);
+    if ((uint32_t)lane < n) stage[idx % kStageBytes] = (uint8_t)byte1;
+    flush_stage(stage, cmap, 0u, n_chunks * 64u, stride);
+    acc.n_sp = bcast0(kDenseMode);
+    return 0u;
+  }
+#pragma nounroll
+  for (uint32_t k = 2; k <= kmax; k++) {
+    uint32_t lo_k, hi_k;
+    classes4(g, k * 0x01010101u, &lo_k, &hi_k);
+    const uint32_t byte_k = class_byte(lo_k, hi_k);
+    const unsigned long long nz = __ballot(byte_k != 0);
+    uint32_t *list = reinterpret_cast<uint32_t *>(cmap + 64u * (k - 1u));
+    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
+    if (byte_k) __builtin_nontemporal_store((idx << 8) | byte_k, list + 1u + at);
+    if (lane == 0) __builtin_nontemporal_store((uint32_t)__popcll(nz), list);
   }
   // the list of ALT #1: count, then the entries (an entry may carry a zero byte: a lane whose fields only hold
   // other alleles)
