@@ -36,7 +36,9 @@ struct BatchCounters {
   uint32_t n_tasks;      // genotype-scan tasks requested past the first n_lines
   uint32_t lines_seen;   // terminated lines in the block (== n_lines on the census path)
   uint32_t cmap_maps;    // streaming path: class maps handed out
-  uint32_t pad[2];
+  uint32_t pad[2];       // [0]: internal error flag; [1]: wide ctxs, the longest sample region
+  uint32_t n_finish;     // streaming path: entries of finish_items (what k_finish still has to settle)
+  uint32_t pad2;
 };
 
 // streaming path: what k_stream knows about a line when it has scanned it
@@ -101,9 +103,13 @@ struct KernelArgs {
                          // least n_header - 1 + eol_chars bytes long
   uint32_t n_tiles;
   StreamEntry *entries;  // [n_tiles * tile_quota]
-  uint32_t *line_len;    // [max_lines]
+  uint32_t *line_len;    // [max_lines]; bit 31: line_bits holds the line's head TAB bitmap
   uint32_t *line_cmap;   // [max_lines] class map of ALT #1
+  uint16_t *head_bits;   // [n_tiles * tile_quota][16] TAB mask per 16 bytes of a line's 256-byte head window (k_stream)
+  uint32_t *line_bits;   // [max_lines][8] the same, in input order (k_order)
+  uint32_t *finish_items;// [max_lines + max_alleles] line index, or 0x80000000 | allele slot, that k_finish settles
 };
+constexpr uint32_t kHasHeadBits = 0x80000000u;
 
 // ------------------------------------------------------------------ wave helpers
 

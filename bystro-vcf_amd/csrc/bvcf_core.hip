@@ -36,7 +36,8 @@ struct Slot {
   uint32_t *d_win_tabs = nullptr;  // wide ctxs only
   uint32_t win_tabs_cap = 0;
   StreamEntry *d_entries = nullptr;
-  uint32_t *d_line_len = nullptr, *d_line_cmap = nullptr;
+  uint32_t *d_line_len = nullptr, *d_line_cmap = nullptr, *d_line_bits = nullptr, *d_finish_items = nullptr;
+  uint16_t *d_head_bits = nullptr;
   BatchCounters *d_counters = nullptr;
   // pinned host
   BatchCounters *h_counters = nullptr;
@@ -138,6 +139,9 @@ void free_slot(Slot &s) {
   hipFree(s.d_entries);
   hipFree(s.d_line_len);
   hipFree(s.d_line_cmap);
+  hipFree(s.d_line_bits);
+  hipFree(s.d_finish_items);
+  hipFree(s.d_head_bits);
   hipFree(s.d_counters);
   hipHostFree(s.h_counters);
   hipHostFree(s.h_lines);
@@ -167,6 +171,10 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   s.d_win_tabs = nullptr;
   hipFree(s.d_line_len);
   hipFree(s.d_line_cmap);
+  hipFree(s.d_line_bits);
+  hipFree(s.d_finish_items);
+  s.d_line_bits = nullptr;
+  s.d_finish_items = nullptr;
   hipHostFree(s.h_lines);
   hipHostFree(s.h_alleles);
   hipHostFree(s.h_errs);
@@ -201,6 +209,10 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   }
   HIP_TRY(c, hipMalloc(&s.d_line_len, c->max_lines * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&s.d_line_cmap, c->max_lines * sizeof(uint32_t)));
+  if (c->fused) {
+    HIP_TRY(c, hipMalloc(&s.d_line_bits, c->max_lines * 8 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&s.d_finish_items, (c->max_lines + c->max_alleles) * sizeof(uint32_t)));
+  }
   HIP_TRY(c, hipHostMalloc(&s.h_lines, c->max_lines * sizeof(bvcf_line), hipHostMallocDefault));
   HIP_TRY(c, hipHostMalloc(&s.h_alleles, c->max_alleles * sizeof(bvcf_allele), hipHostMallocDefault));
   HIP_TRY(c, hipHostMalloc(&s.h_errs, c->max_alleles * sizeof(bvcf_err), hipHostMallocDefault));
@@ -230,6 +242,7 @@ int alloc_slot(bvcf_ctx *c, Slot &s) {
   if (c->fused) {
     const uint64_t max_tiles = (c->p.max_batch_bytes + c->tile_bytes - 1) / c->tile_bytes + 1;
     HIP_TRY(c, hipMalloc(&s.d_entries, max_tiles * c->tile_quota * sizeof(StreamEntry)));
+    HIP_TRY(c, hipMalloc(&s.d_head_bits, max_tiles * c->tile_quota * 16 * sizeof(uint16_t)));
   }
   return alloc_results(c, s);
 }
@@ -274,6 +287,9 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.entries = s.d_entries;
   a.line_len = s.d_line_len;
   a.line_cmap = s.d_line_cmap;
+  a.head_bits = s.d_head_bits;
+  a.line_bits = s.d_line_bits;
+  a.finish_items = s.d_finish_items;
   return a;
 }
 

@@ -56,20 +56,22 @@ __device__ inline bool filter_in(const B &buf, Span f, const uint16_t *off, cons
   return false;
 }
 
+// gr (optional): the genotype counts of the record, when they are already known (streaming path); otherwise
+// k_finish copies them from the scan result of `task`
 __device__ inline void write_allele(const KernelArgs &a, uint32_t idx, uint32_t line, uint32_t alt_idx,
                                     const AlleleEval &e, long long pos, uint8_t ref, uint8_t alt_base,
-                                    uint8_t site_type, uint32_t task, uint32_t cmap_off) {
+                                    uint8_t site_type, uint32_t task, uint32_t cmap_off, const GtResult *gr = nullptr) {
   bvcf_allele r;
   r.pos = pos;
   r.line = line;
   r.alt_idx = alt_idx;
   r.alt_off = e.alt_off;
   r.alt_len = e.mnp ? 1u : e.alt_len;
-  r.ac = 0;
-  r.an = 0;
-  r.n_het = 0;
-  r.n_hom = 0;
-  r.n_miss = 0;
+  r.ac = gr ? gr->ac : 0u;
+  r.an = gr ? gr->an : 0u;
+  r.n_het = gr ? gr->n_het : 0u;
+  r.n_hom = gr ? gr->n_hom : 0u;
+  r.n_miss = gr ? gr->n_miss : 0u;
   // offsets are multiples of 16; k_stream sets bit 0 when the slot holds a class list (bits 1-3: see finish_list)
   const bool sparse = cmap_off != BVCF_NO_CMAP && (cmap_off & 1u);
   r.cmap_off = sparse ? cmap_off & ~15u : cmap_off;
@@ -167,7 +169,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
       if (l < n_lines) {
         my_ls = a.line_off[l];
         if (a.fused) {
-          my_len = a.line_len[l];
+          my_len = a.line_len[l];  // (bit 31 rides along: the line's head TAB bitmap is in line_bits)
         } else {
           const uint32_t le = a.line_off[l + 1];
           my_len = le - my_ls >= a.eol_chars ? le - my_ls - a.eol_chars : 0u;  // chomp, main.go:535
@@ -191,10 +193,30 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     } else {
       v_win[0] = load16(a.buf, __shfl(my_ls, 0, kGroup) + 16u * gl, a.cap);
     }
-    auto tokenise = [&](uint32_t r, uint32_t ls, uint32_t len, const u32x4 &v_first) {
+    auto tokenise = [&](uint32_t r, uint32_t ls, uint32_t len_flag, const u32x4 &v_first) {
       const uint32_t ll = r * kGroupsPerWg + g;
       const uint32_t line = line0 + ll;
       if (line >= n_lines) return;
+      const uint32_t len = len_flag & ~kHasHeadBits;
+      if (len_flag & kHasHeadBits) {
+        // k_stream found this line's TABs when it parsed the head window (line_bits): only stage the bytes here
+        const uint32_t rel = 16u * gl;
+        if (rel < kHeadStage) {
+          uint32_t *row = &s_head[ll * kHeadRow + rel / 4];
+          row[0] = v_first.x;
+          row[1] = v_first.y;
+          row[2] = v_first.z;
+          row[3] = v_first.w;
+        }
+        if (gl == 0) {
+          s_ls[ll] = ls;
+          s_len[ll] = len_flag;
+          s_found[ll] = 0;
+          s_staged[ll] = min(len, kHeadStage);
+          s_extra[ll] = 0;
+        }
+        return;
+      }
       const uint32_t cend = ls + len;
       uint32_t found = 0, base = ls;
       // strings.Split(row, "\t") for the fixed columns, main.go:535
@@ -257,9 +279,28 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     const uint32_t ll = threadIdx.x;
     const uint32_t line = line0 + ll;
     const bool active = line < n_lines;
-    const uint32_t ls = active ? s_ls[ll] : 0u, len = active ? s_len[ll] : 0u, found = active ? s_found[ll] : 0u;
+    const uint32_t ls = active ? s_ls[ll] : 0u, len_flag = active ? s_len[ll] : 0u;
+    const uint32_t len = len_flag & ~kHasHeadBits;
+    uint32_t found = active ? s_found[ll] : 0u;
     const uint32_t cend = ls + len;
-    const uint32_t *tab = &s_tab[ll * kTabRow];
+    uint32_t *tab = &s_tab[ll * kTabRow];
+    if (len_flag & kHasHeadBits) {
+      // the nine TABs from k_stream's bitmap of the head window (256 bits from the dword at or before ls)
+      const u32x4 *bits = reinterpret_cast<const u32x4 *>(a.line_bits + (size_t)line * 8u);
+      const u32x4 b0 = bits[0], b1 = bits[1];
+      const uint32_t w[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const uint32_t base = ls & ~3u;
+      uint32_t k = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) {
+        uint32_t m = w[q];
+        while (m && k < 9u) {
+          tab[k++] = base + 32u * q + (uint32_t)__ffs(m) - 1u;
+          m &= m - 1u;
+        }
+      }
+      found = k;
+    }
     Bytes hb;
     hb.g = a.buf;
     hb.lds = as_lds(&s_head[ll * kHeadRow]);
@@ -400,6 +441,17 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         }
       }
       first_task = task0;
+      // Streaming path: the counts of ALT #1 of a line k_stream scanned are final (results[line]), as are those of the
+      // further ALT indices resolved from class lists below: such records are complete here.  What still depends on
+      // k_gt goes on k_finish's work list.
+      const bool final0 = a.fused && ns > 0 && !deferred && line < a.max_tasks;
+      GtResult g0 = GtResult{};
+      if (final0) g0 = a.results[line];
+      auto to_finish = [&](uint32_t item) {
+        const uint32_t at = atomicAdd(&a.counters->n_finish, 1u);
+        if (at < a.max_lines + a.max_alleles) a.finish_items[at] = item;
+      };
+      if (a.fused && ns > 0 && deferred) to_finish(line);  // its field count comes from k_gt's scan
 
       uint32_t cur = 0, emitted = 0;
       if (mode == 1 || mode == 2) {
@@ -419,6 +471,8 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
           if (e.stop) break;
           if (!e.n) continue;
           uint32_t task = task0, cm_off = cm0;
+          const GtResult *gr = (k == 0 && final0) ? &g0 : nullptr;
+          GtResult r = GtResult{};
           if (ns > 0 && k > 0) {
             task = task_base + tasks_used;
             // Streaming path, a line k_stream kept as a list of its few non-reference samples: the same entries gave
@@ -427,8 +481,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
             bool resolved = false;
             if (a.fused && !deferred && cm0 != BVCF_NO_CMAP && (cm0 & 1u) && task < a.max_tasks) {
               const uint32_t kmax = ((cm0 >> 1) & 7u) + 1u;
-              const GtResult first = a.results[line];
-              GtResult r;
+              const GtResult first = g0;
               r.ac = 0;
               r.an = first.an;
               r.n_het = r.n_hom = 0;
@@ -455,6 +508,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
               if (resolved) {
                 a.results[task] = r;
                 put_task(a, task, line, 0, cend, cend, BVCF_NO_CMAP);  // nothing to scan
+                gr = &r;
               }
             }
             if (!resolved) {
@@ -482,11 +536,13 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
               for (uint32_t i = 0; i < c.ref.len; i++) {
                 const uint8_t rb = hb[c.ref.off + i], ab = hb[t.off + i];
                 if (rb == ab) continue;
-                write_allele(a, slot(emitted + j), line, k, e, c.int_pos + (long long)i, rb, ab, stype, task, cm_off);
+                write_allele(a, slot(emitted + j), line, k, e, c.int_pos + (long long)i, rb, ab, stype, task, cm_off, gr);
+                if (a.fused && ns > 0 && !gr) to_finish(0x80000000u | slot(emitted + j));
                 j++;
               }
             } else {
-              write_allele(a, slot(emitted), line, k, e, e.pos, e.ref, e.alt_base, stype, task, cm_off);
+              write_allele(a, slot(emitted), line, k, e, e.pos, e.ref, e.alt_base, stype, task, cm_off, gr);
+              if (a.fused && ns > 0 && !gr) to_finish(0x80000000u | slot(emitted));
             }
           }
           emitted += e.n;
@@ -505,7 +561,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
       else if (fits)
         n_rec = emitted;
       n_fields = 0;  // settled by k_finish from the scan when there are samples
-      if (ns == 0) n_fields = a.n_header;
+      if (ns == 0 || final0) n_fields = a.n_header;  // (k_stream only lists the lines its regular scan accepted: ns sample fields)
     }
 
     HSTAMP(4);
@@ -552,6 +608,39 @@ __global__ __launch_bounds__(kWgThreads) void k_finish(KernelArgs a) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nthreads = gridDim.x * blockDim.x;
   if (a.n_samples == 0) return;
+  if (a.fused) {
+    // streaming path: k_head completed everything that did not wait for k_gt; the rest is on its work list
+    const uint32_t n_items = min(a.counters->n_finish, a.max_lines + a.max_alleles);
+    for (uint32_t w = tid; w < n_items; w += nthreads) {
+      const uint32_t item = a.finish_items[w];
+      if (item & 0x80000000u) {
+        const uint32_t i = item & 0x7FFFFFFFu;
+        if (i >= n_alleles) continue;
+        bvcf_allele *r = &a.alleles[i];
+        const uint32_t t = r->gt_task;
+        if (t >= n_tasks) continue;
+        const GtResult g = a.results[t];
+        r->ac = g.ac;
+        r->an = g.an;
+        r->n_het = g.n_het;
+        r->n_hom = g.n_hom;
+        r->n_miss = g.n_miss;
+      } else {
+        if (item >= n_lines) continue;
+        bvcf_line *L = &a.lines[item];
+        const uint32_t st = L->status;
+        if (st != BVCF_LINE_OK && st != BVCF_LINE_NOALLELE) continue;
+        if (L->gt_task >= n_tasks) continue;
+        const uint32_t nf = 9u + a.results[L->gt_task].n_fields;
+        L->n_fields = nf;
+        if (nf != a.n_header) {
+          L->status = BVCF_LINE_FIELDS;
+          L->n_rec = 0;
+        }
+      }
+    }
+    return;
+  }
   for (uint32_t i = tid; i < n_lines; i += nthreads) {
     bvcf_line *L = &a.lines[i];
     const uint32_t st = L->status;

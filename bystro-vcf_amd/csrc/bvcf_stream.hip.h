@@ -81,7 +81,9 @@ __device__ __forceinline__ uint32_t head_window(const KernelArgs &a, u32x4 v, ui
 // The same for a 256 B window held by lanes 0..15 (the prefetched head of the next line): a DPP row
 // scan replaces the 64-lane shuffle scan, and a terminator anywhere in the window simply declines
 // (returns kNone: such a line is shorter than 256 B and goes through the general head scan).
-__device__ __forceinline__ uint32_t head_window16(const KernelArgs &a, u32x4 v, uint32_t start) {
+// *mt_out: the lane's TAB mask (lanes 0..15 cover the window, 16 bytes each; bytes before `start` count as no TAB):
+// handed to k_head with the line so that it does not tokenise the head again
+__device__ __forceinline__ uint32_t head_window16(const KernelArgs &a, u32x4 v, uint32_t start, uint32_t *mt_out) {
   const int lane = lane_id();
   const uint32_t need = 9;
   // the window was loaded from the dword at or before `start`: blank the bytes of the previous line
@@ -94,6 +96,7 @@ __device__ __forceinline__ uint32_t head_window16(const KernelArgs &a, u32x4 v, 
   const uint32_t eol_any = (zero_bytes(v.x ^ e4) | zero_bytes(v.y ^ e4) | zero_bytes(v.z ^ e4) | zero_bytes(v.w ^ e4));
   if (__ballot(eol_any != 0 && lane < 16)) return kNone;
   const uint32_t mt = eq_mask16(v, '\t') & valid;
+  *mt_out = mt;
   const uint32_t cnt = __popc(mt);
   // inclusive scan inside the row of 16 lanes: row_shr:1,2,4,8 with zero fill
   uint32_t x = cnt;
@@ -207,7 +210,9 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
     return cmap_of(a, cm_next, true);
   };
   // list a line (in input order) in the tile it starts in
-  auto commit = [&](uint32_t ls, uint32_t cend, const GtStats &st, bool deferred, uint32_t cm_off) {
+  // bits_ok: `bits` is the TAB mask of the line's head window (head_window16), one 16-bit piece per lane 0..15
+  auto commit = [&](uint32_t ls, uint32_t cend, const GtStats &st, bool deferred, uint32_t cm_off, bool bits_ok = false,
+                    uint32_t bits = 0u) {
     // (a deferred line gets its class map with its k_gt task, not here)
     while (ls >= (tile + 1) * T) {  // ls moved into a later tile of the run
       if (lane == 0) a.census[tile] = n_local;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
     if (lane == 0) {
       StreamEntry en;
       en.ls = ls;
-      en.len = cend - ls;
+      en.len = (cend - ls) | (bits_ok ? kHasHeadBits : 0u);
       en.ac = st.ac;
       en.an = st.an;
       en.n_het = st.n_het;
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
       en.cmap_off = cm_off;
       a.entries[(size_t)tile * a.tile_quota + n_local] = en;
     }
+    if (bits_ok && lane < 16) a.head_bits[((size_t)tile * a.tile_quota + n_local) * 16u + (uint32_t)lane] = (uint16_t)bits;
     n_local++;
     if (maps && !deferred) cm_next++;
   };
@@ -283,6 +289,8 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
         uint32_t pA = p, sA = s_begin, peA = (uint32_t)pred;
         u32x4 va[kPipeChunks];
         u32x4 hv = {0u, 0u, 0u, 0u};
+        uint32_t mtA = 0, mtB = 0;  // head TAB masks of A (known once A came through the loop as B) and of B
+        bool bitsA = false;
         auto head_at = [&](uint32_t start) -> u32x4 {  // 256 B from the dword at or before `start`, four times over
           return *reinterpret_cast<const u32x4_u *>(a.buf + min((start & ~3u) + 16u * (lane & 15), cap_off));
         };
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           uint32_t sB = 0, peB = 0;
           bool b_ok = false;
           if (hv_ok) {
-            const uint32_t t9 = head_window16(a, hv, peA + 1u);
+            const uint32_t t9 = head_window16(a, hv, peA + 1u, &mtB);
             if (t9 != kNone) {
               sB = t9 + 1;
               const unsigned long long pb = (unsigned long long)sB + 4ull * ns - 1ull;
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           seen++;
           // (offsets are multiples of 16.  Bit 0 tells k_head that the slot holds a list, BVCF_ALLELE_CMAP_SPARSE;
           // bits 1-3 = kmax - 1: the slot also holds the lists of ALT #2..#kmax, and no sample carries a higher one)
-          commit(pA, peA, st, false, kmax ? cmA | 1u | ((kmax - 1u) << 1) : cmA);
+          commit(pA, peA, st, false, kmax ? cmA | 1u | ((kmax - 1u) << 1) : cmA, bitsA, mtA);
           p = peA + 1u;
           if (!b_ok) {
             s_begin = kNone;  // nothing pending: rediscover from p
@@ -365,6 +373,8 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           sA = sB;
           peA = peB;
           hv_ok = hvc_ok;
+          mtA = mtB;
+          bitsA = true;
           STAMP(4);
         }
       };
@@ -446,8 +456,14 @@ __global__ __launch_bounds__(kWgThreads) void k_order(KernelArgs a) {
     if (g >= a.max_lines) continue;
     const StreamEntry en = a.entries[i];
     a.line_off[g] = en.ls;
-    a.line_len[g] = en.len;
+    a.line_len[g] = en.len;  // (bit 31: line_bits[g] is valid)
     a.line_cmap[g] = en.cmap_off;
+    if (en.len & kHasHeadBits) {
+      const u32x4 *src = reinterpret_cast<const u32x4 *>(a.head_bits + (size_t)i * 16u);
+      u32x4 *dst = reinterpret_cast<u32x4 *>(a.line_bits + (size_t)g * 8u);
+      dst[0] = src[0];
+      dst[1] = src[1];
+    }
     if (g < a.max_tasks) {
       GtResult r;
       r.ac = en.ac;
