@@ -107,7 +107,7 @@ struct KernelArgs {
   uint32_t *line_cmap;   // [max_lines] class map of ALT #1
   uint16_t *head_bits;   // [n_tiles * tile_quota][16] TAB mask per 16 bytes of a line's 256-byte head window (k_stream)
   uint32_t *line_bits;   // [max_lines][8] the same, in input order (k_order)
-  uint32_t *finish_items;// [max_lines + max_alleles] line index, or 0x80000000 | allele slot, that k_finish settles
+  uint32_t *finish_items;// [max_lines + max_alleles] streaming path: the lines k_finish settles (verdict + record counts)
 };
 constexpr uint32_t kHasHeadBits = 0x80000000u;
 

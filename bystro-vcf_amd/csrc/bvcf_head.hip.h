@@ -138,8 +138,8 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
   __shared__ uint32_t s_tab[kLinesPerStep * kTabRow];
   __shared__ uint32_t s_ls[kLinesPerStep], s_len[kLinesPerStep], s_found[kLinesPerStep], s_staged[kLinesPerStep],
       s_extra[kLinesPerStep];
-  __shared__ uint32_t s_wave[kWavesPerWg][2];
-  __shared__ uint32_t s_base[3];
+  __shared__ uint32_t s_wave[kWavesPerWg][3];
+  __shared__ uint32_t s_base[4];
   __shared__ FilterTable s_ft;  // FILTER sets
   {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(a.filters);
@@ -384,20 +384,26 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     // that k_gt only has to visit the slots past n_lines there
     const bool deferred = eval && a.fused && ns > 0 && line < a.max_tasks && a.results[line].n_fields == kDeferred;
     const uint32_t want_task = ((eval && ns > 0 && mode == 2) ? n_commas : 0u) + (deferred ? 1u : 0u);
+    // streaming path: a line with an extra task slot (ALT #1 left to k_gt, or further ALT indices) goes on k_finish's
+    // work list; everything else is complete when this kernel ends
+    const unsigned long long fin_mask = __ballot(a.fused && want_task > 0);
     uint32_t wt_rec, wt_task;
     uint32_t extra_base = wave_excl_scan(want_rec, &wt_rec);
     uint32_t task_base = wave_excl_scan(want_task, &wt_task);
+    uint32_t fin_at = __builtin_amdgcn_mbcnt_hi((uint32_t)(fin_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fin_mask, 0u));
     if (lane == 0) {
       s_wave[w][0] = wt_rec;
       s_wave[w][1] = wt_task;
+      s_wave[w][2] = (uint32_t)__popcll(fin_mask);
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 3) {
       uint32_t sum = 0;
       for (int k = 0; k < kWavesPerWg; k++) sum += s_wave[k][threadIdx.x];
       uint32_t got = 0;
-      if (sum) got = atomicAdd(threadIdx.x == 0 ? &a.counters->n_alleles : &a.counters->n_tasks, sum);
-      s_base[threadIdx.x] = got;
+      if (sum)
+        got = atomicAdd(threadIdx.x == 0 ? &a.counters->n_alleles : (threadIdx.x == 1 ? &a.counters->n_tasks : &a.counters->n_finish), sum);
+      s_base[threadIdx.x == 2 ? 3 : threadIdx.x] = got;
       // streaming path: the class maps of the extra tasks come from the same cursor k_stream used
       if (threadIdx.x == 1) s_base[2] = (sum && a.fused && maps) ? atomicAdd(&a.counters->cmap_maps, sum) : 0u;
     }
@@ -406,7 +412,9 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     for (int k = 0; k < w; k++) {
       extra_base += s_wave[k][0];
       task_rank += s_wave[k][1];
+      fin_at += s_wave[k][2];
     }
+    if (a.fused && want_task > 0 && s_base[3] + fin_at < a.max_lines + a.max_alleles) a.finish_items[s_base[3] + fin_at] = line;
     extra_base += n_lines + s_base[0];
     task_base = n_lines + s_base[1] + task_rank;
     const uint32_t map_base = a.fused ? s_base[2] + task_rank : task_base;
@@ -442,16 +450,11 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
       }
       first_task = task0;
       // Streaming path: the counts of ALT #1 of a line k_stream scanned are final (results[line]), as are those of the
-      // further ALT indices resolved from class lists below: such records are complete here.  What still depends on
-      // k_gt goes on k_finish's work list.
+      // further ALT indices resolved from class lists below: such records are complete here.  A line with records that
+      // still depend on k_gt is on k_finish's work list (above).
       const bool final0 = a.fused && ns > 0 && !deferred && line < a.max_tasks;
       GtResult g0 = GtResult{};
       if (final0) g0 = a.results[line];
-      auto to_finish = [&](uint32_t item) {
-        const uint32_t at = atomicAdd(&a.counters->n_finish, 1u);
-        if (at < a.max_lines + a.max_alleles) a.finish_items[at] = item;
-      };
-      if (a.fused && ns > 0 && deferred) to_finish(line);  // its field count comes from k_gt's scan
 
       uint32_t cur = 0, emitted = 0;
       if (mode == 1 || mode == 2) {
@@ -537,12 +540,10 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
                 const uint8_t rb = hb[c.ref.off + i], ab = hb[t.off + i];
                 if (rb == ab) continue;
                 write_allele(a, slot(emitted + j), line, k, e, c.int_pos + (long long)i, rb, ab, stype, task, cm_off, gr);
-                if (a.fused && ns > 0 && !gr) to_finish(0x80000000u | slot(emitted + j));
                 j++;
               }
             } else {
               write_allele(a, slot(emitted), line, k, e, e.pos, e.ref, e.alt_base, stype, task, cm_off, gr);
-              if (a.fused && ns > 0 && !gr) to_finish(0x80000000u | slot(emitted));
             }
           }
           emitted += e.n;
@@ -612,10 +613,25 @@ __global__ __launch_bounds__(kWgThreads) void k_finish(KernelArgs a) {
     // streaming path: k_head completed everything that did not wait for k_gt; the rest is on its work list
     const uint32_t n_items = min(a.counters->n_finish, a.max_lines + a.max_alleles);
     for (uint32_t w = tid; w < n_items; w += nthreads) {
-      const uint32_t item = a.finish_items[w];
-      if (item & 0x80000000u) {
-        const uint32_t i = item & 0x7FFFFFFFu;
-        if (i >= n_alleles) continue;
+      const uint32_t li = a.finish_items[w];
+      if (li >= n_lines) continue;
+      bvcf_line *L = &a.lines[li];
+      const uint32_t st = L->status;
+      if (st == BVCF_LINE_OK || st == BVCF_LINE_NOALLELE) {
+        if (L->gt_task < n_tasks) {
+          const uint32_t nf = 9u + a.results[L->gt_task].n_fields;
+          L->n_fields = nf;
+          if (nf != a.n_header) {
+            L->status = BVCF_LINE_FIELDS;
+            L->n_rec = 0;
+          }
+        }
+      }
+      // the line's records (slot li, then rec_first ..): counts from the scan each one names
+      const uint32_t n_rec = L->n_rec, rec_first = L->rec_first;
+      for (uint32_t j = 0; j < n_rec; j++) {
+        const uint32_t i = j ? rec_first + j - 1u : li;
+        if (i >= n_alleles) break;
         bvcf_allele *r = &a.alleles[i];
         const uint32_t t = r->gt_task;
         if (t >= n_tasks) continue;
@@ -625,18 +641,6 @@ __global__ __launch_bounds__(kWgThreads) void k_finish(KernelArgs a) {
         r->n_het = g.n_het;
         r->n_hom = g.n_hom;
         r->n_miss = g.n_miss;
-      } else {
-        if (item >= n_lines) continue;
-        bvcf_line *L = &a.lines[item];
-        const uint32_t st = L->status;
-        if (st != BVCF_LINE_OK && st != BVCF_LINE_NOALLELE) continue;
-        if (L->gt_task >= n_tasks) continue;
-        const uint32_t nf = 9u + a.results[L->gt_task].n_fields;
-        L->n_fields = nf;
-        if (nf != a.n_header) {
-          L->status = BVCF_LINE_FIELDS;
-          L->n_rec = 0;
-        }
       }
     }
     return;
