@@ -42,7 +42,7 @@ BENCH_EXPORTS = ["bvcf_bench_device", "bvcf_bench_device_slots"]
 
 # every symbol include/bvcf.h declares
 EXPORTS = [
-    "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_alloc_pinned",
+    "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_set_sample_names", "bvcf_alloc_pinned",
     "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_counters", "bvcf_sum_counters",
     "bvcf_allreduce_counters", "bvcf_device_count", "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_free",
     "bvcf_arrow_open", "bvcf_arrow_append", "bvcf_arrow_close",
@@ -53,7 +53,7 @@ class Params(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("device", C.c_int32), ("n_header_fields", C.c_uint32),
         ("eol_chars", C.c_uint32), ("eol_byte", C.c_uint8), ("want_class_maps", C.c_uint8),
-        ("want_dosage", C.c_uint8), ("reserved0", C.c_uint8 * 1), ("allow_filter", C.c_char_p), ("exclude_filter", C.c_char_p),
+        ("want_dosage", C.c_uint8), ("want_name_lists", C.c_uint8), ("allow_filter", C.c_char_p), ("exclude_filter", C.c_char_p),
         ("max_batch_bytes", C.c_uint64), ("max_lines", C.c_uint32), ("max_alleles", C.c_uint32),
         ("cmap_bytes", C.c_uint64), ("n_slots", C.c_uint32), ("path", C.c_uint32),
     ]
@@ -79,6 +79,7 @@ class Result(C.Structure):
         ("cmap", C.c_void_p), ("need_lines", C.c_uint64), ("need_alleles", C.c_uint64),
         ("need_cmap_bytes", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32),
         ("n_lines_seen", C.c_uint64), ("dosage", C.c_void_p), ("dosage_stride", C.c_uint32), ("reserved2", C.c_uint32),
+        ("name_lists", C.c_void_p), ("names", C.c_void_p), ("n_name_bytes", C.c_uint64),
     ]
 
 
@@ -91,6 +92,7 @@ ALLELE_DTYPE = np.dtype([
     ("alt_base", "u1"), ("kind", "u1"), ("site_type", "u1"), ("trtv", "u1"), ("flags", "u1"), ("pad", "u1", (2,)),
     ("gt_task", "<u4"), ("pad2", "<u4")])
 ERR_DTYPE = np.dtype([("line", "<u4"), ("alt_no", "<u4"), ("code", "<u4"), ("pad", "<u4")])
+NAMES_DTYPE = np.dtype([("off", "<u4", (3,)), ("len", "<u4", (3,))])
 assert LINE_DTYPE.itemsize == 64 and ALLELE_DTYPE.itemsize == 64 and ERR_DTYPE.itemsize == 16
 
 lib.bvcf_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Params)]
@@ -101,6 +103,7 @@ lib.bvcf_last_error.argtypes = [C.c_void_p]
 lib.bvcf_last_error.restype = C.c_char_p
 lib.bvcf_version.restype = C.c_char_p
 lib.bvcf_reserve.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+lib.bvcf_set_sample_names.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p]
 lib.bvcf_alloc_pinned.argtypes = [C.c_size_t]
 lib.bvcf_alloc_pinned.restype = C.c_void_p
 lib.bvcf_free_pinned.argtypes = [C.c_void_p]
@@ -244,6 +247,9 @@ class Batch:
         self.errs = arr(r.errs, r.n_errs, ERR_DTYPE)
         self.cmap = arr(r.cmap, r.n_cmap_bytes, np.dtype("u1"))
         # want_dosage: one int8 row per alleles[] slot (rows of slots without a record hold garbage)
+        # want_name_lists: (off[3], len[3]) per alleles[] slot into the text arena `names`
+        self.name_lists = arr(r.name_lists, r.n_alleles, NAMES_DTYPE) if r.name_lists else None
+        self.names = C.string_at(r.names, r.n_name_bytes) if r.names and r.n_name_bytes else b""
         self.dosage = None
         if r.dosage and r.n_alleles:
             self.dosage = arr(r.dosage, r.n_alleles * r.dosage_stride, np.dtype("i1")).reshape(r.n_alleles, r.dosage_stride)
@@ -262,6 +268,11 @@ class Batch:
         L = self.lines[i]
         n = int(L["n_rec"])
         return [] if n == 0 else [i] + [int(L["rec_first"]) + j - 1 for j in range(1, n)]
+
+    def name_list(self, slot, q):
+        """list q (0 het, 1 hom, 2 missing) of alleles[slot] as the device rendered it"""
+        nl = self.name_lists[slot]
+        return self.names[int(nl["off"][q]):int(nl["off"][q]) + int(nl["len"][q])]
 
     def classes(self, allele_row):
         """per-sample class codes (0 none, 1 het, 2 hom, 3 missing) of one allele record"""
@@ -282,7 +293,7 @@ class Ctx:
 
     def __init__(self, n_header_fields, allow="PASS,.", exclude="", device=0, eol_chars=1, eol_byte=b"\n",
                  max_batch_bytes=0, max_lines=0, max_alleles=0, cmap_bytes=0, n_slots=0, want_class_maps=True,
-                 path=0, want_dosage=False):
+                 path=0, want_dosage=False, sample_names=None, delimiter=";"):
         p = Params()
         p.abi_version = ABI_VERSION
         p.device = device
@@ -299,10 +310,16 @@ class Ctx:
         p.cmap_bytes = cmap_bytes
         p.n_slots = n_slots
         p.path = path
+        p.want_name_lists = int(sample_names is not None)
         self.h = C.c_void_p()
         rc = lib.bvcf_create(C.byref(self.h), C.byref(p))
         if rc:
             raise BvcfError(rc, lib.bvcf_last_error(None).decode())
+        if sample_names is not None:  # device-side rendering of the het / hom / missing name lists
+            enc = [x.encode() if isinstance(x, str) else x for x in sample_names]
+            ptrs = (C.c_char_p * max(len(enc), 1))(*enc)
+            lens = (C.c_uint32 * max(len(enc), 1))(*[len(x) for x in enc])
+            self._check(lib.bvcf_set_sample_names(self.h, ptrs, lens, len(enc), delimiter.encode()))
 
     def close(self):
         if self.h:

@@ -38,6 +38,13 @@ struct Slot {
   StreamEntry *d_entries = nullptr;
   uint32_t *d_line_len = nullptr, *d_line_cmap = nullptr, *d_line_bits = nullptr, *d_finish_items = nullptr;
   uint16_t *d_head_bits = nullptr;
+  // device-side name lists (want_name_lists)
+  bvcf_names *d_name_lists = nullptr, *h_name_lists = nullptr;
+  uint32_t *d_name_tot = nullptr;
+  uint8_t *d_names = nullptr;
+  char *h_names = nullptr;
+  unsigned long long *d_name_total = nullptr, *h_name_total = nullptr;
+  uint64_t cap_names = 0;
   BatchCounters *d_counters = nullptr;
   // pinned host
   BatchCounters *h_counters = nullptr;
@@ -52,6 +59,7 @@ struct Slot {
   bool busy = false;
   uint64_t seq = 0;
   size_t nbytes = 0;
+  const uint8_t *src = nullptr;  // the device text of the batch in flight
 };
 
 }  // namespace
@@ -63,6 +71,10 @@ struct bvcf_ctx {
   int gt_grid = 0, stream_grid = 0;
   bool fused = false;
   bool wide = false;  // census path with k_gt_wide in front of k_gt (see kWideSamples)
+  bool names_on = false;  // want_name_lists and bvcf_set_sample_names called: the chain ends with the k_name_* kernels
+  uint32_t *d_name_off = nullptr;
+  uint8_t *d_name_text = nullptr;
+  NameTable name_table{};
   bool sites = false; // no sample columns: k_sites after the census instead of k_scatter_eol + k_head + k_finish
   int sites_grid = 0;
   uint32_t win_bytes = 64u << 10;  // wide: bytes of a line's sample region per wave of the split general scan
@@ -142,6 +154,13 @@ void free_slot(Slot &s) {
   hipFree(s.d_line_bits);
   hipFree(s.d_finish_items);
   hipFree(s.d_head_bits);
+  hipFree(s.d_name_lists);
+  hipFree(s.d_name_tot);
+  hipFree(s.d_names);
+  hipFree(s.d_name_total);
+  hipHostFree(s.h_name_lists);
+  hipHostFree(s.h_names);
+  hipHostFree(s.h_name_total);
   hipFree(s.d_counters);
   hipHostFree(s.h_counters);
   hipHostFree(s.h_lines);
@@ -154,6 +173,46 @@ void free_slot(Slot &s) {
   if (s.ev_ctr) hipEventDestroy(s.ev_ctr);
   if (s.stream) hipStreamDestroy(s.stream);
   s = Slot{};
+}
+
+// the name-list buffers of a slot: lists / totals follow max_alleles, the text arena keeps its size (collect grows it)
+int alloc_names(bvcf_ctx *c, Slot &s, uint64_t want_bytes) {
+  if (!c->names_on) return BVCF_OK;
+  hipFree(s.d_name_lists);
+  hipFree(s.d_name_tot);
+  hipHostFree(s.h_name_lists);
+  s.d_name_lists = nullptr;
+  s.d_name_tot = nullptr;
+  s.h_name_lists = nullptr;
+  HIP_TRY(c, hipMalloc(&s.d_name_lists, c->max_alleles * sizeof(bvcf_names)));
+  HIP_TRY(c, hipMalloc(&s.d_name_tot, (c->max_alleles + 1) * sizeof(uint32_t)));
+  HIP_TRY(c, hipHostMalloc(&s.h_name_lists, c->max_alleles * sizeof(bvcf_names), hipHostMallocDefault));
+  if (!s.d_name_total) {
+    HIP_TRY(c, hipMalloc(&s.d_name_total, sizeof(unsigned long long)));
+    HIP_TRY(c, hipHostMalloc(&s.h_name_total, sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  if (want_bytes > s.cap_names) {
+    hipFree(s.d_names);
+    hipHostFree(s.h_names);
+    s.d_names = nullptr;
+    s.h_names = nullptr;
+    s.cap_names = 0;
+    HIP_TRY(c, hipMalloc(&s.d_names, want_bytes + 64));
+    HIP_TRY(c, hipHostMalloc(&s.h_names, want_bytes + 64, hipHostMallocDefault));
+    s.cap_names = want_bytes;
+  }
+  return BVCF_OK;
+}
+
+NameArgs make_name_args(bvcf_ctx *c, Slot &s) {
+  NameArgs na{};
+  na.nt = c->name_table;
+  na.lists = s.d_name_lists;
+  na.tot = s.d_name_tot;
+  na.out = s.d_names;
+  na.cap = s.cap_names;
+  na.total = s.d_name_total;
+  return na;
 }
 
 // (re)allocate the result arrays of a slot for the ctx's current capacities
@@ -220,6 +279,10 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   if (c->dosage_stride) {
     HIP_TRY(c, hipMalloc(&s.d_dosage, c->max_alleles * c->dosage_stride + 64));
     HIP_TRY(c, hipHostMalloc(&s.h_dosage, c->max_alleles * c->dosage_stride + 64, hipHostMallocDefault));
+  }
+  {
+    const int rc = alloc_names(c, s, std::max<uint64_t>(s.cap_names, c->p.max_batch_bytes / 2 + (1u << 20)));
+    if (rc) return rc;
   }
   s.cap_lines = c->max_lines;
   s.cap_alleles = c->max_alleles;
@@ -295,6 +358,12 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
 
 // the kernel chain for one resident block; ev_gt0 / ev_gt1 (optional) bracket the dominant kernel
 // (k_gt on the census path, k_stream on the streaming path)
+void launch_names(bvcf_ctx *c, const KernelArgs &a, const NameArgs &na, hipStream_t st) {
+  hipLaunchKernelGGL(k_name_len, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a, na);
+  hipLaunchKernelGGL(k_name_scan, dim3(1), dim3(1024), 0, st, a, na);
+  hipLaunchKernelGGL(k_name_write, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a, na);
+}
+
 void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t ev_gt0, hipEvent_t ev_gt1) {
   if (a.fused) {
     const uint32_t n_groups = (a.n_tiles + kScanGroup - 1) / kScanGroup;
@@ -380,9 +449,14 @@ int submit_common(bvcf_ctx *c, const uint8_t *host_block, const void *dev_block,
   KernelArgs a = make_args(c, s, src, nbytes);
   HIP_TRY(c, hipEventRecord(s.ev_k0, s.stream));
   launch_chain(c, a, s.stream, nullptr, nullptr);
+  const bool names = c->names_on && s.d_name_lists;
+  if (names) launch_names(c, a, make_name_args(c, s), s.stream);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(s.ev_k1, s.stream));
   HIP_TRY(c, hipMemcpyAsync(s.h_counters, s.d_counters, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.stream));
+  if (names)
+    HIP_TRY(c, hipMemcpyAsync(s.h_name_total, s.d_name_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
+  s.src = src;
   HIP_TRY(c, hipEventRecord(s.ev_ctr, s.stream));
   s.busy = true;
   s.seq = seq;
@@ -416,6 +490,8 @@ void bvcf_destroy(bvcf_ctx *c) {
   hipSetDevice(c->device);
   for (auto &s : c->slots) free_slot(s);
   hipFree(c->d_filters);
+  hipFree(c->d_name_off);
+  hipFree(c->d_name_text);
   delete c;
 }
 
@@ -541,6 +617,47 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   return BVCF_OK;
 }
 
+int bvcf_set_sample_names(bvcf_ctx *c, const char *const *names, const uint32_t *lens, uint32_t n, const char *delimiter) {
+  if (!c || (n && (!names || !lens)) || !delimiter) return BVCF_E_ARG;
+  if (c->in_flight) {
+    c->err = "bvcf_set_sample_names with batches in flight";
+    return BVCF_E_BUSY;
+  }
+  const size_t dl = strlen(delimiter);
+  if (n != c->n_samples || dl > sizeof c->name_table.delim) {
+    c->err = "bvcf_set_sample_names: sample count differs from the ctx's, or the delimiter is longer than 16 bytes";
+    return BVCF_E_ARG;
+  }
+  if (!c->p.want_name_lists || !c->p.want_class_maps || !n) return BVCF_OK;  // nothing to render
+  std::vector<uint32_t> off(n + 1);
+  std::string text;
+  for (uint32_t i = 0; i < n; i++) {
+    off[i] = (uint32_t)text.size();
+    text.append(names[i], lens[i]);
+  }
+  off[n] = (uint32_t)text.size();
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipFree(c->d_name_off);
+  hipFree(c->d_name_text);
+  c->d_name_off = nullptr;
+  c->d_name_text = nullptr;
+  HIP_TRY(c, hipMalloc(&c->d_name_off, off.size() * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&c->d_name_text, text.size() + 16));
+  HIP_TRY(c, hipMemcpy(c->d_name_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_name_text, text.data(), text.size(), hipMemcpyHostToDevice));
+  c->name_table.off = c->d_name_off;
+  c->name_table.text = c->d_name_text;
+  c->name_table.delim_len = (uint32_t)dl;
+  memset(c->name_table.delim, 0, sizeof c->name_table.delim);
+  memcpy(c->name_table.delim, delimiter, dl);
+  c->names_on = true;
+  for (auto &s : c->slots) {
+    const int rc = alloc_names(c, s, std::max<uint64_t>(s.cap_names, c->p.max_batch_bytes / 2 + (1u << 20)));
+    if (rc) return rc;
+  }
+  return BVCF_OK;
+}
+
 int bvcf_reserve(bvcf_ctx *c, uint64_t lines, uint64_t alleles, uint64_t cmap_bytes) {
   if (!c) return BVCF_E_ARG;
   if (c->in_flight) {
@@ -628,6 +745,28 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     HIP_TRY(c, hipMemcpyAsync(s.h_cmap, s.d_cmap, cmap_bytes, hipMemcpyDeviceToHost, s.stream));
   if (c->dosage_stride && n_alleles)
     HIP_TRY(c, hipMemcpyAsync(s.h_dosage, s.d_dosage, n_alleles * c->dosage_stride, hipMemcpyDeviceToHost, s.stream));
+  const bool names = c->names_on && s.d_name_lists;
+  uint64_t name_bytes = 0;
+  if (names && n_alleles) {
+    name_bytes = *s.h_name_total;
+    if (name_bytes >= 0xFFFFFFF0ull) {
+      c->err = "the sample-name lists of one batch pass 4 GiB: submit smaller blocks";
+      release();
+      return BVCF_E_TOO_BIG;
+    }
+    if (name_bytes > s.cap_names) {
+      // the arena was too small and k_name_write wrote nothing: grow it and write again (the offsets stand)
+      const int rc = alloc_names(c, s, name_bytes + name_bytes / 4 + (1u << 20));
+      if (rc) {
+        release();
+        return rc;
+      }
+      KernelArgs a = make_args(c, s, s.src, s.nbytes);
+      hipLaunchKernelGGL(k_name_write, dim3(c->n_cu * 4), dim3(kWgThreads), 0, s.stream, a, make_name_args(c, s));
+    }
+    HIP_TRY(c, hipMemcpyAsync(s.h_name_lists, s.d_name_lists, n_alleles * sizeof(bvcf_names), hipMemcpyDeviceToHost, s.stream));
+    if (name_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_names, s.d_names, name_bytes, hipMemcpyDeviceToHost, s.stream));
+  }
   e = hipStreamSynchronize(s.stream);
   if (e != hipSuccess) {
     c->err = std::string("result copy failed: ") + hipGetErrorString(e);
@@ -653,6 +792,9 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   r->cmap = s.h_cmap;
   r->dosage = c->dosage_stride ? s.h_dosage : nullptr;
   r->dosage_stride = c->dosage_stride;
+  r->name_lists = names ? s.h_name_lists : nullptr;
+  r->names = names ? s.h_names : nullptr;
+  r->n_name_bytes = name_bytes;
 
   uint64_t ok = 0, ac0 = 0, recs = 0;
   for (uint32_t i = 0; i < ctr.n_lines; i++) {

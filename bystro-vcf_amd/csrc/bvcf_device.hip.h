@@ -29,6 +29,9 @@
 //   k_order        tile-local line entries -> input-ordered line_off / line_len / results
 // after which k_head, k_gt (further ALT indices only) and k_finish run as above.
 //
+//   (bvcf_params.want_name_lists, after k_finish: k_name_len / k_name_scan / k_name_write render the het / hom / missing
+//    sample-name lists of every output allele as text -- main.go:612-656 -- see bvcf_names.hip.h)
+//
 // Sites-only input (no sample columns): k_count_eol + k_scan_* as above, then ONE pass,
 //   k_sites        a wave walks a run of 8 KiB windows: text ring + TAB bit ring in LDS, line ends into a FIFO, then
 //                  one lane per line for strings.Split / linePasses / getAlleles / trTv and the records
@@ -50,3 +53,4 @@
 #include "bvcf_stream.hip.h"
 #include "bvcf_head.hip.h"
 #include "bvcf_sites.hip.h"
+#include "bvcf_names.hip.h"

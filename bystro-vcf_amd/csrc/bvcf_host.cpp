@@ -220,9 +220,11 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
     const char *row = (const char *)block + L.off;
     auto fstart = [&](int i) -> uint32_t { return i ? L.fend[i - 1] + 1 : 0; };
     for (uint32_t k = 0; k < L.n_rec; k++) {
-      const bvcf_allele &A = r->alleles[k ? L.rec_first + k - 1 : li];
+      const uint32_t slot = k ? L.rec_first + k - 1 : li;
+      const bvcf_allele &A = r->alleles[slot];
       // main.go:555-560: with samples, an allele nobody carries is skipped
       if (ns > 0 && A.ac == 0) continue;
+      const bvcf_names *NL = r->name_lists ? &r->name_lists[slot] : nullptr;
       // main.go:570-574
       const uint32_t nchrom = L.fend[0];
       if (nchrom < 4 || row[0] != 'c') out.append("chr");
@@ -265,7 +267,10 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
           out.append(empty);
           out.append("\t0");
         } else {
-          join_class(out, cm, (A.flags & BVCF_ALLELE_CMAP_SPARSE) != 0, ns, lists[q].cls, lists[q].n, nm);
+          if (NL)  // rendered on the device (bvcf_params.want_name_lists): one copy per list
+            out.append(r->names + NL->off[q], NL->len[q]);
+          else
+            join_class(out, cm, (A.flags & BVCF_ALLELE_CMAP_SPARSE) != 0, ns, lists[q].cls, lists[q].n, nm);
           out.push_back('\t');
           if (rt)
             rt->append(out, lists[q].n, lists[q].denom, lists[q].den);
@@ -577,6 +582,13 @@ int prepare_run(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t 
   p.eol_byte = R.pre.eol_byte;
   R.want_rows = !R.cfg->no_out;
   p.want_class_maps = R.want_rows;  // needsLabels, main.go:502
+  // the sample-name lists of the rows come off the device as text unless BVCF_DEVICE_NAMES=0 (then the
+  // formatter joins the names itself from the class maps) or the delimiter does not fit the device's 16 bytes
+  {
+    const char *e = getenv("BVCF_DEVICE_NAMES");
+    p.want_name_lists = R.want_rows && R.pre.header.size() > 9 && !(e && *e == '0') &&
+                        strlen(or_default(R.cfg->field_delimiter, ";")) <= 16;
+  }
   p.want_dosage = R.cfg->dosage_path && *R.cfg->dosage_path && R.pre.header.size() > 9;
   p.allow_filter = R.cfg->allow_filter;
   p.exclude_filter = R.cfg->exclude_filter;
@@ -633,8 +645,20 @@ int prepare_run(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t 
 int create_ctx(const Run &R, int device, bvcf_ctx **ctx, std::string *msg) {
   bvcf_params p = R.params;
   p.device = device;
-  const int rc = bvcf_create(ctx, &p);
-  if (rc) *msg = std::string("bvcf_create: ") + bvcf_last_error(nullptr);
+  int rc = bvcf_create(ctx, &p);
+  if (rc) {
+    *msg = std::string("bvcf_create: ") + bvcf_last_error(nullptr);
+    return rc;
+  }
+  if (p.want_name_lists) {
+    rc = bvcf_set_sample_names(*ctx, R.name_ptr.data(), R.name_len.data(), (uint32_t)R.name_ptr.size(),
+                               or_default(R.cfg->field_delimiter, ";"));
+    if (rc) {
+      *msg = std::string("bvcf_set_sample_names: ") + bvcf_last_error(*ctx);
+      bvcf_destroy(*ctx);
+      *ctx = nullptr;
+    }
+  }
   return rc;
 }
 

@@ -103,7 +103,8 @@ typedef struct {
   uint8_t eol_byte;           /* endOfLineByte, '\n' unless the file uses lone '\r' */
   uint8_t want_class_maps;    /* needsLabels: emit the 2-bit class maps (main.go:502) */
   uint8_t want_dosage;        /* needsDosages: emit one int8 per sample per output allele (main.go:503,1069-1178) */
-  uint8_t reserved0[1];
+  uint8_t want_name_lists;    /* render the het / hom / missing sample-name lists on the device (bvcf_result.name_lists);
+                                 takes effect once bvcf_set_sample_names has been called; needs want_class_maps */
   const char *allow_filter;   /* --allowFilter text; NULL, "" or "*" = allow all (main.go:98,108-114) */
   const char *exclude_filter; /* --excludeFilter text; NULL or "" = none (main.go:99,117-123) */
   uint64_t max_batch_bytes;   /* largest block bvcf_submit accepts (0 = 64 MiB; below 4 GiB - 1 MiB: offsets are 32-bit) */
@@ -166,6 +167,14 @@ typedef struct {
   uint32_t pad;
 } bvcf_err;
 
+/* the three strings.Join(names, fieldDelimiter) of one output allele (main.go:612-656), rendered on the device:
+ * list q (0 heterozygotes, 1 homozygotes, 2 missingGenos) is names[off[q] .. off[q] + len[q]); len 0 = empty list
+ * (the caller prints emptyField).  Valid for the alleles[] slots that hold a record with ac > 0. */
+typedef struct {
+  uint32_t off[3];
+  uint32_t len[3];
+} bvcf_names;
+
 /* a collected batch.  All pointers are library-owned pinned host memory of the slot the batch ran in.  Collects fill
  * the ctx's n_slots slots in turn, so the pointers stay valid until the n_slots-th following bvcf_collect on the same
  * ctx (with n_slots = 1: the next one), or bvcf_reserve / bvcf_destroy. */
@@ -197,6 +206,10 @@ typedef struct {
   const int8_t *dosage;
   uint32_t dosage_stride;    /* n_samples rounded up to 16 */
   uint32_t reserved2;
+  /* bvcf_params.want_name_lists + bvcf_set_sample_names: name_lists[k] describes alleles[k]; NULL otherwise */
+  const bvcf_names *name_lists;
+  const char *names;
+  uint64_t n_name_bytes;
 } bvcf_result;
 
 /* ---- lifecycle ---- */
@@ -205,6 +218,11 @@ void bvcf_destroy(bvcf_ctx *ctx);
 const char *bvcf_last_error(const bvcf_ctx *ctx);
 const char *bvcf_version(void);
 int bvcf_reserve(bvcf_ctx *ctx, uint64_t lines, uint64_t alleles, uint64_t cmap_bytes);
+/* The (normalised) sample names, header fields 9.., and the --fieldDelimiter text (at most 16 bytes), for
+ * bvcf_params.want_name_lists: with them on the device, every collected batch carries the het / hom / missing name
+ * lists of its output alleles as text, and the caller's TSV assembly copies three strings per row instead
+ * of walking the class map name by name.  Call once, before the first bvcf_submit.  n must be the ctx's sample count. */
+int bvcf_set_sample_names(bvcf_ctx *ctx, const char *const *names, const uint32_t *lens, uint32_t n, const char *delimiter);
 
 /* pinned host memory for blocks handed to bvcf_submit (hipHostMalloc) */
 void *bvcf_alloc_pinned(size_t nbytes);
