@@ -175,7 +175,21 @@ void free_slot(Slot &s) {
   s = Slot{};
 }
 
-// the name-list buffers of a slot: lists / totals follow max_alleles, the text arena keeps its size (collect grows it)
+// the text arena of a slot's name lists (bvcf_collect grows it when a batch needs more)
+int alloc_name_arena(bvcf_ctx *c, Slot &s, uint64_t want_bytes) {
+  if (want_bytes <= s.cap_names) return BVCF_OK;
+  hipFree(s.d_names);
+  hipHostFree(s.h_names);
+  s.d_names = nullptr;
+  s.h_names = nullptr;
+  s.cap_names = 0;
+  HIP_TRY(c, hipMalloc(&s.d_names, want_bytes + 64));
+  HIP_TRY(c, hipHostMalloc(&s.h_names, want_bytes + 64, hipHostMallocDefault));
+  s.cap_names = want_bytes;
+  return BVCF_OK;
+}
+
+// the name-list buffers of a slot: lists / totals follow max_alleles, the text arena keeps its size
 int alloc_names(bvcf_ctx *c, Slot &s, uint64_t want_bytes) {
   if (!c->names_on) return BVCF_OK;
   hipFree(s.d_name_lists);
@@ -191,17 +205,7 @@ int alloc_names(bvcf_ctx *c, Slot &s, uint64_t want_bytes) {
     HIP_TRY(c, hipMalloc(&s.d_name_total, sizeof(unsigned long long)));
     HIP_TRY(c, hipHostMalloc(&s.h_name_total, sizeof(unsigned long long), hipHostMallocDefault));
   }
-  if (want_bytes > s.cap_names) {
-    hipFree(s.d_names);
-    hipHostFree(s.h_names);
-    s.d_names = nullptr;
-    s.h_names = nullptr;
-    s.cap_names = 0;
-    HIP_TRY(c, hipMalloc(&s.d_names, want_bytes + 64));
-    HIP_TRY(c, hipHostMalloc(&s.h_names, want_bytes + 64, hipHostMallocDefault));
-    s.cap_names = want_bytes;
-  }
-  return BVCF_OK;
+  return alloc_name_arena(c, s, want_bytes);
 }
 
 NameArgs make_name_args(bvcf_ctx *c, Slot &s) {
@@ -756,7 +760,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     }
     if (name_bytes > s.cap_names) {
       // the arena was too small and k_name_write wrote nothing: grow it and write again (the offsets stand)
-      const int rc = alloc_names(c, s, name_bytes + name_bytes / 4 + (1u << 20));
+      const int rc = alloc_name_arena(c, s, name_bytes + name_bytes / 4 + (1u << 20));
       if (rc) {
         release();
         return rc;

@@ -582,11 +582,13 @@ int prepare_run(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t 
   p.eol_byte = R.pre.eol_byte;
   R.want_rows = !R.cfg->no_out;
   p.want_class_maps = R.want_rows;  // needsLabels, main.go:502
-  // the sample-name lists of the rows come off the device as text unless BVCF_DEVICE_NAMES=0 (then the
-  // formatter joins the names itself from the class maps) or the delimiter does not fit the device's 16 bytes
+  // BVCF_DEVICE_NAMES=1: the sample-name lists of the rows come off the device as text instead of being
+  // joined by the formatter from the class maps.  Off by default: measured on the dense profile (every row a common
+  // variant, 10 KB of names per row) the text is 16 x the class maps over PCIe and the run gets slower, while the
+  // formatter's worker pool is not what a one-GPU run waits for (profiles/r02_e2e_cli_dense_*.log).
   {
     const char *e = getenv("BVCF_DEVICE_NAMES");
-    p.want_name_lists = R.want_rows && R.pre.header.size() > 9 && !(e && *e == '0') &&
+    p.want_name_lists = R.want_rows && R.pre.header.size() > 9 && e && *e == '1' &&
                         strlen(or_default(R.cfg->field_delimiter, ";")) <= 16;
   }
   p.want_dosage = R.cfg->dosage_path && *R.cfg->dosage_path && R.pre.header.size() > 9;

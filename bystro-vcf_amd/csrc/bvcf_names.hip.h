@@ -66,7 +66,26 @@ __device__ __forceinline__ uint32_t name_map_byte(const KernelArgs &a, const bvc
   return i < n_bytes ? cm[i] : 0u;
 }
 
-__global__ __launch_bounds__(kWgThreads) void k_name_len(KernelArgs a, NameArgs na) {
+constexpr uint32_t kNameLdsSamples = 4095;   // the offset table of up to this many samples is copied into LDS (16 KiB)
+constexpr uint32_t kNameLdsText = 40u << 10;  // ... and so is name text up to this size (k_name_write)
+
+// name lengths / text: from LDS when the tables fit (kLds), from memory otherwise
+template <bool kLds>
+struct NameSrc {
+  const uint32_t *off;   // LDS or global, by kLds
+  const uint8_t *text;
+  __device__ __forceinline__ uint32_t o(uint32_t s) const {
+    if (kLds) return reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((const __attribute__((address_space(3))) uint8_t *)off)[s];
+    return off[s];
+  }
+  __device__ __forceinline__ uint8_t t(uint32_t i) const {
+    if (kLds) return ((const __attribute__((address_space(3))) uint8_t *)text)[i];
+    return text[i];
+  }
+};
+
+template <bool kLds>
+__device__ __forceinline__ void k_name_len_body(const KernelArgs &a, const NameArgs &na, const NameSrc<kLds> &ns_) {
   const int lane = lane_id();
   const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
   const uint32_t n_alleles = min(n_lines + a.counters->n_alleles, a.max_alleles);
@@ -84,7 +103,7 @@ __global__ __launch_bounds__(kWgThreads) void k_name_len(KernelArgs a, NameArgs 
         for (uint32_t q = 0; q < 4; q++) {
           const uint32_t cls = (b >> (2u * q)) & 3u;
           const uint32_t s = bi * 4u + q;
-          if (cls && s < a.n_samples) len[cls - 1u] += na.nt.off[s + 1u] - na.nt.off[s] + dl;
+          if (cls && s < a.n_samples) len[cls - 1u] += ns_.o(s + 1u) - ns_.o(s) + dl;
         }
       }
 #pragma unroll
@@ -102,6 +121,19 @@ __global__ __launch_bounds__(kWgThreads) void k_name_len(KernelArgs a, NameArgs 
       na.lists[k] = nl;
       na.tot[k] = len[0] + len[1] + len[2];
     }
+  }
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_name_len(KernelArgs a, NameArgs na) {
+  __shared__ uint32_t s_off[kNameLdsSamples + 1];
+  if (a.n_samples <= kNameLdsSamples) {
+    for (uint32_t i = threadIdx.x; i <= a.n_samples; i += kWgThreads) s_off[i] = na.nt.off[i];
+    __syncthreads();
+    NameSrc<true> src{s_off, nullptr};
+    k_name_len_body<true>(a, na, src);
+  } else {
+    NameSrc<false> src{na.nt.off, na.nt.text};
+    k_name_len_body<false>(a, na, src);
   }
 }
 
@@ -135,10 +167,9 @@ __global__ __launch_bounds__(1024) void k_name_scan(KernelArgs a, NameArgs na) {
   if (threadIdx.x == 1023) *na.total = s_part[1023];
 }
 
-__global__ __launch_bounds__(kWgThreads) void k_name_write(KernelArgs a, NameArgs na) {
+template <bool kLds>
+__device__ __forceinline__ void k_name_write_body(const KernelArgs &a, const NameArgs &na, const NameSrc<kLds> &ns_) {
   const int lane = lane_id();
-  const unsigned long long total = *na.total;
-  if (total > na.cap || total >= 0xFFFFFFF0ull) return;  // the host grows the arena and launches this kernel again
   const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
   const uint32_t n_alleles = min(n_lines + a.counters->n_alleles, a.max_alleles);
   const uint32_t stride = gridDim.x * kWavesPerWg;
@@ -167,7 +198,7 @@ __global__ __launch_bounds__(kWgThreads) void k_name_write(KernelArgs a, NameArg
       for (uint32_t q = 0; q < 4; q++) {
         const uint32_t cls = (b >> (2u * q)) & 3u;
         const uint32_t s = bi * 4u + q;
-        if (cls && s < a.n_samples) mine[cls - 1u] += na.nt.off[s + 1u] - na.nt.off[s] + dl;
+        if (cls && s < a.n_samples) mine[cls - 1u] += ns_.o(s + 1u) - ns_.o(s) + dl;
       }
       uint32_t pos[3];
 #pragma unroll
@@ -182,10 +213,10 @@ __global__ __launch_bounds__(kWgThreads) void k_name_write(KernelArgs a, NameArg
         const uint32_t s = bi * 4u + q;
         if (cls && s < a.n_samples) {
           const uint32_t c = cls - 1u;
-          const uint32_t n0 = na.nt.off[s], nlen = na.nt.off[s + 1u] - n0;
+          const uint32_t n0 = ns_.o(s), nlen = ns_.o(s + 1u) - n0;
           uint32_t p = c == 0 ? pos[0] : (c == 1 ? pos[1] : pos[2]);
           const uint32_t e = c == 0 ? end[0] : (c == 1 ? end[1] : end[2]);
-          for (uint32_t j = 0; j < nlen; j++) na.out[p + j] = na.nt.text[n0 + j];
+          for (uint32_t j = 0; j < nlen; j++) na.out[p + j] = ns_.t(n0 + j);
           p += nlen;
           for (uint32_t j = 0; j < dl && p + j < e; j++) na.out[p + j] = na.nt.delim[j];  // (not after the list's last name)
           p += dl;
@@ -193,6 +224,25 @@ __global__ __launch_bounds__(kWgThreads) void k_name_write(KernelArgs a, NameArg
         }
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_name_write(KernelArgs a, NameArgs na) {
+  __shared__ uint32_t s_off[kNameLdsSamples + 1];
+  __shared__ __attribute__((aligned(16))) uint8_t s_text[kNameLdsText];
+  const unsigned long long total = *na.total;
+  if (total > na.cap || total >= 0xFFFFFFF0ull) return;  // the host grows the arena and launches this kernel again
+  const uint32_t text_bytes = a.n_samples ? na.nt.off[a.n_samples] : 0u;
+  if (a.n_samples <= kNameLdsSamples && text_bytes <= kNameLdsText) {
+    for (uint32_t i = threadIdx.x; i <= a.n_samples; i += kWgThreads) s_off[i] = na.nt.off[i];
+    for (uint32_t i = threadIdx.x * 4u; i < text_bytes; i += kWgThreads * 4u)
+      *reinterpret_cast<uint32_t *>(&s_text[i]) = *reinterpret_cast<const uint32_t *>(na.nt.text + i);  // (the table is padded)
+    __syncthreads();
+    NameSrc<true> src{s_off, s_text};
+    k_name_write_body<true>(a, na, src);
+  } else {
+    NameSrc<false> src{na.nt.off, na.nt.text};
+    k_name_write_body<false>(a, na, src);
   }
 }
 

@@ -67,7 +67,7 @@ def test_device_lists_equal_join_of_names(bv, ns, name_len, delim, dense, path):
                 want = delim.join(names[s] for s in np.flatnonzero(cls == code)).encode()
                 assert b.name_list(slot, q) == want, (i, int(r["alt_idx"]), q)
                 n_checked += 1
-    assert n_checked > 300
+    assert n_checked > 200
 
 
 @pytest.mark.parametrize("device_names", ["1", "0"])
