@@ -44,7 +44,7 @@ BENCH_EXPORTS = ["bvcf_bench_device", "bvcf_bench_device_slots"]
 EXPORTS = [
     "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_set_sample_names", "bvcf_alloc_pinned",
     "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_counters", "bvcf_sum_counters",
-    "bvcf_allreduce_counters", "bvcf_device_count", "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_free",
+    "bvcf_allreduce_counters", "bvcf_device_count", "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_bgzf_inflate_device", "bvcf_free",
     "bvcf_arrow_open", "bvcf_arrow_append", "bvcf_arrow_close",
 ]
 
@@ -212,6 +212,18 @@ def allreduce_counters(ctxs):
     if rc:
         raise BvcfError(rc, lib.bvcf_last_error(ctxs[0].h).decode())
     return list(out), bool(used.value)
+
+
+lib.bvcf_bgzf_inflate_device.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+
+
+def bgzf_inflate_device(comp, cap=None, device=0):
+    """whole BGZF blocks -> (rc, text) through k_inflate / k_crc32 on the device"""
+    cap = cap if cap is not None else max(64, 66000 * (comp.count(b"\x1f\x8b\x08\x04") + 1))
+    buf = C.create_string_buffer(cap)
+    n = C.c_size_t()
+    rc = lib.bvcf_bgzf_inflate_device(device, comp, len(comp), buf, cap, C.byref(n))
+    return rc, (buf.raw[:n.value] if rc == 0 else b""), n.value
 
 
 def decompress(data, n_threads=0):

@@ -5,6 +5,7 @@
 // collect = wait, size check, D2H of exactly the used parts of the result arrays.
 #include "bvcf_device.hip.h"
 #include "../../include/bvcf_bench.h"
+#include "bvcf_bgzf.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so.1 is dlopen'ed by bvcf_allreduce_counters
@@ -836,6 +837,91 @@ int bvcf_sum_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8]) {
     if (!ctxs[i]) return BVCF_E_ARG;
     for (int k = 0; k < 8; k++) out[k] += ctxs[i]->totals[k];
   }
+  return BVCF_OK;
+}
+
+// x^(8 * 1024 * 2^l) mod P for l = 0..5 (zlib's x2nmodp / multmodp, reflected CRC-32 polynomial): k_crc32's fold
+static CrcConsts crc_consts() {
+  auto mul = [](uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 31; i >= 0; i--) {
+      if ((a >> i) & 1u) p ^= b;
+      b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+  };
+  uint32_t x = 0x40000000u;  // x^1
+  for (int k = 0; k < 13; k++) x = mul(x, x);  // x^(2^13)
+  CrcConsts kc;
+  for (int l = 0; l < 6; l++) {
+    kc.k[l] = x;
+    x = mul(x, x);
+  }
+  return kc;
+}
+
+// inflate + CRC of BGZF blocks whose compressed bytes are at d_comp (device): text to d_text.  desc/crc/status are
+// device arrays of n_blocks entries.
+static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_desc, uint32_t n_blocks, uint8_t *d_text,
+                           uint32_t *d_status, uint32_t *d_crc, hipStream_t st) {
+  static const CrcConsts kc = crc_consts();
+  const uint32_t grid = std::min<uint32_t>(n_blocks, (uint32_t)n_cu * 4u);
+  hipLaunchKernelGGL(k_inflate, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
+  hipLaunchKernelGGL(k_crc32, dim3(grid ? grid : 1), dim3(kWave), 0, st, (const uint8_t *)d_text, d_desc, n_blocks, kc, d_crc);
+}
+
+int bvcf_bgzf_inflate_device(int device, const uint8_t *comp, size_t n_comp, uint8_t *out, size_t cap, size_t *n_out) {
+  if ((!comp && n_comp) || !n_out || (!out && cap)) return BVCF_E_ARG;
+  *n_out = 0;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return BVCF_E_NODEV;
+  std::vector<bvcf_bgzf::Block> blocks;
+  const long used = bvcf_bgzf::scan(comp, n_comp, &blocks);
+  if (used < 0 || (size_t)used != n_comp) return BVCF_E_FATAL;  // not BGZF, or a truncated last block
+  if (n_comp >= 0xFFF00000ull) return BVCF_E_TOO_BIG;
+  std::vector<BgzfDesc> desc(blocks.size());
+  uint64_t total = 0;
+  for (size_t i = 0; i < blocks.size(); i++) {
+    desc[i].in_off = blocks[i].in_off;
+    desc[i].in_len = blocks[i].in_len;
+    desc[i].out_off = (uint32_t)total;
+    desc[i].isize = blocks[i].isize;
+    total += blocks[i].isize;
+  }
+  *n_out = (size_t)total;
+  if (total > cap || total >= 0xFFF00000ull) return BVCF_E_TOO_BIG;
+  if (blocks.empty()) return BVCF_OK;
+  if (hipSetDevice(device) != hipSuccess) return BVCF_E_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BVCF_E_HIP;
+  uint8_t *d_comp = nullptr, *d_text = nullptr;
+  BgzfDesc *d_desc = nullptr;
+  uint32_t *d_status = nullptr, *d_crc = nullptr;
+  const size_t nb = blocks.size();
+  int rc = BVCF_OK;
+  std::vector<uint32_t> status(nb), crc(nb);
+  if (hipMalloc(&d_comp, n_comp + 64) != hipSuccess || hipMalloc(&d_text, total + 64) != hipSuccess ||
+      hipMalloc(&d_desc, nb * sizeof(BgzfDesc)) != hipSuccess || hipMalloc(&d_status, nb * 4) != hipSuccess ||
+      hipMalloc(&d_crc, nb * 4) != hipSuccess) {
+    rc = BVCF_E_NOMEM;
+  } else if (hipMemcpy(d_comp, comp, n_comp, hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(d_desc, desc.data(), nb * sizeof(BgzfDesc), hipMemcpyHostToDevice) != hipSuccess) {
+    rc = BVCF_E_HIP;
+  } else {
+    launch_inflate(prop.multiProcessorCount, d_comp, d_desc, (uint32_t)nb, d_text, d_status, d_crc, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(crc.data(), d_crc, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        (total && hipMemcpy(out, d_text, total, hipMemcpyDeviceToHost) != hipSuccess))
+      rc = BVCF_E_HIP;
+  }
+  hipFree(d_comp);
+  hipFree(d_text);
+  hipFree(d_desc);
+  hipFree(d_status);
+  hipFree(d_crc);
+  if (rc) return rc;
+  for (size_t i = 0; i < nb; i++)
+    if (status[i] != kInfOk || crc[i] != blocks[i].crc) return BVCF_E_FATAL;  // corrupt block (inflate or CRC mismatch)
   return BVCF_OK;
 }
 

@@ -54,3 +54,4 @@
 #include "bvcf_head.hip.h"
 #include "bvcf_sites.hip.h"
 #include "bvcf_names.hip.h"
+#include "bvcf_inflate.hip.h"

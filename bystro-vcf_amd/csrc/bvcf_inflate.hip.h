@@ -1,0 +1,527 @@
+// bvcf_inflate.hip.h — BGZF blocks inflated on the device (device half)
+// Part of the gfx950 device code of libbvcf; see bvcf_device.hip.h for the kernel map.
+//
+// The reference leaves decompression to `pigz -d -c` in front of the pipe, and names that single-threaded inflate as
+// the limit of its headline run (README.md:5,46).  A .vcf.gz written by bgzip / htslib is BGZF: independent gzip
+// members of at most 64 KiB of text each.  k_inflate takes ONE WAVE PER BGZF BLOCK: the compressed bytes cross PCIe
+// (a sixth of the text for genotype VCFs), and the text is produced where the scan kernels read it.
+//
+// DEFLATE (RFC 1951) is a serial bit stream, so the wave decodes it with wave-uniform state -- every lane holds the
+// same bit buffer and positions, which costs what one lane would -- and uses its 64 lanes where the format allows:
+// building the Huffman tables, match copies (up to 258 bytes each; genotype text is mostly matches), stored blocks
+// and the write-out.  Per wave in LDS: a 32 KiB window of the output (the most a match may reach back), written to
+// memory in 16 KiB segments as it fills; a 2 KiB ring of compressed input; a 10-bit literal/length table and a 9-bit
+// distance table with canonical-code fallbacks for longer codes.
+#pragma once
+
+#include "bvcf_common.hip.h"
+
+namespace bvcf_dev {
+
+struct BgzfDesc {
+  uint32_t in_off;    // deflate payload in the compressed buffer
+  uint32_t in_len;
+  uint32_t out_off;   // where the block's text goes
+  uint32_t isize;     // bytes it must inflate to (BGZF trailer)
+};
+
+enum {
+  kInfOk = 0,
+  kInfBadBlockType = 1,
+  kInfBadStored = 2,
+  kInfBadCodeLengths = 3,
+  kInfBadSymbol = 4,
+  kInfBadDistance = 5,
+  kInfOutputOverrun = 6,
+  kInfInputOverrun = 7,
+  kInfSizeMismatch = 8,
+};
+
+constexpr uint32_t kInfWindow = 32768;
+constexpr uint32_t kInfSegment = 16384;
+constexpr uint32_t kInfInRing = 2048;
+constexpr uint32_t kInfLitBits = 10, kInfDistBits = 9;
+constexpr int kInfThreads = kWave;  // one wave per workgroup
+
+struct InfLds {
+  uint8_t win[kInfWindow];                 // output byte p lives at win[p & (kInfWindow - 1)]
+  uint8_t in[kInfInRing];                  // compressed byte q lives at in[q & (kInfInRing - 1)]
+  uint16_t lit[1u << kInfLitBits];         // code (bit-reversed, low bits) -> len << 9 | symbol; 0 = longer than the table
+  uint16_t dist[1u << kInfDistBits];       // the same for distance codes: len << 5 | symbol
+  uint16_t lit_sorted[288], dist_sorted[32];  // symbols in canonical order, for codes longer than the tables
+  uint16_t lit_count[16], dist_count[16];  // codes per length
+  uint8_t lens[384];                       // code lengths being read: [0,19) the code-length code, [32,..) literal/length then distance
+};
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t n) { return __brev(v) >> (32u - n); }
+
+// Huffman tables from code lengths lens[0 .. n) (RFC 1951 3.2.2).  table: primary lookup of `bits` bits; sorted /
+// count: canonical order for longer codes.  sym_shift: where the length goes in a table entry.  Returns false if the
+// lengths over-subscribe the code space.
+__device__ inline bool inf_build(const uint8_t *lens, uint32_t n, uint16_t *table, uint32_t bits, uint16_t *sorted,
+                                 uint16_t *count, uint32_t sym_shift) {
+  const int lane = lane_id();
+  // codes per length
+  for (uint32_t L = lane; L < 16; L += kWave) count[L] = 0;
+  for (uint32_t i = lane; i < (1u << bits); i += kWave) table[i] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t cnt[16];
+#pragma unroll
+  for (uint32_t L = 0; L < 16; L++) cnt[L] = 0;
+  for (uint32_t base = 0; base < n; base += kWave) {
+    const uint32_t s = base + lane;
+    const uint32_t l = s < n ? lens[s] : 0u;
+#pragma unroll
+    for (uint32_t L = 1; L < 16; L++) cnt[L] += (uint32_t)__popcll(__ballot(l == L));
+  }
+  // first code of each length; over-subscription check
+  uint32_t next[16], offs[16];
+  uint32_t code = 0, left = 1, off = 0;
+  bool ok = true;
+#pragma unroll
+  for (uint32_t L = 1; L < 16; L++) {
+    left <<= 1;
+    if (cnt[L] > left) ok = false;
+    left -= min(cnt[L], left);
+    code = (code + cnt[L - 1]) << 1;
+    next[L] = code;
+    offs[L] = off;
+    off += cnt[L];
+  }
+  if (lane < 16) count[lane] = (uint16_t)(lane ? cnt[lane] : 0u);
+  if (!ok) return false;
+  // every symbol: its code = first code of its length + its rank among the symbols of that length
+  for (uint32_t base = 0; base < n; base += kWave) {
+    const uint32_t s = base + lane;
+    const uint32_t l = s < n ? lens[s] : 0u;
+    uint32_t my_code = 0, my_rank = 0;
+#pragma unroll
+    for (uint32_t L = 1; L < 16; L++) {
+      const unsigned long long m = __ballot(l == L);
+      if (l == L) {
+        my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        my_code = next[L] + my_rank;
+        sorted[offs[L] + my_rank] = (uint16_t)s;
+      }
+      const uint32_t c = (uint32_t)__popcll(m);
+      next[L] += c;
+      offs[L] += c;
+    }
+    if (l && l <= bits) {
+      const uint16_t e = (uint16_t)((l << sym_shift) | s);
+      for (uint32_t i = bitrev(my_code, l); i < (1u << bits); i += 1u << l) table[i] = e;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return true;
+}
+
+// length / distance bases (RFC 1951 3.2.5)
+__device__ __forceinline__ uint32_t inf_len_base(uint32_t i, uint32_t *extra) {
+  // codes 257..285 -> i = 0..28
+  if (i < 8) {
+    *extra = 0;
+    return 3 + i;
+  }
+  if (i == 28) {
+    *extra = 0;
+    return 258;
+  }
+  const uint32_t e = (i - 4) >> 2;
+  *extra = e;
+  return 3 + ((4 + (i & 3)) << e);
+}
+__device__ __forceinline__ uint32_t inf_dist_base(uint32_t i, uint32_t *extra) {
+  if (i < 4) {
+    *extra = 0;
+    return 1 + i;
+  }
+  const uint32_t e = (i - 2) >> 1;
+  *extra = e;
+  return 1 + ((2 + (i & 1)) << e);
+}
+
+// one wave per BGZF block; status[k] = kInf*
+__global__ __launch_bounds__(kInfThreads) void k_inflate(const uint8_t *comp, const BgzfDesc *desc, uint32_t n_blocks,
+                                                         uint8_t *out, uint32_t *status) {
+  __shared__ __attribute__((aligned(16))) InfLds S;
+  const int lane = lane_id();
+  for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const BgzfDesc d = desc[blk];
+    const uint8_t *src = comp + d.in_off;
+    uint8_t *dst = out + d.out_off;
+    // wave-uniform decoder state
+    uint32_t in_fetched = 0;   // compressed bytes in the ring so far
+    uint32_t in_pos = 0;       // next byte the bit buffer takes
+    unsigned long long bb = 0; // bit buffer, LSB first
+    uint32_t nb = 0;           // bits in it
+    uint32_t pos = 0;          // output bytes produced
+    uint32_t flushed = 0;      // output bytes written to memory
+    uint32_t err = kInfOk;
+
+    // compressed bytes [in_fetched, in_fetched + 1 KiB) into the ring (all lanes; bytes past the payload are zeros)
+    auto fetch = [&]() {
+      const uint32_t q = in_fetched + 16u * lane;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q + 16u <= d.in_len) v = *reinterpret_cast<const u32x4_u *>(src + q);
+      *reinterpret_cast<u32x4 *>(&S.in[q & (kInfInRing - 1u)]) = v;
+      if (q < d.in_len && q + 16u > d.in_len)  // the payload's last, partial piece: byte by byte over the zeros
+        for (uint32_t i = 0; i < d.in_len - q; i++) S.in[(q + i) & (kInfInRing - 1u)] = src[q + i];
+      in_fetched += kChunk;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    // keep >= 32 bits in the buffer (a symbol needs at most 15 + 13 extra)
+    auto refill = [&]() {
+      while (nb <= 32u) {
+        if (in_pos > d.in_len + 16u) {  // reading far past the payload: a truncated or corrupt stream
+          err = kInfInputOverrun;
+          break;
+        }
+        if (in_pos + 8u > in_fetched) fetch();  // (unread bytes stay below half the ring)
+        const uint32_t a = in_pos & (kInfInRing - 1u);
+        // four bytes at any alignment, across the ring's end
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(&S.in[a & ~3u]);
+        const uint32_t w1 = *reinterpret_cast<const uint32_t *>(&S.in[(a + 4u) & (kInfInRing - 1u) & ~3u]);
+        const uint32_t w = __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+        bb |= (unsigned long long)w << nb;
+        nb += 32u;
+        in_pos += 4u;
+      }
+    };
+    auto take = [&](uint32_t n) -> uint32_t {
+      const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
+      bb >>= n;
+      nb -= n;
+      return v;
+    };
+    // write out the finished 16 KiB segments
+    auto flush_segments = [&](bool all) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      while (flushed + kInfSegment <= pos || (all && flushed < pos)) {
+        const uint32_t n = min(kInfSegment, pos - flushed);
+        for (uint32_t i = 16u * lane; i < n; i += 16u * kWave) {
+          const u32x4 v = *reinterpret_cast<const u32x4 *>(&S.win[(flushed + i) & (kInfWindow - 1u)]);
+          if (i + 16u <= n) {
+            *reinterpret_cast<u32x4_u *>(dst + flushed + i) = v;
+          } else {
+            for (uint32_t j = 0; j < n - i; j++) dst[flushed + i + j] = S.win[(flushed + i + j) & (kInfWindow - 1u)];
+          }
+        }
+        flushed += n;
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+
+    fetch();
+    bool last = false;
+    while (!last && err == kInfOk) {
+      refill();
+      last = take(1) != 0;
+      const uint32_t type = take(2);
+      if (type == 0) {
+        // ---- stored: skip to the byte boundary, LEN / NLEN, then LEN bytes
+        take(nb & 7u);
+        refill();
+        const uint32_t len = take(16), nlen = take(16);
+        if ((len ^ nlen) != 0xFFFFu) {
+          err = kInfBadStored;
+          break;
+        }
+        // the bytes still in the bit buffer come first
+        uint32_t q = in_pos - nb / 8u;  // payload offset of the next unread byte
+        if (q + len > d.in_len) {
+          err = kInfInputOverrun;
+          break;
+        }
+        if (pos + len > d.isize) {
+          err = kInfOutputOverrun;
+          break;
+        }
+        for (uint32_t done = 0; done < len;) {
+          // in pieces that keep a segment's worth of window
+          const uint32_t n = min(len - done, kInfSegment - ((pos + 0u) & (kInfSegment - 1u)));
+          for (uint32_t i = lane; i < n; i += kWave) S.win[(pos + i) & (kInfWindow - 1u)] = src[q + done + i];
+          pos += n;
+          done += n;
+          flush_segments(false);
+        }
+        // restart the input after the stored bytes
+        in_pos = q + len;
+        bb = 0;
+        nb = 0;
+        in_fetched = in_pos & ~(kChunk - 1u);
+        fetch();
+        continue;
+      }
+      if (type == 3) {
+        err = kInfBadBlockType;
+        break;
+      }
+      uint32_t n_lit = 288, n_dist = 30;
+      if (type == 1) {
+        // ---- fixed codes (RFC 1951 3.2.6)
+        for (uint32_t i = lane; i < 288; i += kWave) S.lens[i] = (uint8_t)(i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8)));
+        for (uint32_t i = lane; i < 32; i += kWave) S.lens[288 + i] = 5;
+        n_dist = 32;
+      } else {
+        // ---- dynamic codes: HLIT, HDIST, HCLEN, the code-length code, then the lengths (serial: run-length coded)
+        refill();
+        n_lit = take(5) + 257u;
+        n_dist = take(5) + 1u;
+        const uint32_t n_clen = take(4) + 4u;
+        if (n_lit > 286u || n_dist > 30u) {
+          err = kInfBadCodeLengths;
+          break;
+        }
+        // code lengths of the code-length alphabet, in the order of RFC 1951 3.2.7
+        if (lane < 19) S.lens[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = 0; i < n_clen; i++) {
+          refill();
+          const uint32_t v = take(3);
+          // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+          const uint32_t ord = i < 3 ? 16u + i : (i == 3 ? 0u : ((i & 1u) ? 8u - ((i - 3u) >> 1) : 7u + ((i - 2u) >> 1)));
+          if (lane == 0) S.lens[ord] = (uint8_t)v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // a 7-bit table for the 19 code-length symbols (in the distance table's storage)
+        if (!inf_build(S.lens, 19, S.dist, 7, S.dist_sorted, S.dist_count, 5)) {
+          err = kInfBadCodeLengths;
+          break;
+        }
+        uint32_t got = 0, prev = 0;
+        const uint32_t want = n_lit + n_dist;
+        while (got < want && err == kInfOk) {
+          refill();
+          const uint32_t e = S.dist[(uint32_t)bb & 127u];
+          const uint32_t l = e >> 5, sym = e & 31u;
+          if (l == 0) {
+            err = kInfBadCodeLengths;
+            break;
+          }
+          take(l);
+          uint32_t rep = 1, val = sym;
+          if (sym == 16) {
+            if (got == 0) {
+              err = kInfBadCodeLengths;
+              break;
+            }
+            rep = 3 + take(2);
+            val = prev;
+          } else if (sym == 17) {
+            rep = 3 + take(3);
+            val = 0;
+          } else if (sym == 18) {
+            rep = 11 + take(7);
+            val = 0;
+          }
+          if (got + rep > want) {
+            err = kInfBadCodeLengths;
+            break;
+          }
+          // (lens[] for the real alphabets start at 32: the first 19 entries are the code-length code's)
+          for (uint32_t i = lane; i < rep; i += kWave) S.lens[32 + got + i] = (uint8_t)val;
+          got += rep;
+          prev = val;
+        }
+        if (err != kInfOk) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      const uint8_t *lit_lens = type == 1 ? S.lens : S.lens + 32;
+      const uint8_t *dist_lens = type == 1 ? S.lens + 288 : S.lens + 32 + n_lit;
+      if (type == 2 && lit_lens[256] == 0) {
+        err = kInfBadCodeLengths;  // no end-of-block code
+        break;
+      }
+      if (!inf_build(lit_lens, n_lit, S.lit, kInfLitBits, S.lit_sorted, S.lit_count, 9) ||
+          !inf_build(dist_lens, n_dist, S.dist, kInfDistBits, S.dist_sorted, S.dist_count, 5)) {
+        err = kInfBadCodeLengths;
+        break;
+      }
+      // canonical decode of a code longer than the primary table: returns the symbol, consumes the bits
+      auto slow_decode = [&](const uint16_t *count, const uint16_t *sorted) -> uint32_t {
+        uint32_t code = 0, first = 0, index = 0;
+        unsigned long long b = bb;
+        for (uint32_t l = 1; l <= 15; l++) {
+          code |= (uint32_t)b & 1u;
+          b >>= 1;
+          const uint32_t c = count[l];
+          if (code < first + c) {
+            take(l);
+            return sorted[index + (code - first)];
+          }
+          index += c;
+          first += c;
+          first <<= 1;
+          code <<= 1;
+        }
+        return 0xFFFFu;
+      };
+      // ---- the symbols of this block
+      for (;;) {
+        refill();
+        if (err != kInfOk) break;
+        uint32_t e = S.lit[(uint32_t)bb & ((1u << kInfLitBits) - 1u)];
+        uint32_t sym;
+        if (e) {
+          take(e >> 9);
+          sym = e & 511u;
+        } else {
+          sym = slow_decode(S.lit_count, S.lit_sorted);
+          if (sym == 0xFFFFu) {
+            err = kInfBadSymbol;
+            break;
+          }
+        }
+        if (sym < 256u) {
+          if (pos >= d.isize) {
+            err = kInfOutputOverrun;
+            break;
+          }
+          if (lane == 0) S.win[pos & (kInfWindow - 1u)] = (uint8_t)sym;
+          pos++;
+          if ((pos & (kInfSegment - 1u)) == 0u) flush_segments(false);
+          continue;
+        }
+        if (sym == 256u) break;
+        if (sym > 285u) {
+          err = kInfBadSymbol;
+          break;
+        }
+        uint32_t extra;
+        uint32_t len = inf_len_base(sym - 257u, &extra);
+        len += take(extra);
+        refill();
+        e = S.dist[(uint32_t)bb & ((1u << kInfDistBits) - 1u)];
+        uint32_t dsym;
+        if (e) {
+          take(e >> 5);
+          dsym = e & 31u;
+        } else {
+          dsym = slow_decode(S.dist_count, S.dist_sorted);
+        }
+        if (dsym > 29u) {
+          err = kInfBadDistance;
+          break;
+        }
+        uint32_t dist = inf_dist_base(dsym, &extra);
+        dist += take(extra);
+        if (dist > pos) {
+          err = kInfBadDistance;
+          break;
+        }
+        if (pos + len > d.isize) {
+          err = kInfOutputOverrun;
+          break;
+        }
+        // ---- the match, by all lanes: byte i comes from the `dist` bytes before pos, repeated
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+          const uint32_t from = pos - dist;
+          uint8_t v[5];
+          // read all source bytes first: a piece that wraps into what this match writes is the periodic case
+#pragma unroll
+          for (uint32_t r = 0; r < 5; r++) {
+            const uint32_t i = lane + r * kWave;
+            uint32_t k = i;
+            // i mod dist for i < 320, dist < 258: the quotient from a float division ((i + 0.5) / dist is never within
+            // 0.002 of an integer)
+            if (dist < len && i >= dist) k = i - dist * (uint32_t)(((float)i + 0.5f) / (float)dist);
+            v[r] = i < len ? S.win[(from + k) & (kInfWindow - 1u)] : (uint8_t)0;
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (uint32_t r = 0; r < 5; r++) {
+            const uint32_t i = lane + r * kWave;
+            if (i < len) S.win[(pos + i) & (kInfWindow - 1u)] = v[r];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t before = pos;
+        pos += len;
+        if ((before ^ pos) & ~(kInfSegment - 1u)) flush_segments(false);
+      }
+    }
+    if (err == kInfOk) {
+      flush_segments(true);
+      if (pos != d.isize) err = kInfSizeMismatch;
+    }
+    if (lane == 0) status[blk] = err;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
+// ------------------------------------------------------------------ CRC-32 of the inflated blocks
+// BGZF's trailer carries the CRC-32 (IEEE 802.3, reflected) of each block's text.  One wave per block: the block is
+// seen as the tail of a 64 KiB buffer of zeros (leading zeros do not change a CRC that starts from 0; the usual
+// 0xFFFFFFFF start value is the same as inverting the first four bytes), lane i takes the i-th KiB byte by byte from a
+// 256-entry table in LDS, and six scan steps fold the 64 partial CRCs: crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in
+// GF(2)[x] mod P, with the six constants x^(8 * 1024 * 2^l) mod P supplied by the host.
+struct CrcConsts {
+  uint32_t k[6];
+};
+
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {  // zlib's multmodp, branch-free
+  uint32_t p = 0;
+#pragma unroll
+  for (int i = 31; i >= 0; i--) {
+    p ^= b & (0u - ((a >> i) & 1u));
+    b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+  }
+  return p;
+}
+
+__global__ __launch_bounds__(kWave) void k_crc32(const uint8_t *text, const BgzfDesc *desc, uint32_t n_blocks, CrcConsts kc,
+                                                 uint32_t *crc_out) {
+  __shared__ uint32_t s_tab[256];
+  const int lane = lane_id();
+  for (uint32_t i = lane; i < 256; i += kWave) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+    s_tab[i] = c;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const BgzfDesc d = desc[blk];
+    const uint8_t *p = text + d.out_off;
+    const uint32_t n = d.isize;           // <= 65536
+    const uint32_t pad = 65536u - n;      // virtual leading zeros
+    const uint32_t v_lo = (uint32_t)lane * 1024u, v_hi = v_lo + 1024u;
+    uint32_t crc = 0;
+    // the lane's real bytes: virtual [max(v_lo, pad), v_hi) -> real offsets - pad
+    for (uint32_t v = max(v_lo, pad); v < v_hi; v++) {
+      const uint32_t r = v - pad;
+      uint32_t b = p[r];
+      if (r < 4u) b ^= 0xFFu;  // the 0xFFFFFFFF start value
+      crc = s_tab[(crc ^ b) & 0xFFu] ^ (crc >> 8);
+    }
+    // inclusive scan: after step l a lane holds the CRC of up to 2^(l+1) KiB ending with its own
+#pragma unroll
+    for (int l = 0; l < 6; l++) {
+      const uint32_t left = __shfl_up(crc, 1u << l);
+      if (lane >= (1 << l)) crc = gf2_mulmod(kc.k[l], left) ^ crc;
+    }
+    if (lane == kWave - 1) {
+      uint32_t out = crc ^ 0xFFFFFFFFu;
+      if (n < 4u) {
+        // shorter than the start value: the plain definition
+        uint32_t c = 0xFFFFFFFFu;
+        for (uint32_t j = 0; j < n; j++) c = s_tab[(c ^ p[j]) & 0xFFu] ^ (c >> 8);
+        out = c ^ 0xFFFFFFFFu;
+      }
+      crc_out[blk] = out;
+    }
+  }
+}
+
+}  // namespace bvcf_dev

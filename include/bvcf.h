@@ -311,6 +311,13 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
  * or BGZF (block-parallel, n_threads workers; 0 = up to 32) on the way.  Host-only: needs no device. */
 int bvcf_decompress_fd(int fd_in, int fd_out, uint32_t n_threads, char *kind_out /* >= 8 bytes or NULL */);
 
+/* BGZF blocks inflated ON THE DEVICE (one wavefront per block): comp holds whole BGZF blocks
+ * (bgzip / htslib output; the empty end-of-file block may be among them), out receives their text, *n_out its length.
+ * Each block is checked against its ISIZE and CRC32.  Returns BVCF_E_FATAL for data that is not BGZF or is corrupt,
+ * BVCF_E_TOO_BIG if out is too small (*n_out then holds the size needed).  This is the building block of
+ * bvcf_run_fd's compressed path, exported for tests and for callers that keep compressed data resident. */
+int bvcf_bgzf_inflate_device(int device, const uint8_t *comp, size_t n_comp, uint8_t *out, size_t cap, size_t *n_out);
+
 void bvcf_free(void *p);
 
 /* ---- the dosage matrix file (--dosageOutput) ----
