@@ -43,7 +43,7 @@ BENCH_EXPORTS = ["bvcf_bench_device", "bvcf_bench_device_slots"]
 # every symbol include/bvcf.h declares
 EXPORTS = [
     "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_set_sample_names", "bvcf_alloc_pinned",
-    "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_collect", "bvcf_counters", "bvcf_sum_counters",
+    "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_submit_bgzf", "bvcf_collect", "bvcf_counters", "bvcf_sum_counters",
     "bvcf_allreduce_counters", "bvcf_device_count", "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_bgzf_inflate_device", "bvcf_free",
     "bvcf_arrow_open", "bvcf_arrow_append", "bvcf_arrow_close",
 ]
@@ -80,6 +80,7 @@ class Result(C.Structure):
         ("need_cmap_bytes", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32),
         ("n_lines_seen", C.c_uint64), ("dosage", C.c_void_p), ("dosage_stride", C.c_uint32), ("reserved2", C.c_uint32),
         ("name_lists", C.c_void_p), ("names", C.c_void_p), ("n_name_bytes", C.c_uint64),
+        ("text", C.c_void_p), ("n_text_bytes", C.c_uint64),
     ]
 
 
@@ -109,6 +110,7 @@ lib.bvcf_alloc_pinned.restype = C.c_void_p
 lib.bvcf_free_pinned.argtypes = [C.c_void_p]
 lib.bvcf_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
 lib.bvcf_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
+lib.bvcf_submit_bgzf.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64]
 lib.bvcf_collect.argtypes = [C.c_void_p, C.POINTER(Result)]
 lib.bvcf_bench_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
                                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
@@ -259,6 +261,8 @@ class Batch:
         self.errs = arr(r.errs, r.n_errs, ERR_DTYPE)
         self.cmap = arr(r.cmap, r.n_cmap_bytes, np.dtype("u1"))
         # want_dosage: one int8 row per alleles[] slot (rows of slots without a record hold garbage)
+        # bvcf_submit_bgzf: the batch's inflated text (lines[].off point into it)
+        self.text = C.string_at(r.text, r.n_text_bytes) if r.text and r.n_text_bytes else b""
         # want_name_lists: (off[3], len[3]) per alleles[] slot into the text arena `names`
         self.name_lists = arr(r.name_lists, r.n_alleles, NAMES_DTYPE) if r.name_lists else None
         self.names = C.string_at(r.names, r.n_name_bytes) if r.names and r.n_name_bytes else b""
@@ -351,6 +355,11 @@ class Ctx:
     def submit(self, block, seq=0):
         self._blk = block  # keep alive until collect
         self._check(lib.bvcf_submit(self.h, block, len(block), seq))
+
+    def submit_bgzf(self, comp, n_own, skip_first_line, first_off=0, seq=0):
+        """whole BGZF blocks: n_own bytes of own blocks, then look-ahead blocks (see include/bvcf.h)"""
+        self._blk = comp
+        self._check(lib.bvcf_submit_bgzf(self.h, comp, len(comp), n_own, int(skip_first_line), first_off, seq))
 
     def submit_device(self, dptr, nbytes, seq=0):
         self._check(lib.bvcf_submit_device(self.h, dptr, nbytes, seq))

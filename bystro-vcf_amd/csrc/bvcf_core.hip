@@ -46,6 +46,19 @@ struct Slot {
   char *h_names = nullptr;
   unsigned long long *d_name_total = nullptr, *h_name_total = nullptr;
   uint64_t cap_names = 0;
+  // bvcf_submit_bgzf: compressed bytes, block descriptors, inflate results, the batch's text on the host
+  uint8_t *d_comp = nullptr;
+  uint64_t cap_comp = 0;
+  uint32_t *d_bgzf = nullptr, *h_bgzf = nullptr;  // per block: BgzfDesc (4 words), expected crc, then status[], crc[]
+  uint64_t cap_bgzf_blocks = 0;
+  uint32_t *d_cuts = nullptr, *h_cuts = nullptr;  // {start, end, flags, first bad block}
+  uint8_t *h_text = nullptr;
+  hipEvent_t ev_cut = nullptr;
+  bool await_cuts = false;  // inflate enqueued, the kernel chain not yet (it needs the cut points)
+  bool is_bgzf = false;     // the batch in flight came through bvcf_submit_bgzf
+  int bgzf_rc = 0;          // ... and was refused (corrupt block, line past the look-ahead): reported by bvcf_collect
+  const char *bgzf_err = nullptr;
+  uint32_t text_start = 0, text_total = 0;
   BatchCounters *d_counters = nullptr;
   // pinned host
   BatchCounters *h_counters = nullptr;
@@ -162,6 +175,13 @@ void free_slot(Slot &s) {
   hipHostFree(s.h_name_lists);
   hipHostFree(s.h_names);
   hipHostFree(s.h_name_total);
+  hipFree(s.d_comp);
+  hipFree(s.d_bgzf);
+  hipHostFree(s.h_bgzf);
+  hipFree(s.d_cuts);
+  hipHostFree(s.h_cuts);
+  hipHostFree(s.h_text);
+  if (s.ev_cut) hipEventDestroy(s.ev_cut);
   hipFree(s.d_counters);
   hipHostFree(s.h_counters);
   hipHostFree(s.h_lines);
@@ -430,6 +450,55 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
   }
 }
 
+// x^(8 * 1024 * 2^l) mod P for l = 0..5 (zlib's x2nmodp / multmodp, reflected CRC-32 polynomial): k_crc32's fold
+static CrcConsts crc_consts() {
+  auto mul = [](uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 31; i >= 0; i--) {
+      if ((a >> i) & 1u) p ^= b;
+      b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+  };
+  uint32_t x = 0x40000000u;  // x^1
+  for (int k = 0; k < 13; k++) x = mul(x, x);  // x^(2^13)
+  CrcConsts kc;
+  for (int l = 0; l < 6; l++) {
+    kc.k[l] = x;
+    x = mul(x, x);
+  }
+  return kc;
+}
+
+// inflate + CRC of BGZF blocks whose compressed bytes are at d_comp (device): text to d_text.  desc/crc/status are
+// device arrays of n_blocks entries.
+static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_desc, uint32_t n_blocks, uint8_t *d_text,
+                           uint32_t *d_status, uint32_t *d_crc, hipStream_t st) {
+  static const CrcConsts kc = crc_consts();
+  const uint32_t grid = std::min<uint32_t>(n_blocks, (uint32_t)n_cu * 4u);
+  hipLaunchKernelGGL(k_inflate, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
+  hipLaunchKernelGGL(k_crc32, dim3(grid ? grid : 1), dim3(kWave), 0, st, (const uint8_t *)d_text, d_desc, n_blocks, kc, d_crc);
+}
+
+// the kernel chain of the batch in slot s over the resident text src[0 .. nbytes), the counter read-back and the event
+// bvcf_collect waits for
+int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
+  KernelArgs a = make_args(c, s, src, nbytes);
+  HIP_TRY(c, hipEventRecord(s.ev_k0, s.stream));
+  launch_chain(c, a, s.stream, nullptr, nullptr);
+  const bool names = c->names_on && s.d_name_lists;
+  if (names) launch_names(c, a, make_name_args(c, s), s.stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(s.ev_k1, s.stream));
+  HIP_TRY(c, hipMemcpyAsync(s.h_counters, s.d_counters, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.stream));
+  if (names)
+    HIP_TRY(c, hipMemcpyAsync(s.h_name_total, s.d_name_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
+  s.src = src;
+  s.nbytes = nbytes;
+  HIP_TRY(c, hipEventRecord(s.ev_ctr, s.stream));
+  return BVCF_OK;
+}
+
 int submit_common(bvcf_ctx *c, const uint8_t *host_block, const void *dev_block, size_t nbytes, uint64_t seq) {
   if (!c) return BVCF_E_ARG;
   if (nbytes > c->p.max_batch_bytes || nbytes >= kMaxBlockBytes) {
@@ -451,24 +520,41 @@ int submit_common(bvcf_ctx *c, const uint8_t *host_block, const void *dev_block,
     HIP_TRY(c, hipMemsetAsync(s.d_in + nbytes, '\n', BVCF_DEVICE_PAD, s.stream));
     src = s.d_in;
   }
-  KernelArgs a = make_args(c, s, src, nbytes);
-  HIP_TRY(c, hipEventRecord(s.ev_k0, s.stream));
-  launch_chain(c, a, s.stream, nullptr, nullptr);
-  const bool names = c->names_on && s.d_name_lists;
-  if (names) launch_names(c, a, make_name_args(c, s), s.stream);
-  HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipEventRecord(s.ev_k1, s.stream));
-  HIP_TRY(c, hipMemcpyAsync(s.h_counters, s.d_counters, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.stream));
-  if (names)
-    HIP_TRY(c, hipMemcpyAsync(s.h_name_total, s.d_name_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
-  s.src = src;
-  HIP_TRY(c, hipEventRecord(s.ev_ctr, s.stream));
+  s.await_cuts = false;
+  s.is_bgzf = false;
+  s.bgzf_rc = 0;
+  rc = launch_batch(c, s, src, nbytes);
+  if (rc) return rc;
   s.busy = true;
   s.seq = seq;
-  s.nbytes = nbytes;
   c->head = (c->head + 1) % c->slots.size();
   c->in_flight++;
   return BVCF_OK;
+}
+
+// second half of bvcf_submit_bgzf, once the cut points of the slot's text are on the host: the kernel chain over
+// text[start, end) and the copy of that text for the caller's TSV assembly.  wait: block until they are.
+int launch_after_cuts(bvcf_ctx *c, Slot &s, bool wait) {
+  if (!s.await_cuts) return BVCF_OK;
+  if (!wait && hipEventQuery(s.ev_cut) != hipSuccess) return BVCF_OK;  // not yet (or an error: collect reports it)
+  hipError_t e = hipEventSynchronize(s.ev_cut);
+  s.await_cuts = false;
+  if (e != hipSuccess) {
+    c->err = std::string("BGZF inflate failed: ") + hipGetErrorString(e);
+    return BVCF_E_HIP;
+  }
+  const uint32_t start = s.h_cuts[0], end = s.h_cuts[1], flags = s.h_cuts[2];
+  if (flags) {
+    s.bgzf_err = (flags & kCutInflateError) ? "bgzf: corrupt block (inflate)"
+                 : (flags & kCutCrcMismatch) ? "bgzf: corrupt block (CRC mismatch)"
+                                              : "bgzf: a line does not end within the look-ahead blocks";
+    s.bgzf_rc = BVCF_E_FATAL;
+    return launch_batch(c, s, s.d_in, 0);  // (the slot still has to be collected: an empty batch carries the error)
+  }
+  s.text_start = start;
+  const size_t nbytes = end - start;
+  if (nbytes) HIP_TRY(c, hipMemcpyAsync(s.h_text, s.d_in + start, nbytes, hipMemcpyDeviceToHost, s.stream));
+  return launch_batch(c, s, s.d_in + start, nbytes);
 }
 
 }  // namespace
@@ -692,6 +778,120 @@ int bvcf_submit_device(bvcf_ctx *c, const void *dblock, size_t nbytes, uint64_t 
   return submit_common(c, nullptr, dblock, nbytes, batch_seq);
 }
 
+int bvcf_submit_bgzf(bvcf_ctx *c, const uint8_t *comp, size_t n_comp, size_t n_own, int skip_first_line, uint32_t first_off,
+                     uint64_t batch_seq) {
+  if (!c || !comp || !n_comp || n_own > n_comp) return BVCF_E_ARG;
+  if (c->in_flight == c->slots.size()) {
+    c->err = "all slots in flight";
+    return BVCF_E_BUSY;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  // chains of older bgzf batches whose cut points have arrived go first (keeps the device busy between collects)
+  for (size_t k = 0, i = c->tail; k < c->in_flight; k++, i = (i + 1) % c->slots.size()) {
+    const int rc = launch_after_cuts(c, c->slots[i], false);
+    if (rc) return rc;
+  }
+  std::vector<bvcf_bgzf::Block> blocks;
+  const long used = bvcf_bgzf::scan(comp, n_comp, &blocks);
+  if (used < 0 || (size_t)used != n_comp || blocks.empty()) {
+    c->err = "bvcf_submit_bgzf: not whole BGZF blocks";
+    return BVCF_E_ARG;
+  }
+  uint64_t total = 0, own = 0, own_bytes = 0;
+  for (const auto &b : blocks) {
+    if (own_bytes < n_own) {
+      own_bytes += b.total;
+      own += b.isize;
+    }
+    total += b.isize;
+  }
+  if (own_bytes != n_own) {
+    c->err = "bvcf_submit_bgzf: n_own does not fall on a block boundary";
+    return BVCF_E_ARG;
+  }
+  if (total > c->p.max_batch_bytes || total >= kMaxBlockBytes || n_comp >= kMaxBlockBytes) {
+    c->err = "bgzf batch inflates to more than max_batch_bytes";
+    return BVCF_E_TOO_BIG;
+  }
+  if (!skip_first_line && first_off > total) return BVCF_E_ARG;
+  Slot &s = c->slots[c->head];
+  int rc = alloc_results(c, s);
+  if (rc) return rc;
+  // ---- buffers of the compressed path, on first use / growth
+  const size_t nb = blocks.size();
+  if (!s.ev_cut) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_cut, hipEventDisableTiming));
+  if (!s.h_text) HIP_TRY(c, hipHostMalloc(&s.h_text, c->p.max_batch_bytes + BVCF_DEVICE_PAD, hipHostMallocDefault));
+  if (!s.d_cuts) {
+    HIP_TRY(c, hipMalloc(&s.d_cuts, 4 * sizeof(uint32_t)));
+    HIP_TRY(c, hipHostMalloc(&s.h_cuts, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  if (n_comp > s.cap_comp) {
+    hipFree(s.d_comp);
+    s.d_comp = nullptr;
+    s.cap_comp = 0;
+    const uint64_t want = std::max<uint64_t>(n_comp + n_comp / 4, 1u << 20);
+    HIP_TRY(c, hipMalloc(&s.d_comp, want + 64));
+    s.cap_comp = want;
+  }
+  if (nb > s.cap_bgzf_blocks) {
+    hipFree(s.d_bgzf);
+    hipHostFree(s.h_bgzf);
+    s.d_bgzf = nullptr;
+    s.h_bgzf = nullptr;
+    s.cap_bgzf_blocks = 0;
+    const uint64_t want = std::max<uint64_t>(nb + nb / 4, 4096);
+    HIP_TRY(c, hipMalloc(&s.d_bgzf, want * 7 * sizeof(uint32_t)));
+    HIP_TRY(c, hipHostMalloc(&s.h_bgzf, want * 5 * sizeof(uint32_t), hipHostMallocDefault));
+    s.cap_bgzf_blocks = want;
+  }
+  // descriptors (4 words per block), then the expected CRCs; status[] and crc[] follow on the device
+  BgzfDesc *h_desc = reinterpret_cast<BgzfDesc *>(s.h_bgzf);
+  uint32_t *h_crc = s.h_bgzf + 4 * nb;
+  uint64_t out_off = 0;
+  for (size_t i = 0; i < nb; i++) {
+    h_desc[i].in_off = blocks[i].in_off;
+    h_desc[i].in_len = blocks[i].in_len;
+    h_desc[i].out_off = (uint32_t)out_off;
+    h_desc[i].isize = blocks[i].isize;
+    h_crc[i] = blocks[i].crc;
+    out_off += blocks[i].isize;
+  }
+  BgzfDesc *d_desc = reinterpret_cast<BgzfDesc *>(s.d_bgzf);
+  uint32_t *d_want = s.d_bgzf + 4 * nb, *d_status = s.d_bgzf + 5 * nb, *d_crc = s.d_bgzf + 6 * nb;
+  HIP_TRY(c, hipMemcpyAsync(s.d_comp, comp, n_comp, hipMemcpyHostToDevice, s.stream));
+  HIP_TRY(c, hipMemcpyAsync(s.d_bgzf, s.h_bgzf, 5 * nb * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
+  launch_inflate(c->n_cu, s.d_comp, d_desc, (uint32_t)nb, s.d_in, d_status, d_crc, s.stream);
+  // the pad behind the text is read (and masked) by the scans: keep it defined
+  HIP_TRY(c, hipMemsetAsync(s.d_in + total, '\n', BVCF_DEVICE_PAD, s.stream));
+  CutArgs ca;
+  ca.text = s.d_in;
+  ca.total = (uint32_t)total;
+  ca.own = (uint32_t)own;
+  ca.skip_first = skip_first_line ? 1u : 0u;
+  ca.first_off = first_off;
+  ca.eol_byte = c->p.eol_byte;
+  ca.n_blocks = (uint32_t)nb;
+  ca.status = d_status;
+  ca.crc = d_crc;
+  ca.want_crc = d_want;
+  ca.out = s.d_cuts;
+  hipLaunchKernelGGL(k_cuts, dim3(1), dim3(kWave), 0, s.stream, ca);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(s.h_cuts, s.d_cuts, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+  HIP_TRY(c, hipEventRecord(s.ev_cut, s.stream));
+  s.await_cuts = true;
+  s.is_bgzf = true;
+  s.bgzf_rc = 0;
+  s.text_total = (uint32_t)total;
+  s.text_start = 0;
+  s.busy = true;
+  s.seq = batch_seq;
+  s.nbytes = 0;
+  c->head = (c->head + 1) % c->slots.size();
+  c->in_flight++;
+  return BVCF_OK;
+}
+
 int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   if (!c || !r) return BVCF_E_ARG;
   if (!c->in_flight) {
@@ -705,11 +905,26 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     c->tail = (c->tail + 1) % c->slots.size();
     c->in_flight--;
   };
+  const bool was_bgzf = s.is_bgzf;
+  {
+    const int rc2 = launch_after_cuts(c, s, true);
+    if (rc2) {
+      release();
+      return rc2;
+    }
+  }
   hipError_t e = hipEventSynchronize(s.ev_ctr);
   if (e != hipSuccess) {
     c->err = std::string("kernel chain failed: ") + hipGetErrorString(e);
     release();
     return BVCF_E_HIP;
+  }
+  if (s.bgzf_rc) {
+    const int rc2 = s.bgzf_rc;
+    c->err = s.bgzf_err ? s.bgzf_err : "bgzf: batch refused";
+    s.bgzf_rc = 0;
+    release();
+    return rc2;
   }
   memset(r, 0, sizeof *r);
   r->batch_seq = s.seq;
@@ -797,6 +1012,8 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   r->cmap = s.h_cmap;
   r->dosage = c->dosage_stride ? s.h_dosage : nullptr;
   r->dosage_stride = c->dosage_stride;
+  r->text = was_bgzf ? s.h_text : nullptr;
+  r->n_text_bytes = was_bgzf ? s.nbytes : 0;
   r->name_lists = names ? s.h_name_lists : nullptr;
   r->names = names ? s.h_names : nullptr;
   r->n_name_bytes = name_bytes;
@@ -838,36 +1055,6 @@ int bvcf_sum_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8]) {
     for (int k = 0; k < 8; k++) out[k] += ctxs[i]->totals[k];
   }
   return BVCF_OK;
-}
-
-// x^(8 * 1024 * 2^l) mod P for l = 0..5 (zlib's x2nmodp / multmodp, reflected CRC-32 polynomial): k_crc32's fold
-static CrcConsts crc_consts() {
-  auto mul = [](uint32_t a, uint32_t b) {
-    uint32_t p = 0;
-    for (int i = 31; i >= 0; i--) {
-      if ((a >> i) & 1u) p ^= b;
-      b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
-    }
-    return p;
-  };
-  uint32_t x = 0x40000000u;  // x^1
-  for (int k = 0; k < 13; k++) x = mul(x, x);  // x^(2^13)
-  CrcConsts kc;
-  for (int l = 0; l < 6; l++) {
-    kc.k[l] = x;
-    x = mul(x, x);
-  }
-  return kc;
-}
-
-// inflate + CRC of BGZF blocks whose compressed bytes are at d_comp (device): text to d_text.  desc/crc/status are
-// device arrays of n_blocks entries.
-static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_desc, uint32_t n_blocks, uint8_t *d_text,
-                           uint32_t *d_status, uint32_t *d_crc, hipStream_t st) {
-  static const CrcConsts kc = crc_consts();
-  const uint32_t grid = std::min<uint32_t>(n_blocks, (uint32_t)n_cu * 4u);
-  hipLaunchKernelGGL(k_inflate, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
-  hipLaunchKernelGGL(k_crc32, dim3(grid ? grid : 1), dim3(kWave), 0, st, (const uint8_t *)d_text, d_desc, n_blocks, kc, d_crc);
 }
 
 int bvcf_bgzf_inflate_device(int device, const uint8_t *comp, size_t n_comp, uint8_t *out, size_t cap, size_t *n_out) {

@@ -524,4 +524,86 @@ __global__ __launch_bounds__(kWave) void k_crc32(const uint8_t *text, const Bgzf
   }
 }
 
+// ------------------------------------------------------------------ where a batch of inflated text starts and ends
+// A batch is cut in the compressed domain (whole BGZF blocks), so its text begins and ends inside lines.  The line
+// that straddles the boundary to the next batch belongs to THIS batch: the caller appends the next batch's first
+// block(s) as look-ahead, and the text ends after the first terminator at or past the end of the batch's own blocks.
+// Accordingly the text before the first terminator of a batch that is not the stream's first belongs to the previous
+// batch and is skipped.  One wave; also folds the per-block inflate status and CRC comparison.
+struct CutArgs {
+  const uint8_t *text;
+  uint32_t total;        // bytes of text (own + look-ahead blocks)
+  uint32_t own;          // bytes the batch's own blocks inflate to
+  uint32_t skip_first;   // 1: start after the first terminator; 0: start at first_off
+  uint32_t first_off;
+  uint32_t eol_byte;
+  uint32_t n_blocks;
+  const uint32_t *status, *crc, *want_crc;
+  uint32_t *out;         // {start, end, flags, first bad block}
+};
+enum { kCutInflateError = 1, kCutCrcMismatch = 2, kCutNoTerminator = 4 };
+
+__global__ __launch_bounds__(kWave) void k_cuts(CutArgs c) {
+  const int lane = lane_id();
+  // first terminator at a position >= from, or kNoPos
+  constexpr uint32_t kNoPos = 0xFFFFFFFFu;
+  auto first_eol = [&](uint32_t from) -> uint32_t {
+    for (uint32_t base = from & ~15u; base < c.total; base += kChunk) {
+      const uint32_t off = base + 16u * lane;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (off + 16u <= c.total) {
+        v = *reinterpret_cast<const u32x4_u *>(c.text + off);
+      } else if (off < c.total) {
+        // the last, partial piece
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        for (uint32_t i = 0; i < c.total - off; i++) {
+          const uint32_t b = (uint32_t)c.text[off + i] << (8u * (i & 3u));
+          if (i < 4) w0 |= b; else if (i < 8) w1 |= b; else if (i < 12) w2 |= b; else w3 |= b;
+        }
+        v = u32x4{w0, w1, w2, w3};
+      }
+      uint32_t m = eq_mask16(v, c.eol_byte) & bits_until(c.total, off);
+      if (off < from) m &= ~bits_until(from, off);
+      const unsigned long long b = __ballot(m != 0);
+      if (b) {
+        const int src = __ffsll((long long)b) - 1;
+        return lane_value(off + __ffs(m) - 1, src);
+      }
+    }
+    return kNoPos;
+  };
+  uint32_t flags = 0, bad_block = kNoPos;
+  for (uint32_t base = 0; base < c.n_blocks; base += kWave) {
+    const uint32_t i = base + lane;
+    const bool inf_bad = i < c.n_blocks && c.status[i] != kInfOk;
+    const bool crc_bad = i < c.n_blocks && !inf_bad && c.crc[i] != c.want_crc[i];
+    const unsigned long long bi = __ballot(inf_bad), bc = __ballot(crc_bad);
+    if (bi) flags |= kCutInflateError;
+    if (bc) flags |= kCutCrcMismatch;
+    if ((bi | bc) && bad_block == kNoPos) bad_block = base + (uint32_t)__ffsll((long long)(bi | bc)) - 1u;
+  }
+  uint32_t start = c.first_off, end = c.total;
+  if (c.skip_first) {
+    const uint32_t e = first_eol(0);
+    start = e == kNoPos ? c.total : e + 1u;
+  }
+  if (c.own < c.total) {  // there is look-ahead: the batch ends with the line that straddles `own`
+    // (the next batch skips everything up to the first terminator of ITS text, i.e. at or after `own`: even when
+    // this batch's own text happens to end on a line boundary, the following line is this batch's)
+    const uint32_t e = first_eol(c.own);
+    if (e == kNoPos) {
+      flags |= kCutNoTerminator;
+    } else {
+      end = e + 1u;
+    }
+  }
+  if (start > end) start = end;
+  if (lane == 0) {
+    c.out[0] = start;
+    c.out[1] = end;
+    c.out[2] = flags;
+    c.out[3] = bad_block;
+  }
+}
+
 }  // namespace bvcf_dev

@@ -210,6 +210,10 @@ typedef struct {
   const bvcf_names *name_lists;
   const char *names;
   uint64_t n_name_bytes;
+  /* bvcf_submit_bgzf: the inflated text of the batch, from its first line on (lines[].off are offsets into it);
+   * NULL for batches submitted as text */
+  const uint8_t *text;
+  uint64_t n_text_bytes;
 } bvcf_result;
 
 /* ---- lifecycle ---- */
@@ -234,6 +238,22 @@ void bvcf_free_pinned(void *p);
 int bvcf_submit(bvcf_ctx *ctx, const uint8_t *block, size_t nbytes, uint64_t batch_seq);
 /* same, block already resident on ctx's device; it must own BVCF_DEVICE_PAD bytes past nbytes */
 int bvcf_submit_device(bvcf_ctx *ctx, const void *dblock, size_t nbytes, uint64_t batch_seq);
+/* A batch given as BGZF blocks (bgzip / htslib .vcf.gz): the compressed bytes cross to the device and are inflated
+ * and CRC-checked there (one wavefront per block), so no host core inflates and PCIe carries a fraction of the text.
+ * comp holds whole BGZF blocks, n_own bytes of which are the batch's own; the blocks after them are look-ahead (the
+ * next batch's first blocks, which that batch submits again as its own).  Batches are cut in the compressed domain,
+ * so their text begins and ends inside lines; the rule that makes every line belong to exactly one batch:
+ *   - the batch's text ends after the first terminator at or past the end of its own blocks' text (found in the
+ *     look-ahead; without look-ahead -- the stream's last batch -- it ends where the text ends);
+ *   - skip_first_line != 0: the text before the batch's first terminator belongs to the previous batch and is skipped;
+ *     skip_first_line == 0: the batch starts at byte first_off of its text (the stream's first batch: first_off is
+ *     where the data lines begin).
+ * bvcf_collect then also returns the text the line offsets refer to (bvcf_result.text: a pinned host copy).  Errors
+ * surface at bvcf_collect: BVCF_E_FATAL for a corrupt block (inflate error or CRC mismatch) and for a line that does
+ * not end within the look-ahead (give more look-ahead blocks).  The text of own + look-ahead blocks must fit
+ * max_batch_bytes. */
+int bvcf_submit_bgzf(bvcf_ctx *ctx, const uint8_t *comp, size_t n_comp, size_t n_own, int skip_first_line,
+                     uint32_t first_off, uint64_t batch_seq);
 /* blocks until the oldest submitted batch is done */
 int bvcf_collect(bvcf_ctx *ctx, bvcf_result *r);
 /* 1 = census path, 2 = streaming path (see bvcf_params.path) */

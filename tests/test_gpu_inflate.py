@@ -126,3 +126,82 @@ def test_reference_regression_file_is_bgzf_compatible(bv, golden_1kg):
     comp = bgzf.bgzf_compress(part, level=1)
     rc, text, n = bv.bgzf_inflate_device(comp, cap=len(part) + 64)
     assert rc == 0 and text == part
+
+
+def _bgzf_blocks(data, block, level=6):
+    return [bgzf.bgzf_block(data[i:i + block], level) for i in range(0, len(data), block)]
+
+
+@pytest.mark.parametrize("ns,block,per_batch,look", [(2504, 0xFF00, 5, 1), (300, 3000, 7, 2), (40, 700, 3, 6), (2504, 20000, 1, 2)])
+def test_submit_bgzf_batches_cover_every_line_once(bv, ns, block, per_batch, look):
+    """a VCF body cut into batches of BGZF blocks at arbitrary byte positions: own blocks + look-ahead, skip-first-line
+    on all but the first batch.  Every line must come out exactly once, in order, with the records of a text submit."""
+    import vcfgen
+    vcf = vcfgen.gen_vcf(ns, 300 if ns > 1000 else 2000, ns, weird=0.02)
+    body = vcf[vcf.index(b"\n", vcf.index(b"#CHROM")) + 1:]
+    # a junk prefix stands for the header lines that share the first block with the data
+    prefix = b"##junk header bytes\n#CHROM\tPOS\n"
+    blocks = _bgzf_blocks(prefix + body, block)
+    ctx_t = bv.Ctx(9 + ns, allow="", max_batch_bytes=len(body) + 4096)
+    want = ctx_t.process(body)
+    ctx_t.close()
+    want_lines = [body[int(L["off"]):int(L["off"]) + int(L["len"])] for L in want.lines]
+    ctx = bv.Ctx(9 + ns, allow="", max_batch_bytes=max(1 << 20, (per_batch + look + 1) * (block + 64)), n_slots=3)
+    got_lines, got_recs, pending = [], [], []
+
+    def collect():
+        b = ctx.collect()
+        for i, L in enumerate(b.lines):
+            got_lines.append(b.text[int(L["off"]):int(L["off"]) + int(L["len"])])
+            got_recs.append([(int(r["alt_idx"]), int(r["ac"]), int(r["an"]), int(r["n_het"]), int(r["n_hom"]), int(r["n_miss"]))
+                             for r in b.records(i)] if L["status"] == 0 else None)
+
+    for b0 in range(0, len(blocks), per_batch):
+        own = blocks[b0:b0 + per_batch]
+        ahead = blocks[b0 + per_batch:b0 + per_batch + look]
+        comp = b"".join(own + ahead)
+        if len(pending) == 2:
+            collect()
+            pending.pop(0)
+        ctx.submit_bgzf(comp, sum(len(x) for x in own), skip_first_line=b0 > 0, first_off=len(prefix) if b0 == 0 else 0, seq=b0)
+        pending.append(b0)
+    while pending:
+        collect()
+        pending.pop(0)
+    ctx.close()
+    assert got_lines == want_lines
+    want_recs = [[(int(r["alt_idx"]), int(r["ac"]), int(r["an"]), int(r["n_het"]), int(r["n_hom"]), int(r["n_miss"]))
+                  for r in want.records(i)] if want.lines[i]["status"] == 0 else None for i in range(len(want.lines))]
+    assert got_recs == want_recs
+
+
+def test_submit_bgzf_errors(bv):
+    import vcfgen
+    ns = 50
+    vcf = vcfgen.gen_vcf(5, 400, ns)
+    body = vcf[vcf.index(b"\n", vcf.index(b"#CHROM")) + 1:]
+    blocks = _bgzf_blocks(body, 2000)
+    ctx = bv.Ctx(9 + ns, allow="", max_batch_bytes=1 << 20)
+    # a corrupt own block is refused at collect, and the ctx stays usable
+    bad = bytearray(blocks[1])
+    bad[30] ^= 0x55
+    ctx.submit_bgzf(blocks[0] + bytes(bad) + blocks[2], len(blocks[0]) + len(bad), False)
+    with pytest.raises(bv.BvcfError) as ei:
+        ctx.collect()
+    assert ei.value.rc == bv.E_FATAL and "bgzf" in str(ei.value)
+    # a line that does not end within the look-ahead
+    long_line = b"1\t5\t.\tA\tG\t.\tPASS\t" + b"X" * 9000 + b"\n"
+    lb = _bgzf_blocks(body[:3000] + long_line + body[3000:6000], 1500)
+    ctx.submit_bgzf(b"".join(lb[:3]), len(lb[0]) + len(lb[1]), False)
+    with pytest.raises(bv.BvcfError) as ei:
+        ctx.collect()
+    assert ei.value.rc == bv.E_FATAL and "look-ahead" in str(ei.value)
+    # n_own off a block boundary, not BGZF
+    with pytest.raises(bv.BvcfError):
+        ctx.submit_bgzf(blocks[0] + blocks[1], len(blocks[0]) + 3, False)
+    with pytest.raises(bv.BvcfError):
+        ctx.submit_bgzf(b"plain text\n", 5, False)
+    ctx.submit_bgzf(b"".join(blocks), sum(len(x) for x in blocks), False)
+    b = ctx.collect()
+    assert len(b.lines) == body.count(b"\n")
+    ctx.close()
