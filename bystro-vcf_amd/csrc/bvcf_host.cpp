@@ -4,6 +4,7 @@
 // Nothing here computes what the kernels compute: rows are assembled from bvcf_result only.
 #include "../../include/bvcf.h"
 #include "bvcf_input.h"
+#include "bvcf_bgzf.h"
 
 #include <errno.h>
 #include <fcntl.h>
@@ -11,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -779,6 +781,17 @@ struct Block {
   size_t fill = 0;           // bytes read into buf (preamble parsing needs this on the first block)
   bool first = false, last = false, too_long = false, read_error = false;
   uint64_t seq = 0;          // block number: the order of the output
+  // BGZF input inflated on the device: buf[0, nb) holds whole compressed blocks, the first `own` bytes of them the
+  // batch's own, the rest look-ahead (bvcf_submit_bgzf)
+  bool bgzf = false, skip_first = false;
+  size_t own = 0;
+  uint32_t first_off = 0;
+  // ... and what the reader learnt from the blocks it inflated itself to get at the header
+  struct Pre {
+    Preamble pre;
+    std::vector<uint8_t> sample;  // the first data lines, for prepare_run
+  };
+  std::shared_ptr<Pre> pre;
 };
 
 }  // namespace
@@ -1019,10 +1032,197 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   };
   std::atomic<uint8_t> eol_byte{'\n'};
 
-  // ---- reader: whole lines per block; the partial last line is carried into the next buffer
   std::string source_err;
+  std::atomic<bool> input_is_bgzf_device{false};
+  // ---- reader, BGZF on the device: whole compressed blocks per buffer.  The header has to be read here, so the
+  // leading blocks are inflated with zlib until the #CHROM line is complete; everything from the block that holds the
+  // first data line on is handed over compressed, each buffer with the next buffer's first blocks as look-ahead.
+  auto read_bgzf_raw = [&](bvcf_input::ByteSource &src) {
+    input_is_bgzf_device.store(true);
+    std::vector<uint8_t> pend;  // compressed bytes read from the input; pend[pp..] not yet handed over
+    size_t pp = 0;
+    bool raw_eof = false;
+    auto fail_read = [&](const std::string &m) {
+      source_err = m;
+      Block b;
+      b.read_error = true;
+      b.last = true;
+      ready_q.push(b);
+    };
+    auto more = [&]() -> bool {
+      if (raw_eof) return false;
+      if (pp > (32u << 20)) {
+        pend.erase(pend.begin(), pend.begin() + (ptrdiff_t)pp);
+        pp = 0;
+      }
+      const size_t old = pend.size(), step = 8u << 20;
+      pend.resize(old + step);
+      const ssize_t got = src.read_raw(pend.data() + old, step);
+      pend.resize(old + (got > 0 ? (size_t)got : 0));
+      if (got <= 0) {
+        raw_eof = true;
+        if (got < 0) source_err = src.error();
+        return false;
+      }
+      return true;
+    };
+    // the whole block at pend[pp + off]: its size; 0 at a clean end of input; -1 malformed / truncated / read error
+    auto block_at = [&](size_t off, bvcf_bgzf::Block *b) -> long {
+      for (;;) {
+        const size_t have = pend.size() - pp - off;
+        uint32_t xlen = 0;
+        const long bs = have ? bvcf_bgzf::block_size(pend.data() + pp + off, have, &xlen) : 0;
+        if (bs < 0) return -1;
+        if (bs > 0 && (size_t)bs <= have) {
+          std::vector<bvcf_bgzf::Block> one;
+          if (bvcf_bgzf::scan(pend.data() + pp + off, (size_t)bs, &one) != bs || one.size() != 1) return -1;
+          *b = one[0];
+          return bs;
+        }
+        if (!more()) return (!source_err.empty() || have) ? -1 : 0;
+      }
+    };
+    // ---- the header, from blocks inflated here
+    auto pre = std::make_shared<Block::Pre>();
+    std::vector<uint8_t> htext;
+    std::vector<std::pair<size_t, size_t>> marks;  // (compressed offset from pp, text offset) of each inflated block
+    size_t hoff = 0;
+    std::string msg;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return fail_read("inflateInit2 failed");
+    auto inflate_next = [&]() -> int {  // 1 = a block was inflated, 0 = end of input, -1 = bad
+      bvcf_bgzf::Block b;
+      const long bs = block_at(hoff, &b);
+      if (bs <= 0) return (int)bs;
+      marks.emplace_back(hoff, htext.size());
+      const size_t at = htext.size();
+      htext.resize(at + b.isize);
+      inflateReset(&zs);
+      zs.next_in = pend.data() + pp + hoff + b.in_off;
+      zs.avail_in = b.in_len;
+      zs.next_out = htext.data() + at;
+      zs.avail_out = b.isize;
+      const int zr = b.isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+      if ((b.isize && (zr != Z_STREAM_END || zs.avail_out != 0)) ||
+          (uint32_t)crc32(crc32(0L, Z_NULL, 0), htext.data() + at, b.isize) != b.crc)
+        return -1;
+      hoff += (size_t)bs;
+      return 1;
+    };
+    int pr = 1;
+    bool hdr_eof = false;
+    while (pr == 1) {
+      const int ir = inflate_next();
+      if (ir < 0) {
+        inflateEnd(&zs);
+        return fail_read(source_err.empty() ? std::string("bgzf: corrupt block (inflate or CRC mismatch)") : source_err);
+      }
+      hdr_eof = ir == 0;
+      pr = parse_preamble(htext.data(), htext.size(), hdr_eof, c->normalize_header, &pre->pre, &msg);
+      if (hdr_eof) break;
+    }
+    if (pr != 0) {
+      inflateEnd(&zs);
+      return fail_read(pr < 0 ? msg : std::string("No header found"));
+    }
+    const size_t data_off = pre->pre.data_off;
+    // a few data lines for prepare_run (path choice, reservation): make sure at least one whole line is in view
+    for (int extra = 0; extra < 8; extra++) {
+      if (memchr(htext.data() + data_off, pre->pre.eol_byte, htext.size() - data_off)) break;
+      if (inflate_next() != 1) break;
+    }
+    inflateEnd(&zs);
+    pre->sample.assign(htext.begin() + (ptrdiff_t)data_off, htext.end());
+    // the block that holds the first data byte (or the end of what was inflated)
+    size_t b0 = marks.size();
+    for (size_t i = 0; i < marks.size(); i++) {
+      const size_t t_end = i + 1 < marks.size() ? marks[i + 1].second : htext.size();
+      if (data_off < t_end) {
+        b0 = i;
+        break;
+      }
+    }
+    uint32_t first_off = 0;
+    if (b0 < marks.size()) {
+      first_off = (uint32_t)(data_off - marks[b0].second);
+      pp += marks[b0].first;
+    } else {
+      pp += hoff;
+    }
+    // look-ahead: the longest line must end within it.  Twice the first line, or 16 bytes per column.
+    size_t line_len = 16 * pre->pre.header.size() + 4096;
+    if (const uint8_t *e = (const uint8_t *)memchr(pre->sample.data(), pre->pre.eol_byte, pre->sample.size()))
+      line_len = std::max<size_t>(line_len, 2 * (size_t)(e - pre->sample.data()));
+    const size_t look = std::min<size_t>(line_len / 65280 + 2, std::max<size_t>(2, cap / (4 * 65536)));
+    const size_t text_limit = cap > (look + 1) * 65536 ? cap - (look + 1) * 65536 : cap / 2;
+    const size_t comp_limit = cap > (look + 1) * 66000 ? cap - (look + 1) * 66000 : cap / 2;
+
+    bool first = true;
+    for (;;) {
+      if (stop.load()) break;
+      Block b;
+      b.buf = free_q.pop();
+      if (!b.buf) break;
+      b.bgzf = true;
+      b.first = first;
+      b.skip_first = !first;
+      b.first_off = first ? first_off : 0;
+      if (first) b.pre = pre;
+      size_t off = 0, own_text = 0;
+      bool bad = false;
+      for (;;) {
+        bvcf_bgzf::Block k;
+        const long bs = block_at(off, &k);
+        if (bs < 0) bad = true;
+        if (bs <= 0) break;
+        if (off && (own_text + k.isize > text_limit || off + (size_t)bs > comp_limit)) break;
+        off += (size_t)bs;
+        own_text += k.isize;
+      }
+      size_t la = 0, la_text = 0;
+      for (size_t n = 0; n < look && !bad; n++) {
+        bvcf_bgzf::Block k;
+        const long bs = block_at(off + la, &k);
+        if (bs < 0) bad = true;
+        if (bs <= 0) break;
+        if (own_text + la_text + k.isize > cap || off + la + (size_t)bs > cap) break;
+        la += (size_t)bs;
+        la_text += k.isize;
+      }
+      if (bad) {
+        free_q.push(b.buf);
+        return fail_read(source_err.empty() ? std::string("bgzf: not a BGZF block, or a truncated file") : source_err);
+      }
+      if (off) memcpy(b.buf, pend.data() + pp, off + la);
+      b.nb = off + la;
+      b.own = off;
+      pp += off;
+      // the stream ends with this buffer if nothing follows its own blocks
+      b.last = la == 0 && raw_eof && pend.size() == pp;
+      if (b.last) stop_alloc.store(true);
+      first = false;
+      const bool last = b.last;
+      ready_q.push(b);
+      if (last) return;
+    }
+    Block end;
+    end.last = true;
+    ready_q.push(end);
+  };
+
+  // ---- reader: whole lines per block; the partial last line is carried into the next buffer
   std::thread reader([&]() {
     bvcf_input::ByteSource src(fd_in, std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
+    {
+      // BGZF input (bgzip / htslib .vcf.gz): the blocks go to the device compressed and are inflated there
+      // (bvcf_submit_bgzf) unless BVCF_DEVICE_INFLATE=0 (then this thread's workers inflate them with zlib)
+      const char *e = getenv("BVCF_DEVICE_INFLATE");
+      if (!(e && *e == '0') && src.sniff_bgzf()) {
+        read_bgzf_raw(src);
+        return;
+      }
+    }
     std::vector<uint8_t> carry;
     bool first = true, eof = false;
     while (!eof && !stop.load()) {
@@ -1220,8 +1420,11 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
         }
         r = bvcf_reserve(W->ctx, res.need_lines + res.need_lines / 4 + 64, res.need_alleles + res.need_alleles / 4 + 64,
                          res.need_cmap_bytes + res.need_cmap_bytes / 4 + 4096);
-        for (size_t k = 0; k < in_flight.size() && r == BVCF_OK; k++)
-          r = bvcf_submit(W->ctx, in_flight[k].buf + in_flight[k].start, in_flight[k].nb, in_flight[k].seq);
+        for (size_t k = 0; k < in_flight.size() && r == BVCF_OK; k++) {
+          const Block &q = in_flight[k];
+          r = q.bgzf ? bvcf_submit_bgzf(W->ctx, q.buf, q.nb, q.own, q.skip_first, q.first_off, q.seq)
+                     : bvcf_submit(W->ctx, q.buf + q.start, q.nb, q.seq);
+        }
         if (r == BVCF_OK) {
           r = bvcf_collect(W->ctx, &res);
           n_collects++;
@@ -1259,7 +1462,8 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       if (in_flight.size() >= 2) finish_oldest();
       if (failed.load()) continue;
       const double ts = now_s();
-      const int r = bvcf_submit(W->ctx, b.buf + b.start, b.nb, b.seq);
+      const int r = b.bgzf ? bvcf_submit_bgzf(W->ctx, b.buf, b.nb, b.own, b.skip_first, b.first_off, b.seq)
+                           : bvcf_submit(W->ctx, b.buf + b.start, b.nb, b.seq);
       if (!W->n_blocks) W->t_first_submit = now_s() - t_start;
       W->t_submit += now_s() - ts;
       if (r) {
@@ -1289,7 +1493,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
         }
       }
       if (!ps) ps = new Parts();
-      const uint8_t *text = j.b.buf + j.b.start;
+      const uint8_t *text = j.b.bgzf ? j.res.text : j.b.buf + j.b.start;  // (inflated on the device: the copy that came back)
       std::string jlog;
       format_log(&j.res, text, jlog);
       if (R.want_rows)
@@ -1326,6 +1530,24 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     t_wait_read += now_s() - t0;
     if (b.read_error) fail(source_err.empty() ? std::string("read error") : source_err, BVCF_E_FATAL);
     if (b.too_long) fail("a line is longer than max_batch_bytes", BVCF_E_TOO_BIG);
+    if (!failed.load() && b.buf && !have_pre && b.bgzf) {
+      // BGZF on the device: the reader inflated the header blocks itself
+      t0 = now_s();
+      if (!b.pre) {
+        fail("internal: BGZF block without its header", BVCF_E_FATAL);
+      } else {
+        R.pre = b.pre->pre;
+        have_pre = true;
+        int r = prepare_run(R, &msg, b.pre->sample.data(), b.pre->sample.size());
+        if (r) fail(msg, r);
+        if (!failed.load() && R.pre.header.size() == 9) {
+          const char *m = "Found 9 header fields. When genotypes present, we expect 1+ samples after FORMAT (10 fields minimum)\n";
+          write_all(fd_err, m, strlen(m));
+        }
+      }
+      t_prepare = now_s() - t0;
+      t_init += t_prepare;
+    }
     if (!failed.load() && b.buf && !have_pre) {
       t0 = now_s();
       int pr = parse_preamble(b.buf, b.fill, true, c->normalize_header, &R.pre, &msg);
@@ -1451,8 +1673,9 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       num("wait_for_formatter_max_s", t_fmt_wait);
       num("formatter_busy_s", t_fmt);
       num("teardown_s", now_s() - t_end0);
-      j.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "\"lines_in\": %llu, \"devices_used\": %zu, \"count_gather\": \"%s\", ",
-                                     (unsigned long long)lines_in.load(), used, used_rccl ? "rccl" : "host"));
+      j.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "\"lines_in\": %llu, \"devices_used\": %zu, \"count_gather\": \"%s\", \"input\": \"%s\", ",
+                                     (unsigned long long)lines_in.load(), used, used_rccl ? "rccl" : "host",
+                                     input_is_bgzf_device.load() ? "bgzf, inflated on the device" : "text, gzip or bgzf through the host"));
       j.append("\"devices\": [");
       for (size_t d = 0; d < n_dev; d++)
         j.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "%s{\"device\": %d, \"blocks\": %llu, \"bytes\": %llu, \"gpu_wait_s\": %.6f}",

@@ -97,17 +97,30 @@ bool ByteSource::fill_compressed() {
   return got_total > 0;
 }
 
-ssize_t ByteSource::read(uint8_t *dst, size_t cap) {
-  if (!err_.empty()) return -1;
+bool ByteSource::sniff_bgzf() {
   if (kind_ == kUnknown) {
     while (cbuf_.size() < 18 && fill_compressed()) {
     }
-    if (!err_.empty()) return -1;
+    if (!err_.empty()) return false;
     kind_ = kText;
     if (cbuf_.size() >= 2 && cbuf_[0] == 0x1f && cbuf_[1] == 0x8b) {
       uint32_t xlen;
       kind_ = bgzf_block_size(cbuf_.data(), cbuf_.size(), &xlen) != -1 ? kBgzf : kGzip;
     }
+  }
+  return kind_ == kBgzf;
+}
+
+ssize_t ByteSource::read_raw(uint8_t *dst, size_t cap) {
+  if (!err_.empty()) return -1;
+  return read_text(dst, cap);  // what the sniffing buffered, then the fd itself (parallel pread for files)
+}
+
+ssize_t ByteSource::read(uint8_t *dst, size_t cap) {
+  if (!err_.empty()) return -1;
+  if (kind_ == kUnknown) {
+    sniff_bgzf();
+    if (!err_.empty()) return -1;
   }
   switch (kind_) {
     case kGzip: return read_gzip(dst, cap);

@@ -30,7 +30,12 @@ class ByteSource {
   static constexpr ssize_t kNoRoom = -2;
   ssize_t read(uint8_t *dst, size_t cap);
   const std::string &error() const { return err_; }
-  const char *kind() const;  // "text", "gzip" or "bgzf" (after the first read)
+  const char *kind() const;  // "text", "gzip" or "bgzf" (after the first read / sniff)
+  // Looks at the first bytes without consuming them: true if the input is BGZF (block-gzip).
+  bool sniff_bgzf();
+  // The raw (still compressed) bytes of the input, for a caller that inflates elsewhere (the device): up to cap bytes,
+  // 0 at end of input, -1 on error.
+  ssize_t read_raw(uint8_t *dst, size_t cap);
 
  private:
   enum Kind { kUnknown, kText, kGzip, kBgzf };

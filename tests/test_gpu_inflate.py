@@ -205,3 +205,67 @@ def test_submit_bgzf_errors(bv):
     b = ctx.collect()
     assert len(b.lines) == body.count(b"\n")
     ctx.close()
+
+
+def _cli(args, data, env=None):
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bystro-vcf_amd", "bystro-vcf")
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([exe] + args, input=data, capture_output=True, timeout=600, env=e)
+
+
+@pytest.mark.parametrize("ns,n_lines,block,batch_mb,devices", [
+    (150, 4000, 0xFF00, 1, "0"), (150, 4000, 777, 1, "0,0"), (2504, 600, 30000, 2, "0"), (0, 30000, 5000, 1, "0,0,0"),
+    (40000, 24, 0xFF00, 8, "0"),
+])
+def test_cli_bgzf_on_device_equals_text_input(bv, ns, n_lines, block, batch_mb, devices):
+    """the CLI over BGZF input: blocks inflated on the device (default) and by the host's zlib workers
+    (BVCF_DEVICE_INFLATE=0) must both give the text input's bytes; small blocks and batches make every batch start and
+    end inside a line; 40 000 samples: lines of 160 KB span three BGZF blocks"""
+    import json
+    import vcfgen
+    vcf = vcfgen.gen_vcf(900 + ns % 97, n_lines, ns, weird=0.02)
+    want = _cli(["--keepId", "--batchMB", str(batch_mb)], vcf)
+    assert want.returncode == 0
+    data = bgzf.bgzf_compress(vcf, block=block, level=1, eof_marker=block != 777)
+    for dev_inf in ("1", "0"):
+        p = _cli(["--keepId", "--batchMB", str(batch_mb), "--devices", devices], data,
+                 {"BVCF_DEVICE_INFLATE": dev_inf, "BVCF_TIMING": "json"})
+        assert p.returncode == 0, (dev_inf, p.stderr[-300:])
+        assert p.stdout == want.stdout, dev_inf
+        log = [ln for ln in p.stderr.decode().splitlines() if not ln.startswith("[bvcf timing")]
+        assert "\n".join(log) == want.stderr.decode().rstrip("\n"), dev_inf
+        t = [json.loads(ln.split("] ", 1)[1]) for ln in p.stderr.decode().splitlines() if ln.startswith("[bvcf timing-json]")][0]
+        assert ("device" in t["input"]) == (dev_inf == "1")
+        assert t["lines_in"] == vcf[vcf.index(b"\n", vcf.index(b"#CHROM")) + 1:].count(b"\n")
+
+
+def test_cli_bgzf_edge_files(bv, golden_1kg):
+    import vcfgen
+    hdr = vcfgen.header(3).encode()
+    # header only; header + unterminated line; data starting exactly at a block boundary; header spread over blocks
+    for vcf, blk in ((hdr, 0xFF00), (hdr + b"1\t5\t.\tA\tG\t.\tPASS\t.\tGT\t0|1\t1|1\t0|0", 0xFF00), (hdr + b"1\t5\t.\tA\tG\t.\tPASS\t.\tGT\t0|1\t1|1\t0|0\n" * 50, len(hdr)),
+                     (hdr + b"1\t5\t.\tA\tG\t.\tPASS\t.\tGT\t0|1\t1|1\t0|0\n" * 50, 13)):
+        want = _cli([], vcf)
+        p = _cli([], bgzf.bgzf_compress(vcf, block=blk))
+        assert p.returncode == want.returncode == 0 and p.stdout == want.stdout and p.stderr == want.stderr
+    # fatal paths keep their messages
+    p = _cli([], bgzf.bgzf_compress(b"not a vcf\n"))
+    assert p.returncode == 1 and b"Not a VCF file" in p.stderr
+    p = _cli([], bgzf.bgzf_compress(b"##fileformat=VCFv4.2\n##x\n"))
+    assert p.returncode == 1 and b"No header found" in p.stderr
+    # damage past the header: refused with a message, exit status 1
+    vcf = vcfgen.gen_vcf(3, 3000, 100)
+    data = bytearray(bgzf.bgzf_compress(vcf, block=4000))
+    data[len(data) // 2] ^= 0x10
+    p = _cli([], bytes(data))
+    assert p.returncode == 1 and b"bgzf" in p.stderr
+    p = _cli([], bgzf.bgzf_compress(vcf, block=4000)[:-100])
+    assert p.returncode == 1 and b"bgzf" in p.stderr
+    # the reference's regression input, BGZF-compressed: the golden rows
+    vcf, want_sorted, hdr_line = golden_1kg
+    p = _cli(["--batchMB", "16"], bgzf.bgzf_compress(vcf, level=1))
+    assert p.returncode == 0
+    rows = p.stdout.split(b"\n")
+    assert rows[0] == hdr_line and sorted(rows[1:-1]) == want_sorted
