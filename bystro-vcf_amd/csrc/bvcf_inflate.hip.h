@@ -426,21 +426,25 @@ __global__ __launch_bounds__(kInfThreads) void k_inflate(const uint8_t *comp, co
         {
           const uint32_t from = pos - dist;
           uint8_t v[5];
-          // read all source bytes first: a piece that wraps into what this match writes is the periodic case
+          // read all source bytes first: a piece that wraps into what this match writes is the periodic case.
+          // i mod dist for i < 320, dist < 258 from a float reciprocal: (i + 0.5) / dist is never within 0.002 of an
+          // integer, the product's error stays below 0.0004
+          const bool periodic = dist < len;
+          const float inv = 1.0f / (float)dist;
 #pragma unroll
           for (uint32_t r = 0; r < 5; r++) {
             const uint32_t i = lane + r * kWave;
-            uint32_t k = i;
-            // i mod dist for i < 320, dist < 258: the quotient from a float division ((i + 0.5) / dist is never within
-            // 0.002 of an integer)
-            if (dist < len && i >= dist) k = i - dist * (uint32_t)(((float)i + 0.5f) / (float)dist);
-            v[r] = i < len ? S.win[(from + k) & (kInfWindow - 1u)] : (uint8_t)0;
+            if (r * kWave < len) {
+              uint32_t k = i;
+              if (periodic && i >= dist) k = i - dist * (uint32_t)(((float)i + 0.5f) * inv);
+              v[r] = i < len ? S.win[(from + k) & (kInfWindow - 1u)] : (uint8_t)0;
+            }
           }
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (uint32_t r = 0; r < 5; r++) {
             const uint32_t i = lane + r * kWave;
-            if (i < len) S.win[(pos + i) & (kInfWindow - 1u)] = v[r];
+            if (r * kWave < len && i < len) S.win[(pos + i) & (kInfWindow - 1u)] = v[r];
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -482,12 +486,22 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {  // zli
 
 __global__ __launch_bounds__(kWave) void k_crc32(const uint8_t *text, const BgzfDesc *desc, uint32_t n_blocks, CrcConsts kc,
                                                  uint32_t *crc_out) {
-  __shared__ uint32_t s_tab[256];
+  __shared__ uint32_t s_tab4[4][256];  // slicing-by-4: table j = the CRC of a byte followed by j zero bytes
+  uint32_t *s_tab = s_tab4[0];
   const int lane = lane_id();
   for (uint32_t i = lane; i < 256; i += kWave) {
     uint32_t c = i;
     for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-    s_tab[i] = c;
+    s_tab4[0][i] = c;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = lane; i < 256; i += kWave) {
+    uint32_t c = s_tab4[0][i];
+    for (int j = 1; j < 4; j++) {
+      c = s_tab4[0][c & 0xFFu] ^ (c >> 8);
+      s_tab4[j][i] = c;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -499,12 +513,20 @@ __global__ __launch_bounds__(kWave) void k_crc32(const uint8_t *text, const Bgzf
     const uint32_t v_lo = (uint32_t)lane * 1024u, v_hi = v_lo + 1024u;
     uint32_t crc = 0;
     // the lane's real bytes: virtual [max(v_lo, pad), v_hi) -> real offsets - pad
-    for (uint32_t v = max(v_lo, pad); v < v_hi; v++) {
+    uint32_t v = max(v_lo, pad);
+    // up to the first real offset that is a multiple of 4 (and past the inverted first four bytes), byte by byte
+    for (; v < v_hi && (((v - pad) & 3u) != 0u || v - pad < 4u); v++) {
       const uint32_t r = v - pad;
       uint32_t b = p[r];
       if (r < 4u) b ^= 0xFFu;  // the 0xFFFFFFFF start value
       crc = s_tab[(crc ^ b) & 0xFFu] ^ (crc >> 8);
     }
+    for (; v + 4u <= v_hi; v += 4u) {  // four bytes per step
+      typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+      const uint32_t w = *reinterpret_cast<const u32_unaligned *>(p + (v - pad)) ^ crc;  // (text + out_off + r: r % 4 == 0; out_off may be odd)
+      crc = s_tab4[3][w & 0xFFu] ^ s_tab4[2][(w >> 8) & 0xFFu] ^ s_tab4[1][(w >> 16) & 0xFFu] ^ s_tab4[0][w >> 24];
+    }
+    for (; v < v_hi; v++) crc = s_tab[(crc ^ p[v - pad]) & 0xFFu] ^ (crc >> 8);
     // inclusive scan: after step l a lane holds the CRC of up to 2^(l+1) KiB ending with its own
 #pragma unroll
     for (int l = 0; l < 6; l++) {

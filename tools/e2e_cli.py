@@ -111,7 +111,7 @@ def main():
                 sys.exit(1)
     finally:
         for q in (text_path, text_path + ".gz", path + ".arrow"):
-            if os.path.exists(q) and not (keep and q == text_path):
+            if os.path.exists(q) and not (keep and q in (text_path, text_path + ".gz")):
                 os.unlink(q)
 
 
