@@ -475,7 +475,13 @@ static CrcConsts crc_consts() {
 static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_desc, uint32_t n_blocks, uint8_t *d_text,
                            uint32_t *d_status, uint32_t *d_crc, hipStream_t st) {
   static const CrcConsts kc = crc_consts();
-  const uint32_t grid = std::min<uint32_t>(n_blocks, (uint32_t)n_cu * 4u);
+  static const int per_cu = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_inflate, kInfThreads, 0) != hipSuccess || n < 1) n = 4;
+    if (getenv("BVCF_DEBUG")) fprintf(stderr, "[bvcf debug] k_inflate: %d workgroups per CU, %zu bytes of LDS each\n", n, sizeof(InfLds));
+    return n;
+  }();
+  const uint32_t grid = std::min<uint32_t>(n_blocks, (uint32_t)n_cu * (uint32_t)per_cu);
   hipLaunchKernelGGL(k_inflate, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
   hipLaunchKernelGGL(k_crc32, dim3(grid ? grid : 1), dim3(kWave), 0, st, (const uint8_t *)d_text, d_desc, n_blocks, kc, d_crc);
 }
