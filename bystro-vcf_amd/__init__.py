@@ -64,7 +64,7 @@ class Config(C.Structure):
         ("empty_field", C.c_char_p), ("field_delimiter", C.c_char_p), ("allow_filter", C.c_char_p),
         ("exclude_filter", C.c_char_p), ("keep_id", C.c_uint8), ("keep_info", C.c_uint8),
         ("keep_pos", C.c_uint8), ("keep_qual", C.c_uint8), ("normalize_header", C.c_uint8),
-        ("reserved", C.c_uint8 * 3), ("device", C.c_int32), ("n_format_threads", C.c_uint32),
+        ("leave_teardown_to_exit", C.c_uint8), ("reserved", C.c_uint8 * 2), ("device", C.c_int32), ("n_format_threads", C.c_uint32),
         ("max_batch_bytes", C.c_uint64), ("sample_list_path", C.c_char_p),
         ("dosage_path", C.c_char_p), ("no_out", C.c_uint8), ("reserved3", C.c_uint8 * 3),
         ("n_devices", C.c_uint32), ("devices", C.POINTER(C.c_int32)),

@@ -1635,9 +1635,10 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       }
     if (!live.empty() && rc == BVCF_OK && bvcf_allreduce_counters(live.data(), (int)live.size(), totals, &used_rccl) != BVCF_OK)
       bvcf_sum_counters(live.data(), (int)live.size(), totals);  // the summary is informational: never fail the run on it
-    for (bvcf_ctx *x : live) bvcf_destroy(x);
+    if (!c->leave_teardown_to_exit)
+      for (bvcf_ctx *x : live) bvcf_destroy(x);
   }
-  free_bufs();
+  if (!c->leave_teardown_to_exit) free_bufs();
   if (timing) {
     const double t_total = now_s() - t_start;
     double t_ctx = 0, t_gpu = 0, t_submit = 0, t_fmt_wait = 0, t_first = 0;

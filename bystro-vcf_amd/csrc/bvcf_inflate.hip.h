@@ -420,34 +420,43 @@ __global__ __launch_bounds__(kInfThreads) void k_inflate(const uint8_t *comp, co
           err = kInfOutputOverrun;
           break;
         }
-        // ---- the match, by all lanes: byte i comes from the `dist` bytes before pos, repeated
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // ---- the match, by all lanes, four bytes per lane and step: byte j comes from the `dist` bytes before pos,
+        // repeated.  (LDS operations of one wave execute in order: the bytes earlier symbols wrote are there.)
         __builtin_amdgcn_wave_barrier();
         {
           const uint32_t from = pos - dist;
-          uint8_t v[5];
-          // read all source bytes first: a piece that wraps into what this match writes is the periodic case.
-          // i mod dist for i < 320, dist < 258 from a float reciprocal: (i + 0.5) / dist is never within 0.002 of an
-          // integer, the product's error stays below 0.0004
           const bool periodic = dist < len;
           const float inv = 1.0f / (float)dist;
-#pragma unroll
-          for (uint32_t r = 0; r < 5; r++) {
-            const uint32_t i = lane + r * kWave;
-            if (r * kWave < len) {
-              uint32_t k = i;
-              if (periodic && i >= dist) k = i - dist * (uint32_t)(((float)i + 0.5f) * inv);
-              v[r] = i < len ? S.win[(from + k) & (kInfWindow - 1u)] : (uint8_t)0;
+          for (uint32_t base = 0; base < len; base += 4u * kWave) {
+            const uint32_t j0 = base + 4u * lane;
+            if (j0 < len) {
+              uint32_t w;
+              if (!periodic) {
+                // source and destination do not overlap: four source bytes from two aligned words of the ring
+                const uint32_t a = (from + j0) & (kInfWindow - 1u);
+                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(&S.win[a & ~3u]);
+                const uint32_t w1 = *reinterpret_cast<const uint32_t *>(&S.win[(a + 4u) & (kInfWindow - 1u) & ~3u]);
+                w = __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+              } else {
+                // j mod dist for j < 260, dist < 258 from a float reciprocal ((j + 0.5) / dist is never within 0.002
+                // of an integer, the product's error stays below 0.0004); the next three by stepping
+                uint32_t k = j0 - dist * (uint32_t)(((float)j0 + 0.5f) * inv);
+                w = S.win[(from + k) & (kInfWindow - 1u)];
+                k = k + 1u == dist ? 0u : k + 1u;
+                w |= (uint32_t)S.win[(from + k) & (kInfWindow - 1u)] << 8;
+                k = k + 1u == dist ? 0u : k + 1u;
+                w |= (uint32_t)S.win[(from + k) & (kInfWindow - 1u)] << 16;
+                k = k + 1u == dist ? 0u : k + 1u;
+                w |= (uint32_t)S.win[(from + k) & (kInfWindow - 1u)] << 24;
+              }
+              const uint32_t o = pos + j0;
+              S.win[o & (kInfWindow - 1u)] = (uint8_t)w;
+              if (j0 + 1u < len) S.win[(o + 1u) & (kInfWindow - 1u)] = (uint8_t)(w >> 8);
+              if (j0 + 2u < len) S.win[(o + 2u) & (kInfWindow - 1u)] = (uint8_t)(w >> 16);
+              if (j0 + 3u < len) S.win[(o + 3u) & (kInfWindow - 1u)] = (uint8_t)(w >> 24);
             }
           }
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (uint32_t r = 0; r < 5; r++) {
-            const uint32_t i = lane + r * kWave;
-            if (r * kWave < len && i < len) S.win[(pos + i) & (kInfWindow - 1u)] = v[r];
-          }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t before = pos;
         pos += len;
