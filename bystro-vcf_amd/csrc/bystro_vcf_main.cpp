@@ -200,5 +200,8 @@ int main(int argc, char **argv) {
   rc = bvcf_run_fd(&cfg, fd_in, fd_out, fd_err, &n_lines);
   if (fd_out != 1) close(fd_out);
   fflush(nullptr);
+  // (a profiler writes its results from exit handlers: leave normally under rocprofv3)
+  const char *pre = getenv("LD_PRELOAD");
+  if (getenv("ROCP_TOOL_LIBRARIES") || (pre && strstr(pre, "rocprof"))) return rc == BVCF_OK ? 0 : 1;
   _exit(rc == BVCF_OK ? 0 : 1);  // log.Fatal exits 1
 }
