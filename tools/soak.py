@@ -33,6 +33,7 @@ for i in range(n_cases):
         os.environ["BVCF_PATH"] = "1" if path == "wide" else path
         os.environ.pop("BVCF_WIDE", None)
         os.environ.pop("BVCF_WIDE_WIN", None)
+        os.environ["BVCF_DEVICE_NAMES"] = rng.choice(["0", "1"])  # host join / device-rendered name lists
         if path == "wide":
             os.environ["BVCF_WIDE"] = "1"
             os.environ["BVCF_WIDE_WIN"] = str(rng.choice([64, 100, 777, 1024, 4096, 65536]))
