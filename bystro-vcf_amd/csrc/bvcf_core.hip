@@ -85,6 +85,7 @@ struct bvcf_ctx {
   int gt_grid = 0, stream_grid = 0;
   bool fused = false;
   bool wide = false;  // census path with k_gt_wide in front of k_gt (see kWideSamples)
+  uint64_t avg_line_bytes = 0;  // of the last collected batch (bvcf_submit_bgzf picks its inflate kernel by it)
   bool names_on = false;  // want_name_lists and bvcf_set_sample_names called: the chain ends with the k_name_* kernels
   uint32_t *d_name_off = nullptr;
   uint8_t *d_name_text = nullptr;
@@ -472,18 +473,29 @@ static CrcConsts crc_consts() {
 
 // inflate + CRC of BGZF blocks whose compressed bytes are at d_comp (device): text to d_text.  desc/crc/status are
 // device arrays of n_blocks entries.
+// w16: the 16 KiB-window kernel (two batches of blocks resident at once), for text whose lines are well under 16 KB
 static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_desc, uint32_t n_blocks, uint8_t *d_text,
-                           uint32_t *d_status, uint32_t *d_crc, hipStream_t st) {
+                           uint32_t *d_status, uint32_t *d_crc, hipStream_t st, bool w16) {
   static const CrcConsts kc = crc_consts();
-  static const int per_cu = [] {
+  static const int per_cu32 = [] {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_inflate, kInfThreads, 0) != hipSuccess || n < 1) n = 4;
-    if (getenv("BVCF_DEBUG")) fprintf(stderr, "[bvcf debug] k_inflate: %d workgroups per CU, %zu bytes of LDS each\n", n, sizeof(InfLds));
     return n;
   }();
-  const uint32_t grid = std::min<uint32_t>(n_blocks, (uint32_t)n_cu * (uint32_t)per_cu);
-  hipLaunchKernelGGL(k_inflate, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
-  hipLaunchKernelGGL(k_crc32, dim3(grid ? grid : 1), dim3(kWave), 0, st, (const uint8_t *)d_text, d_desc, n_blocks, kc, d_crc);
+  static const int per_cu16 = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_inflate_w16, kInfThreads, 0) != hipSuccess || n < 1) n = 7;
+    if (getenv("BVCF_DEBUG")) fprintf(stderr, "[bvcf debug] k_inflate_w16: %d workgroups per CU\n", n);
+    return n;
+  }();
+  if (const char *e = getenv("BVCF_INFLATE_W16")) w16 = *e == '1';  // tests / tuning: force the variant
+  const uint32_t grid = std::min<uint32_t>(n_blocks, (uint32_t)n_cu * (uint32_t)(w16 ? per_cu16 : per_cu32));
+  if (w16)
+    hipLaunchKernelGGL(k_inflate_w16, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
+  else
+    hipLaunchKernelGGL(k_inflate, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
+  hipLaunchKernelGGL(k_crc32, dim3(std::min<uint32_t>(n_blocks ? n_blocks : 1, (uint32_t)n_cu * 8u)), dim3(kWave), 0, st,
+                     (const uint8_t *)d_text, d_desc, n_blocks, kc, d_crc);
 }
 
 // the kernel chain of the batch in slot s over the resident text src[0 .. nbytes), the counter read-back and the event
@@ -866,7 +878,8 @@ int bvcf_submit_bgzf(bvcf_ctx *c, const uint8_t *comp, size_t n_comp, size_t n_o
   uint32_t *d_want = s.d_bgzf + 4 * nb, *d_status = s.d_bgzf + 5 * nb, *d_crc = s.d_bgzf + 6 * nb;
   HIP_TRY(c, hipMemcpyAsync(s.d_comp, comp, n_comp, hipMemcpyHostToDevice, s.stream));
   HIP_TRY(c, hipMemcpyAsync(s.d_bgzf, s.h_bgzf, 5 * nb * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
-  launch_inflate(c->n_cu, s.d_comp, d_desc, (uint32_t)nb, s.d_in, d_status, d_crc, s.stream);
+  // lines well under 16 KB (the batches so far say): the small-window kernel, so that two batches inflate side by side
+  launch_inflate(c->n_cu, s.d_comp, d_desc, (uint32_t)nb, s.d_in, d_status, d_crc, s.stream, c->avg_line_bytes && c->avg_line_bytes <= 12000);
   // the pad behind the text is read (and masked) by the scans: keep it defined
   HIP_TRY(c, hipMemsetAsync(s.d_in + total, '\n', BVCF_DEVICE_PAD, s.stream));
   CutArgs ca;
@@ -1033,6 +1046,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     if (c->n_samples)
       for (uint32_t j = 0; j < L.n_rec; j++) ac0 += s.h_alleles[j ? L.rec_first + j - 1 : i].ac == 0;
   }
+  if (ctr.lines_seen) c->avg_line_bytes = s.nbytes / ctr.lines_seen;
   c->totals[0] += ctr.lines_seen;
   c->totals[1] += ok;
   c->totals[2] += recs;
@@ -1101,7 +1115,7 @@ int bvcf_bgzf_inflate_device(int device, const uint8_t *comp, size_t n_comp, uin
              hipMemcpy(d_desc, desc.data(), nb * sizeof(BgzfDesc), hipMemcpyHostToDevice) != hipSuccess) {
     rc = BVCF_E_HIP;
   } else {
-    launch_inflate(prop.multiProcessorCount, d_comp, d_desc, (uint32_t)nb, d_text, d_status, d_crc, nullptr);
+    launch_inflate(prop.multiProcessorCount, d_comp, d_desc, (uint32_t)nb, d_text, d_status, d_crc, nullptr, false);
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(crc.data(), d_crc, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         (total && hipMemcpy(out, d_text, total, hipMemcpyDeviceToHost) != hipSuccess))

@@ -37,12 +37,12 @@ enum {
   kInfSizeMismatch = 8,
 };
 
-constexpr uint32_t kInfWindow = 32768;
-constexpr uint32_t kInfSegment = 16384;
+constexpr uint32_t kInfWindowFull = 32768;  // the most a DEFLATE match may reach back
 constexpr uint32_t kInfInRing = 2048;
 constexpr uint32_t kInfLitBits = 10, kInfDistBits = 9;
 constexpr int kInfThreads = kWave;  // one wave per workgroup
 
+template <uint32_t kInfWindow>
 struct InfLds {
   uint8_t win[kInfWindow];                 // output byte p lives at win[p & (kInfWindow - 1)]
   uint8_t in[kInfInRing];                  // compressed byte q lives at in[q & (kInfInRing - 1)]
@@ -144,9 +144,14 @@ __device__ __forceinline__ uint32_t inf_dist_base(uint32_t i, uint32_t *extra) {
 }
 
 // one wave per BGZF block; status[k] = kInf*
-__global__ __launch_bounds__(kInfThreads) void k_inflate(const uint8_t *comp, const BgzfDesc *desc, uint32_t n_blocks,
-                                                         uint8_t *out, uint32_t *status) {
-  __shared__ __attribute__((aligned(16))) InfLds S;
+// kInfWindow: bytes of output kept in LDS.  32 KiB holds everything a match may refer to (39 KB of LDS: four waves per
+// CU, i.e. one batch of ~1 000 blocks fills the chip).  16 KiB (23 KB: seven waves per CU, so two batches inflate side
+// by side) is for files whose lines are well under 16 KB -- a genotype line mostly repeats the line before it --
+// and reads the few older bytes a match asks for back from memory, where the finished segments already are.
+template <uint32_t kInfWindow>
+__device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDesc *desc, uint32_t n_blocks, uint8_t *out,
+                                               uint32_t *status, InfLds<kInfWindow> &S) {
+  constexpr uint32_t kInfSegment = kInfWindow / 2;
   const int lane = lane_id();
   for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const BgzfDesc d = desc[blk];
@@ -427,11 +432,23 @@ __global__ __launch_bounds__(kInfThreads) void k_inflate(const uint8_t *comp, co
           const uint32_t from = pos - dist;
           const bool periodic = dist < len;
           const float inv = 1.0f / (float)dist;
+          // a source byte older than this is no longer in the ring (this match may overwrite it): it is in memory
+          const bool far = kInfWindow < kInfWindowFull && dist + len > kInfWindow;
+          if (far) __builtin_amdgcn_s_waitcnt(0);  // the segment stores that carry those bytes have landed
+          auto src_byte = [&](uint32_t p) -> uint32_t {
+            if (kInfWindow < kInfWindowFull && far && p + kInfWindow < pos + len) {
+              // (cache-bypassing: this CU's L1 may hold an older copy of the line from before its segment was written)
+              const uint32_t *wp = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(dst + p) & ~(uintptr_t)3);
+              const uint32_t w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              return (w >> (8u * (uint32_t)(reinterpret_cast<uintptr_t>(dst + p) & 3u))) & 0xFFu;
+            }
+            return S.win[p & (kInfWindow - 1u)];
+          };
           for (uint32_t base = 0; base < len; base += 4u * kWave) {
             const uint32_t j0 = base + 4u * lane;
             if (j0 < len) {
               uint32_t w;
-              if (!periodic) {
+              if (!periodic && !far) {
                 // source and destination do not overlap: four source bytes from two aligned words of the ring
                 const uint32_t a = (from + j0) & (kInfWindow - 1u);
                 const uint32_t w0 = *reinterpret_cast<const uint32_t *>(&S.win[a & ~3u]);
@@ -440,14 +457,14 @@ __global__ __launch_bounds__(kInfThreads) void k_inflate(const uint8_t *comp, co
               } else {
                 // j mod dist for j < 260, dist < 258 from a float reciprocal ((j + 0.5) / dist is never within 0.002
                 // of an integer, the product's error stays below 0.0004); the next three by stepping
-                uint32_t k = j0 - dist * (uint32_t)(((float)j0 + 0.5f) * inv);
-                w = S.win[(from + k) & (kInfWindow - 1u)];
-                k = k + 1u == dist ? 0u : k + 1u;
-                w |= (uint32_t)S.win[(from + k) & (kInfWindow - 1u)] << 8;
-                k = k + 1u == dist ? 0u : k + 1u;
-                w |= (uint32_t)S.win[(from + k) & (kInfWindow - 1u)] << 16;
-                k = k + 1u == dist ? 0u : k + 1u;
-                w |= (uint32_t)S.win[(from + k) & (kInfWindow - 1u)] << 24;
+                uint32_t k = periodic ? j0 - dist * (uint32_t)(((float)j0 + 0.5f) * inv) : j0;
+                w = src_byte(from + k);
+                k = (periodic && k + 1u == dist) ? 0u : k + 1u;
+                w |= src_byte(from + k) << 8;
+                k = (periodic && k + 1u == dist) ? 0u : k + 1u;
+                w |= src_byte(from + k) << 16;
+                k = (periodic && k + 1u == dist) ? 0u : k + 1u;
+                w |= src_byte(from + k) << 24;
               }
               const uint32_t o = pos + j0;
               S.win[o & (kInfWindow - 1u)] = (uint8_t)w;
@@ -472,6 +489,18 @@ __global__ __launch_bounds__(kInfThreads) void k_inflate(const uint8_t *comp, co
   }
 }
 
+
+__global__ __launch_bounds__(kInfThreads) void k_inflate(const uint8_t *comp, const BgzfDesc *desc, uint32_t n_blocks,
+                                                         uint8_t *out, uint32_t *status) {
+  __shared__ __attribute__((aligned(16))) InfLds<kInfWindowFull> S;
+  k_inflate_body<kInfWindowFull>(comp, desc, n_blocks, out, status, S);
+}
+// the 16 KiB-window variant (see k_inflate_body)
+__global__ __launch_bounds__(kInfThreads) void k_inflate_w16(const uint8_t *comp, const BgzfDesc *desc, uint32_t n_blocks,
+                                                             uint8_t *out, uint32_t *status) {
+  __shared__ __attribute__((aligned(16))) InfLds<16384> S;
+  k_inflate_body<16384>(comp, desc, n_blocks, out, status, S);
+}
 
 // ------------------------------------------------------------------ CRC-32 of the inflated blocks
 // BGZF's trailer carries the CRC-32 (IEEE 802.3, reflected) of each block's text.  One wave per block: the block is

@@ -18,6 +18,13 @@ def bv():
     return b
 
 
+@pytest.fixture(autouse=True, params=["w32", "w16"])
+def window(request, monkeypatch):
+    """both inflate kernels: the 32 KiB window, and the 16 KiB one that reads older bytes back from memory"""
+    monkeypatch.setenv("BVCF_INFLATE_W16", "1" if request.param == "w16" else "0")
+    return request.param
+
+
 def _block_raw(payload, data):
     bsize = len(payload) + 25  # header 18 + payload + crc 4 + isize 4 - 1
     assert bsize < 65536
@@ -49,6 +56,10 @@ def _texts():
         "text": (b"The quick brown fox jumps over the lazy dog. " * 2000)[:64000],
         "bytes_all": bytes(range(256)) * 200,
         "max": bytes(rng.choice(b"01|\t") for _ in range(65280)),
+        # 20 KB of noise, then copies of it: matches that reach 20 KB back (past the 16 KiB window)
+        "far_refs": (lambda n: n + n[:15000] + b"xyz" + n[3000:19000] + n[:9000])(bytes(rng.getrandbits(8) for _ in range(20000))),
+        # lines of 30 KB that repeat the line before them
+        "long_lines": b"".join(bytes(rng.choice(b"01|\t") for _ in range(40)) + (b"0|0\t" * 7400) + b"\n" for _ in range(2)),
     }
 
 
