@@ -990,8 +990,8 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   }
 
   const size_t cap = R.max_batch;
-  // being read into, two on each device, up to two with the formatter, one spare
-  const int kBufs = (int)std::min<size_t>(2 * n_dev + 4, 64);
+  // being read into, two (BGZF inflated on the device: three) on each device, up to two with the formatter, one spare
+  const int kBufs = (int)std::min<size_t>(3 * n_dev + 4, 64);
   // Pinning memory costs about 25 ms per 64 MiB: only the first buffer is allocated before the reader starts, the
   // others follow in the background while the first block is read and the ctx is created, and stop at end of input
   // (a small file never pays for all of them).
@@ -1034,6 +1034,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
 
   std::string source_err;
   std::atomic<bool> input_is_bgzf_device{false};
+  std::atomic<size_t> max_in_flight{2};  // batches a device worker keeps submitted
   // ---- reader, BGZF on the device: whole compressed blocks per buffer.  The header has to be read here, so the
   // leading blocks are inflated with zlib until the #CHROM line is complete; everything from the block that holds the
   // first data line on is handed over compressed, each buffer with the next buffer's first blocks as look-ahead.
@@ -1458,8 +1459,8 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
           continue;
         }
       }
-      // keep one block ahead of the one being collected
-      if (in_flight.size() >= 2) finish_oldest();
+      // keep one block (BGZF on the device: two) ahead of the one being collected
+      if (in_flight.size() >= max_in_flight.load()) finish_oldest();
       if (failed.load()) continue;
       const double ts = now_s();
       const int r = b.bgzf ? bvcf_submit_bgzf(W->ctx, b.buf, b.nb, b.own, b.skip_first, b.first_off, b.seq)
@@ -1538,6 +1539,10 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       } else {
         R.pre = b.pre->pre;
         have_pre = true;
+        // one more batch in flight per device than for text: two batches' blocks inflate side by side (k_inflate_w16)
+        // while a third is in its kernel chain / on its way back
+        R.n_slots = 4;
+        max_in_flight.store(3);
         int r = prepare_run(R, &msg, b.pre->sample.data(), b.pre->sample.size());
         if (r) fail(msg, r);
         if (!failed.load() && R.pre.header.size() == 9) {
