@@ -570,9 +570,9 @@ int launch_after_cuts(bvcf_ctx *c, Slot &s, bool wait) {
     return launch_batch(c, s, s.d_in, 0);  // (the slot still has to be collected: an empty batch carries the error)
   }
   s.text_start = start;
-  const size_t nbytes = end - start;
-  if (nbytes) HIP_TRY(c, hipMemcpyAsync(s.h_text, s.d_in + start, nbytes, hipMemcpyDeviceToHost, s.stream));
-  return launch_batch(c, s, s.d_in + start, nbytes);
+  // (the text itself is copied back by bvcf_collect, with the other result arrays: h_text may still be read by the
+  // caller for the batch this slot held before)
+  return launch_batch(c, s, s.d_in + start, end - start);
 }
 
 }  // namespace
@@ -984,6 +984,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     HIP_TRY(c, hipMemcpyAsync(s.h_cmap, s.d_cmap, cmap_bytes, hipMemcpyDeviceToHost, s.stream));
   if (c->dosage_stride && n_alleles)
     HIP_TRY(c, hipMemcpyAsync(s.h_dosage, s.d_dosage, n_alleles * c->dosage_stride, hipMemcpyDeviceToHost, s.stream));
+  if (was_bgzf && s.nbytes) HIP_TRY(c, hipMemcpyAsync(s.h_text, s.src, s.nbytes, hipMemcpyDeviceToHost, s.stream));
   const bool names = c->names_on && s.d_name_lists;
   uint64_t name_bytes = 0;
   if (names && n_alleles) {
