@@ -1011,9 +1011,14 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   free_q.push(bufs[0]);
   std::atomic<bool> stop{false};
   std::atomic<bool> stop_alloc{false}, alloc_failed{false};
+  // BGZF input inflated on the device fills a buffer with compressed bytes only: the buffers after the first are then
+  // a quarter of the size (pinning is what they cost), and batches are cut to fit them.  0 = not known yet.
+  std::atomic<size_t> later_buf_bytes{0};
   std::thread allocator([&]() {
+    while (!later_buf_bytes.load() && !stop_alloc.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    const size_t bytes = later_buf_bytes.load() ? later_buf_bytes.load() : cap;
     for (int i = 1; i < kBufs && !stop_alloc.load(); i++) {
-      bufs[i] = (uint8_t *)bvcf_alloc_pinned(cap);
+      bufs[i] = (uint8_t *)bvcf_alloc_pinned(bytes);
       if (!bufs[i]) {
         // the pipeline needs three buffers to make progress: end the run (reported below) rather than stall
         alloc_failed.store(true);
@@ -1044,6 +1049,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     size_t pp = 0;
     bool raw_eof = false;
     auto fail_read = [&](const std::string &m) {
+      if (!later_buf_bytes.load()) later_buf_bytes.store(cap);
       source_err = m;
       Block b;
       b.read_error = true;
@@ -1157,7 +1163,10 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       line_len = std::max<size_t>(line_len, 2 * (size_t)(e - pre->sample.data()));
     const size_t look = std::min<size_t>(line_len / 65280 + 2, std::max<size_t>(2, cap / (4 * 65536)));
     const size_t text_limit = cap > (look + 1) * 65536 ? cap - (look + 1) * 65536 : cap / 2;
-    const size_t comp_limit = cap > (look + 1) * 66000 ? cap - (look + 1) * 66000 : cap / 2;
+    // the compressed bytes of a batch (own + look-ahead blocks) must fit the smaller buffers
+    const size_t small = std::min<size_t>(cap, std::max<size_t>(cap / 4, (2 * look + 8) * 66000));
+    later_buf_bytes.store(small);
+    const size_t comp_limit = small - (look + 1) * 66000;
 
     bool first = true;
     for (;;) {
@@ -1187,7 +1196,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
         const long bs = block_at(off + la, &k);
         if (bs < 0) bad = true;
         if (bs <= 0) break;
-        if (own_text + la_text + k.isize > cap || off + la + (size_t)bs > cap) break;
+        if (own_text + la_text + k.isize > cap || off + la + (size_t)bs > small) break;
         la += (size_t)bs;
         la_text += k.isize;
       }
@@ -1223,6 +1232,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
         read_bgzf_raw(src);
         return;
       }
+      later_buf_bytes.store(cap);
     }
     std::vector<uint8_t> carry;
     bool first = true, eof = false;
