@@ -80,7 +80,7 @@ class Result(C.Structure):
         ("need_cmap_bytes", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32),
         ("n_lines_seen", C.c_uint64), ("dosage", C.c_void_p), ("dosage_stride", C.c_uint32), ("reserved2", C.c_uint32),
         ("name_lists", C.c_void_p), ("names", C.c_void_p), ("n_name_bytes", C.c_uint64),
-        ("text", C.c_void_p), ("n_text_bytes", C.c_uint64),
+        ("text", C.c_void_p), ("n_text_bytes", C.c_uint64), ("head_off", C.c_void_p),
     ]
 
 
@@ -263,6 +263,8 @@ class Batch:
         # want_dosage: one int8 row per alleles[] slot (rows of slots without a record hold garbage)
         # bvcf_submit_bgzf: the batch's inflated text (lines[].off point into it)
         self.text = C.string_at(r.text, r.n_text_bytes) if r.text and r.n_text_bytes else b""
+        # ... with samples only the line heads (CHROM..INFO), packed: line i's bytes start at text[head_off[i]]
+        self.head_off = arr(r.head_off, r.n_lines, np.dtype("<u4")) if r.head_off else None
         # want_name_lists: (off[3], len[3]) per alleles[] slot into the text arena `names`
         self.name_lists = arr(r.name_lists, r.n_alleles, NAMES_DTYPE) if r.name_lists else None
         self.names = C.string_at(r.names, r.n_name_bytes) if r.names and r.n_name_bytes else b""
@@ -284,6 +286,15 @@ class Batch:
         L = self.lines[i]
         n = int(L["n_rec"])
         return [] if n == 0 else [i] + [int(L["rec_first"]) + j - 1 for j in range(1, n)]
+
+    def line_head(self, i):
+        """the bytes of line i that came back with a bvcf_submit_bgzf batch: the whole line (no samples) or its head up
+        to the end of the INFO column"""
+        L = self.lines[i]
+        if self.head_off is None:
+            return self.text[int(L["off"]):int(L["off"]) + int(L["len"])]
+        n = min(int(L["fend"][7]), int(L["len"]))
+        return self.text[int(self.head_off[i]):int(self.head_off[i]) + n]
 
     def name_list(self, slot, q):
         """list q (0 het, 1 hom, 2 missing) of alleles[slot] as the device rendered it"""

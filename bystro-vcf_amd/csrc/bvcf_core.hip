@@ -54,6 +54,12 @@ struct Slot {
   uint64_t cap_bgzf_blocks = 0;
   uint32_t *d_cuts = nullptr, *h_cuts = nullptr;  // {start, end, flags, first bad block}
   uint8_t *h_text = nullptr;
+  // ... of which only the line heads come back when there are samples (k_heads_*)
+  uint32_t *d_head_off = nullptr, *h_head_off = nullptr;
+  uint8_t *d_heads = nullptr;
+  unsigned long long *d_head_total = nullptr, *h_head_total = nullptr;
+  uint64_t cap_head_lines = 0;
+  bool heads = false;  // the batch in flight returns heads
   hipEvent_t ev_cut = nullptr;
   bool await_cuts = false;  // inflate enqueued, the kernel chain not yet (it needs the cut points)
   bool is_bgzf = false;     // the batch in flight came through bvcf_submit_bgzf
@@ -183,6 +189,11 @@ void free_slot(Slot &s) {
   hipFree(s.d_cuts);
   hipHostFree(s.h_cuts);
   hipHostFree(s.h_text);
+  hipFree(s.d_head_off);
+  hipHostFree(s.h_head_off);
+  hipFree(s.d_heads);
+  hipFree(s.d_head_total);
+  hipHostFree(s.h_head_total);
   if (s.ev_cut) hipEventDestroy(s.ev_cut);
   hipFree(s.d_counters);
   hipHostFree(s.h_counters);
@@ -512,6 +523,19 @@ int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
   HIP_TRY(c, hipMemcpyAsync(s.h_counters, s.d_counters, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.stream));
   if (names)
     HIP_TRY(c, hipMemcpyAsync(s.h_name_total, s.d_name_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
+  s.heads = s.is_bgzf && c->n_samples > 0 && s.d_head_off && nbytes > 0;
+  if (s.heads) {
+    HeadArgs h;
+    h.off = s.d_head_off;
+    h.out = s.d_heads;
+    h.cap = c->p.max_batch_bytes;
+    h.total = s.d_head_total;
+    hipLaunchKernelGGL(k_heads_len, dim3(c->n_cu * 2), dim3(kWgThreads), 0, s.stream, a, h);
+    hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, s.stream, a, h);
+    hipLaunchKernelGGL(k_heads_copy, dim3(c->n_cu * 4), dim3(kWgThreads), 0, s.stream, a, h);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(s.h_head_total, s.d_head_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
+  }
   s.src = src;
   s.nbytes = nbytes;
   HIP_TRY(c, hipEventRecord(s.ev_ctr, s.stream));
@@ -854,6 +878,21 @@ int bvcf_submit_bgzf(bvcf_ctx *c, const uint8_t *comp, size_t n_comp, size_t n_o
       return BVCF_E_NOMEM;
     }
   }
+  if (c->n_samples && s.cap_head_lines < c->max_lines) {
+    hipFree(s.d_head_off);
+    hipHostFree(s.h_head_off);
+    s.d_head_off = nullptr;
+    s.h_head_off = nullptr;
+    s.cap_head_lines = 0;
+    HIP_TRY(c, hipMalloc(&s.d_head_off, (c->max_lines + 1) * sizeof(uint32_t)));
+    HIP_TRY(c, hipHostMalloc(&s.h_head_off, (c->max_lines + 1) * sizeof(uint32_t), hipHostMallocDefault));
+    if (!s.d_heads) HIP_TRY(c, hipMalloc(&s.d_heads, c->p.max_batch_bytes + 64));
+    if (!s.d_head_total) {
+      HIP_TRY(c, hipMalloc(&s.d_head_total, sizeof(unsigned long long)));
+      HIP_TRY(c, hipHostMalloc(&s.h_head_total, sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    s.cap_head_lines = c->max_lines;
+  }
   if (!s.d_cuts) {
     HIP_TRY(c, hipMalloc(&s.d_cuts, 4 * sizeof(uint32_t)));
     HIP_TRY(c, hipHostMalloc(&s.h_cuts, 4 * sizeof(uint32_t), hipHostMallocDefault));
@@ -999,7 +1038,21 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     HIP_TRY(c, hipMemcpyAsync(s.h_cmap, s.d_cmap, cmap_bytes, hipMemcpyDeviceToHost, s.stream));
   if (c->dosage_stride && n_alleles)
     HIP_TRY(c, hipMemcpyAsync(s.h_dosage, s.d_dosage, n_alleles * c->dosage_stride, hipMemcpyDeviceToHost, s.stream));
-  if (was_bgzf && s.nbytes) HIP_TRY(c, hipMemcpyAsync(s.h_text, s.src, s.nbytes, hipMemcpyDeviceToHost, s.stream));
+  uint64_t text_bytes = 0;
+  if (was_bgzf && s.heads) {
+    // the packed line heads and where each line's is
+    text_bytes = *s.h_head_total;
+    if (text_bytes > c->p.max_batch_bytes) {
+      c->err = "internal error: line heads larger than the batch";
+      release();
+      return BVCF_E_HIP;
+    }
+    if (ctr.n_lines) HIP_TRY(c, hipMemcpyAsync(s.h_head_off, s.d_head_off, ctr.n_lines * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+    if (text_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_text, s.d_heads, text_bytes, hipMemcpyDeviceToHost, s.stream));
+  } else if (was_bgzf && s.nbytes) {
+    text_bytes = s.nbytes;
+    HIP_TRY(c, hipMemcpyAsync(s.h_text, s.src, s.nbytes, hipMemcpyDeviceToHost, s.stream));
+  }
   const bool names = c->names_on && s.d_name_lists;
   uint64_t name_bytes = 0;
   if (names && n_alleles) {
@@ -1048,7 +1101,8 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   r->dosage = c->dosage_stride ? s.h_dosage : nullptr;
   r->dosage_stride = c->dosage_stride;
   r->text = was_bgzf ? s.h_text : nullptr;
-  r->n_text_bytes = was_bgzf ? s.nbytes : 0;
+  r->n_text_bytes = was_bgzf ? text_bytes : 0;
+  r->head_off = (was_bgzf && s.heads) ? s.h_head_off : nullptr;
   r->name_lists = names ? s.h_name_lists : nullptr;
   r->names = names ? s.h_names : nullptr;
   r->n_name_bytes = name_bytes;

@@ -188,8 +188,13 @@ const char *err_text(uint32_t code) {
 }
 
 // one log line in the reference's formats (main.go:730-986)
-void append_err(std::string &log, const bvcf_err &e, const bvcf_line &L, const uint8_t *block) {
-  const char *row = (const char *)block + L.off;
+// where line li's bytes are: in the block the batch was submitted as, or -- bvcf_submit_bgzf with head_off -- in the
+// compact copy of the line heads that came back
+inline const char *row_of(const bvcf_result *r, const uint8_t *block, uint32_t li) {
+  return (const char *)block + (r->head_off ? r->head_off[li] : r->lines[li].off);
+}
+
+void append_err(std::string &log, const bvcf_err &e, const bvcf_line &L, const char *row) {
   log.append(row, L.fend[0]);  // chrom
   log.push_back(':');
   log.append(row + L.fend[0] + 1, L.fend[1] - L.fend[0] - 1);  // pos
@@ -219,7 +224,7 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
   for (uint32_t li = lo; li < hi; li++) {
     const bvcf_line &L = r->lines[li];
     if (L.status != BVCF_LINE_OK) continue;
-    const char *row = (const char *)block + L.off;
+    const char *row = row_of(r, block, li);
     auto fstart = [&](int i) -> uint32_t { return i ? L.fend[i - 1] + 1 : 0; };
     for (uint32_t k = 0; k < L.n_rec; k++) {
       const uint32_t slot = k ? L.rec_first + k - 1 : li;
@@ -245,7 +250,7 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
         out.push_back((char)A.alt_base);
       } else if (A.kind == BVCF_ALT_INS) {
         out.push_back('+');
-        out.append((const char *)block + A.alt_off, A.alt_len);
+        out.append(row + (A.alt_off - L.off), A.alt_len);  // (alt_off is a block offset inside the line's ALT column)
       } else {
         out.push_back('-');
         append_ll(out, A.alt_len);
@@ -391,7 +396,7 @@ void format_log(const bvcf_result *r, const uint8_t *block, std::string &log) {
   std::vector<uint32_t> idx(r->n_errs);
   for (uint32_t i = 0; i < r->n_errs; i++) idx[i] = i;
   std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return r->errs[x].line < r->errs[y].line; });
-  for (uint32_t i : idx) append_err(log, r->errs[i], r->lines[r->errs[i].line], block);
+  for (uint32_t i : idx) append_err(log, r->errs[i], r->lines[r->errs[i].line], row_of(r, block, r->errs[i].line));
 }
 
 // rows of one batch as consecutive pieces (parts[0] + parts[1] + ... is the batch's TSV): runs of lines are claimed
@@ -679,7 +684,7 @@ int append_dosage(Run &R, const bvcf_result *r, const uint8_t *block) {
   for (uint32_t li = 0; li < r->n_lines; li++) {
     const bvcf_line &L = r->lines[li];
     if (L.status != BVCF_LINE_OK) continue;
-    const char *row = (const char *)block + L.off;
+    const char *row = row_of(r, block, li);
     for (uint32_t k = 0; k < L.n_rec; k++) {
       const uint32_t slot = k ? L.rec_first + k - 1 : li;
       const bvcf_allele &A = r->alleles[slot];
@@ -699,7 +704,7 @@ int append_dosage(Run &R, const bvcf_result *r, const uint8_t *block) {
         locus.push_back((char)A.alt_base);
       } else if (A.kind == BVCF_ALT_INS) {
         locus.push_back('+');
-        locus.append((const char *)block + A.alt_off, A.alt_len);
+        locus.append(row + (A.alt_off - L.off), A.alt_len);
       } else {
         locus.push_back('-');
         append_ll(locus, A.alt_len);

@@ -666,4 +666,69 @@ __global__ __launch_bounds__(kWave) void k_cuts(CutArgs c) {
   }
 }
 
+// ------------------------------------------------------------------ the line heads of a batch, packed
+// The host's TSV assembly reads CHROM..INFO of every line that passed; when the text was inflated on the device only
+// those bytes go back (k_heads_len -> k_heads_scan -> k_heads_copy), not the sample columns.
+struct HeadArgs {
+  uint32_t *off;              // [max_lines + 1] head length per line -> exclusive prefix
+  uint8_t *out;               // the packed heads
+  unsigned long long cap;
+  unsigned long long *total;  // bytes of all heads
+};
+
+__global__ __launch_bounds__(kWgThreads) void k_heads_len(KernelArgs a, HeadArgs h) {
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += gridDim.x * blockDim.x) {
+    const uint32_t st = a.lines[i].status;
+    // up to the end of the INFO column (fields past the line's end have fend == len)
+    h.off[i] = (st == BVCF_LINE_OK || st == BVCF_LINE_NOALLELE) ? min(a.lines[i].fend[7], a.lines[i].len) : 0u;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_heads_scan(KernelArgs a, HeadArgs h) {
+  __shared__ unsigned long long s_part[1024];
+  const uint32_t n = min(a.counters->n_lines, a.max_lines);
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t lo = threadIdx.x * per;
+  unsigned long long sum = 0;
+  for (uint32_t i = 0; i < per; i++)
+    if (lo + i < n) sum += h.off[lo + i];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const unsigned long long t = threadIdx.x >= (unsigned)d ? s_part[threadIdx.x - d] : 0ull;
+    __syncthreads();
+    s_part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  unsigned long long run = s_part[threadIdx.x] - sum;
+  for (uint32_t i = 0; i < per; i++) {
+    if (lo + i < n) {
+      const uint32_t v = h.off[lo + i];
+      h.off[lo + i] = (uint32_t)run;
+      run += v;
+    }
+  }
+  if (threadIdx.x == 1023) {
+    *h.total = s_part[1023];
+    if (n <= a.max_lines) h.off[n] = (uint32_t)s_part[1023];
+  }
+}
+
+// 16 lanes per line
+__global__ __launch_bounds__(kWgThreads) void k_heads_copy(KernelArgs a, HeadArgs h) {
+  if (*h.total > h.cap) return;
+  const uint32_t n_lines = min(a.counters->n_lines, a.max_lines);
+  const uint32_t gl = threadIdx.x & 15u;
+  const uint32_t groups = gridDim.x * (blockDim.x / 16u);
+  for (uint32_t i = blockIdx.x * (blockDim.x / 16u) + threadIdx.x / 16u; i < n_lines; i += groups) {
+    const uint32_t st = a.lines[i].status;
+    if (st != BVCF_LINE_OK && st != BVCF_LINE_NOALLELE) continue;
+    const uint32_t n = min(a.lines[i].fend[7], a.lines[i].len);
+    const uint8_t *src = a.buf + a.lines[i].off;
+    uint8_t *dst = h.out + h.off[i];
+    for (uint32_t j = gl; j < n; j += 16u) dst[j] = src[j];
+  }
+}
+
 }  // namespace bvcf_dev

@@ -210,10 +210,15 @@ typedef struct {
   const bvcf_names *name_lists;
   const char *names;
   uint64_t n_name_bytes;
-  /* bvcf_submit_bgzf: the inflated text of the batch, from its first line on (lines[].off are offsets into it);
-   * NULL for batches submitted as text */
+  /* bvcf_submit_bgzf: the text the caller's TSV assembly needs; NULL for batches submitted as text (the caller has it).
+   * head_off == NULL (no sample columns): the whole inflated text from the batch's first line on; lines[i].off index
+   * into it.  head_off != NULL (files with samples): only the HEAD of every line that passed the gate -- its bytes up
+   * to the end of the INFO column, fend[7] -- packed back to back: line i's bytes start at text[head_off[i]] (the
+   * samples, 98 % of a cohort file, do not cross PCIe a second time).  Offsets inside a line (fend[], alt_off -
+   * lines[i].off) apply to both forms. */
   const uint8_t *text;
   uint64_t n_text_bytes;
+  const uint32_t *head_off;  /* [n_lines]; entries of lines that did not pass (status FIELDS / FILTER) are undefined */
 } bvcf_result;
 
 /* ---- lifecycle ---- */
