@@ -219,8 +219,6 @@ def main():
     import benchgen as bg
     import bystro_vcf_amd as bv
 
-    if args.profile == "c5" and args.path == 0:
-        args.path = 1  # FORMAT is not plain GT: the host driver (choose_path) sends such files down the census path
     cfg = bg.make_cfg(args.profile, align16=int(args.align16), **({"n_samples": args.samples} if args.samples else {}))
     ns = cfg.n_samples
     # ---- synthetic blocks, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)
@@ -249,10 +247,13 @@ def main():
             sizes.append(nbytes)
     max_bytes = max(sizes)
     stride = ((ns + 3) // 4 + 15) & ~15
-    n_alt_cap = args.rows * (4 if args.profile == "c4" or args.golden else 1) + 1024
+    # (c5: the first launches go through k_stream, which leaves every line of this shape to a k_gt task of its own)
+    n_alt_cap = args.rows * (4 if args.profile == "c4" or args.golden else 2 if args.profile == "c5" else 1) + 1024
     ctx = bv.Ctx(bg.n_header_fields(cfg), device=local_rank, max_batch_bytes=max_bytes, n_slots=max(1, args.slots),
                  max_lines=args.rows + 16, max_alleles=n_alt_cap,
-                 cmap_bytes=min((n_alt_cap + 16 * 8192) * stride + 4096, 0xFFFFFF00),  # + the slack of the streaming path's per-wave slot ranges
+                 # (the streaming path hands every wave a range of map slots sized by bytes, one per 4 ns + 8 of them,
+                 # plus two of slack)
+                 cmap_bytes=min((n_alt_cap + (max_bytes // (4 * ns + 8) if ns else 0) + 16 * 8192) * stride + 4096, 0xFFFFFF00),
                  path=args.path,
                  want_class_maps=not args.no_class_maps)
     ptrs = [t.data_ptr() for t in blocks]

@@ -38,7 +38,8 @@ struct BatchCounters {
   uint32_t cmap_maps;    // streaming path: class maps handed out
   uint32_t pad[2];       // [0]: internal error flag; [1]: wide ctxs, the longest sample region
   uint32_t n_finish;     // streaming path: entries of finish_items (what k_finish still has to settle)
-  uint32_t pad2;
+  uint32_t n_other_shape;  // streaming path: listed lines that were not of the shape the kernel is made for -- k_stream: not the
+                           // 4-byte grid (left to k_gt); k_stream_gen: of the 4-byte grid.  The host picks the next batch's kernel by it.
 };
 
 // streaming path: what k_stream knows about a line when it has scanned it
@@ -94,6 +95,7 @@ struct KernelArgs {
   BatchCounters *counters;
   // streaming path
   uint32_t fused;        // 1: k_stream found the lines and scanned ALT #1
+  uint32_t gen_stream;   // 1: k_stream also scans lines that are not the 4-byte grid (bvcf_streamgen.hip.h); 0: leaves them to k_gt
   uint32_t wide;         // 1: census path, regular scans split into windows over several waves (k_gt_wide)
   uint32_t win_bytes;    // wide: bytes of a line's sample region per wave of the split general scan
   uint32_t win_tabs_cap; // entries of win_tabs

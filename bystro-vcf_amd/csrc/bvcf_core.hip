@@ -24,6 +24,7 @@ namespace {
 
 struct Slot {
   hipStream_t stream = nullptr;
+  bool used_gen = false;  // the batch in flight went through k_stream_gen
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_ctr = nullptr;
   // device
   uint8_t *d_in = nullptr;
@@ -91,6 +92,12 @@ struct bvcf_ctx {
   int n_cu = 0;
   int gt_grid = 0, stream_grid = 0;
   bool fused = false;
+  // streaming path: which kernel walks the next batch -- k_stream (made for the 4-byte sample grid; other lines are
+  // left to k_gt) or k_stream_gen (any fields, one pass).  Adaptive: a batch whose lines were mostly of the other
+  // kernel's shape switches (the results are the same either way); BVCF_GEN_STREAM=0 / 1 pins it.
+  bool gen_mode = false;
+  int gen_policy = -1;  // -1 adaptive, 0 never, 1 always
+  uint32_t gen_grid = 0;
   bool wide = false;  // census path with k_gt_wide in front of k_gt (see kWideSamples)
   uint64_t avg_line_bytes = 0;  // of the last collected batch (bvcf_submit_bgzf picks its inflate kernel by it)
   bool names_on = false;  // want_name_lists and bvcf_set_sample_names called: the chain ends with the k_name_* kernels
@@ -378,6 +385,7 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.results = s.d_results;
   a.counters = s.d_counters;
   a.fused = c->fused ? 1u : 0u;
+  a.gen_stream = c->gen_mode ? 1u : 0u;
   a.wide = c->wide ? 1u : 0u;
   a.win_bytes = c->win_bytes;
   a.win_tabs = s.d_win_tabs;
@@ -402,12 +410,21 @@ void launch_names(bvcf_ctx *c, const KernelArgs &a, const NameArgs &na, hipStrea
   hipLaunchKernelGGL(k_name_write, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a, na);
 }
 
+// a batch's counters are in: should the next one go through the other streaming kernel?
+void adapt_stream_kernel(bvcf_ctx *c, bool was_gen, const BatchCounters &ctr) {
+  if (c->gen_policy >= 0 || !c->fused || ctr.n_lines < 16) return;
+  if ((uint64_t)ctr.n_other_shape * 2u > ctr.n_lines) c->gen_mode = !was_gen;
+}
+
 void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t ev_gt0, hipEvent_t ev_gt1) {
   if (a.fused) {
     const uint32_t n_groups = (a.n_tiles + kScanGroup - 1) / kScanGroup;
     hipMemsetAsync(a.counters, 0, sizeof(BatchCounters), st);
     if (ev_gt0) hipEventRecord(ev_gt0, st);
-    hipLaunchKernelGGL(k_stream, dim3(c->stream_grid), dim3(kWgThreads), 0, st, a);
+    if (a.gen_stream)
+      hipLaunchKernelGGL(k_stream_gen, dim3(c->gen_grid), dim3(kWgThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL(k_stream, dim3(c->stream_grid), dim3(kWgThreads), 0, st, a);
     if (ev_gt1) hipEventRecord(ev_gt1, st);
     hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, a.n_tiles);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
@@ -514,6 +531,7 @@ static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_de
 // bvcf_collect waits for
 int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
   KernelArgs a = make_args(c, s, src, nbytes);
+  s.used_gen = a.gen_stream != 0;
   HIP_TRY(c, hipEventRecord(s.ev_k0, s.stream));
   launch_chain(c, a, s.stream, nullptr, nullptr);
   const bool names = c->names_on && s.d_name_lists;
@@ -679,6 +697,9 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   const bool many_samples = c->n_samples >= kWideSamples;
   c->fused = c->n_samples > 0 && (path == 2 || (path == 0 && p->n_header_fields >= 256 && !many_samples));
   c->wide = !c->fused && many_samples;
+  if (const char *e = getenv("BVCF_GEN_STREAM")) c->gen_policy = atoi(e) != 0 ? 1 : 0;
+  if (!c->fused || c->n_samples > 4u * kStageBytes) c->gen_policy = 0;  // (a line's dense class map is staged in LDS)
+  c->gen_mode = c->gen_policy == 1;
   if (const char *e = getenv("BVCF_WIDE")) c->wide = !c->fused && c->n_samples > 0 && atoi(e) != 0;  // test / tuning override
   if (const char *e = getenv("BVCF_WIDE_WIN")) {  // test / tuning: window of the split general scan, bytes
     const long v = atol(e);
@@ -716,6 +737,14 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
     if (w >= 1 && w <= 4) per_cu = w;
   }
   c->stream_grid = c->n_cu * per_cu;
+  per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream_gen, kWgThreads, 0) != hipSuccess || per_cu < 1)
+    per_cu = 2;
+  if (const char *e = getenv("BVCF_GEN_WGS")) {  // experiment: workgroups per CU
+    const int w = atoi(e);
+    if (w >= 1 && w <= 8) per_cu = w;
+  }
+  c->gen_grid = c->n_cu * per_cu;
   // sites-only input takes the fused kernel (BVCF_SITES=0: the census chain with k_head, for A/B and parity tests)
   c->sites = c->n_samples == 0;
   if (const char *e = getenv("BVCF_SITES")) c->sites = c->sites && atoi(e) != 0;
@@ -1007,6 +1036,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   hipEventElapsedTime(&ms, s.ev_k0, s.ev_k1);
   r->kernel_ms = ms;
   const BatchCounters ctr = *s.h_counters;
+  adapt_stream_kernel(c, s.used_gen, ctr);
   // slot i of alleles[] / tasks / class maps belongs to line i; the counters count the extras
   const uint64_t n_alleles = (uint64_t)ctr.n_lines + ctr.n_alleles;
   const uint64_t n_tasks = (uint64_t)ctr.n_lines + ctr.n_tasks;
@@ -1337,6 +1367,7 @@ int bvcf_bench_device_slots(bvcf_ctx *c, const void *const *dblocks, const size_
   }
   for (auto &e : ev) hipEventDestroy(e);
   const BatchCounters ctr = *s.h_counters;
+  adapt_stream_kernel(c, c->gen_mode, ctr);  // (every launch of this call went through the same kernel)
   if (counts) {
     counts[0] = ctr.n_lines;
     counts[1] = (uint64_t)ctr.n_lines + ctr.n_alleles;

@@ -524,12 +524,14 @@ struct Run {
   bvcf_params params;              // what every ctx of the run is created with (prepare_run), bar the device
 };
 
-// Which device path suits this file: the streaming path shines when sample fields are the bare
-// 4-byte "x|y<TAB>" of a FORMAT == GT file (1000-Genomes style); files whose FORMAT carries more
-// sub-fields are scanned by the general path, for which the census path is the faster frame.
+// Which device path suits this file: the streaming path reads the text once -- the bare 4-byte "x|y<TAB>" fields of
+// a FORMAT == GT file (1000-Genomes style) through its regular scan, fields with further sub-fields through its
+// general stream -- as long as a line's class map fits the LDS stage (16 384 samples); beyond that, lines that are
+// not regular would all be left to k_gt, for which the census path is the better frame.
 uint32_t choose_path(const Run &R, const uint8_t *data, size_t n) {
   if (R.pre.header.size() < 256) return 0;  // the library's own rule (census for narrow files)
   if (R.pre.header.size() >= 9 + (size_t)BVCF_WIDE_SAMPLES) return 0;  // very wide lines: the census path's split scan
+  if (R.pre.header.size() <= 9 + 16384u) return 2;
   // FORMAT column (index 8) of the first record
   size_t pos = 0;
   for (int tabs = 0; pos < n && tabs < 8; pos++) {

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   const bool pipelined = n_chunks >= 1 && n_chunks <= (uint32_t)kPipeChunks && a.eol_chars == 1;
   uint32_t cm_next = 0, cm_end = 0;  // this wave's private block of class-map slots
   uint32_t seen = 0;                 // terminated lines this wave walked over
+  uint32_t n_other = 0;              // listed lines that were not of the regular shape (left to k_gt)
 
   // A wave owns a contiguous run of tiles and walks it front to back, so only the first tile needs
   // a search for its first line start (those bytes are the previous wave's last line).  Entries
@@ -411,7 +412,8 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
     }
 
     // ---- not a regular "x|y<TAB>" region: only find where the line ends here; its ALT #1 scan is
-    // left to k_gt (k_head turns the entry into a task), which also settles its field count
+    // left to k_gt (k_head turns the entry into a task), which also settles its field count.  (A file made of such
+    // lines is walked by k_stream_gen instead, see there and bvcf_core.hip.)
     {
       const uint32_t e = find_eol(a, s_begin, nb);
       if (e == kNone) break;  // unterminated tail
@@ -425,7 +427,10 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
       // a line shorter than n_header - 1 bytes cannot have n_header fields: never listed (this
       // is what bounds the per-tile quota)
       const GtStats none = {0, 0, 0, 0, 0};
-      if (cend - p + 1u >= a.n_header) commit(p, cend, none, true, BVCF_NO_CMAP);
+      if (cend - p + 1u >= a.n_header) {
+        commit(p, cend, none, true, BVCF_NO_CMAP);
+        n_other++;
+      }
       p = cend + a.eol_chars;
     }
   }
@@ -434,6 +439,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
     n_local = 0;
   }
   if (lane == 0 && seen) atomicAdd(&a.counters->lines_seen, seen);
+  if (lane == 0 && n_other) atomicAdd(&a.counters->n_other_shape, n_other);
 #ifdef BVCF_EXP_TIMES
   if (lane == 0) {
     g_wave_t[1][wave] = wall_clock64();
@@ -441,6 +447,10 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   }
 #endif
 }
+
+}  // namespace bvcf_dev
+#include "bvcf_streamgen.hip.h"
+namespace bvcf_dev {
 
 // tile-local entries -> input order (the exclusive scan of the tile counts is in census/group_base)
 __global__ __launch_bounds__(kWgThreads) void k_order(KernelArgs a) {

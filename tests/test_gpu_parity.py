@@ -12,11 +12,14 @@ import vcfgen
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["census", "streaming", "census-wide"])
+@pytest.fixture(autouse=True, params=["census", "streaming", "census-wide", "streaming-general"])
 def bvcf_path(request, monkeypatch):
-    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`), and on the census
-    path with the regular scan split over waves as it is for cohorts of >= 32 768 samples (k_gt_wide)"""
-    monkeypatch.setenv("BVCF_PATH", "2" if request.param == "streaming" else "1")
+    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`), on the census
+    path with the regular scan split over waves as it is for cohorts of >= 32 768 samples (k_gt_wide), and on the
+    streaming path with k_stream_gen -- the kernel for files whose sample fields carry more than GT -- pinned from the
+    first batch (left alone the library switches to it after a batch of such lines)"""
+    monkeypatch.setenv("BVCF_PATH", "2" if request.param.startswith("streaming") else "1")
+    monkeypatch.setenv("BVCF_GEN_STREAM", "1" if request.param == "streaming-general" else "0")
     if request.param == "census-wide":
         monkeypatch.setenv("BVCF_WIDE", "1")
         monkeypatch.setenv("BVCF_WIDE_WIN", "1000")  # the general scan of one line in 1000-byte shares
@@ -502,7 +505,7 @@ def test_cli_large_stream(bv, golden_1kg):
 def test_streaming_tile_boundaries(bv, monkeypatch, tile_kb, bvcf_path, golden_1kg):
     """tiny tiles: almost every line straddles a tile (and wave-run) boundary, many tiles hold no
     line start at all, and 10 KB lines span several tiles"""
-    if bvcf_path != "streaming":
+    if not bvcf_path.startswith("streaming"):
         pytest.skip("tile logic only exists on the streaming path")
     monkeypatch.setenv("BVCF_TILE_KB", str(tile_kb))
     for seed, n_lines, n_samples, fmt_extra, weird in [(61, 500, 3, False, 0.05), (62, 400, 40, True, 0.05),

@@ -8,11 +8,13 @@ import oracle_lib as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["census", "streaming", "census-wide"])
+@pytest.fixture(autouse=True, params=["census", "streaming", "census-wide", "streaming-general"])
 def bvcf_path(request, monkeypatch):
-    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`), and on the census
-    path with the regular scan split over waves as it is for cohorts of >= 32 768 samples (k_gt_wide)"""
-    monkeypatch.setenv("BVCF_PATH", "2" if request.param == "streaming" else "1")
+    """every parity test runs on both device paths (bvcf_params.path; BVCF_PATH overrides `choose`), on the census
+    path with the regular scan split over waves as it is for cohorts of >= 32 768 samples (k_gt_wide), and on the
+    streaming path with k_stream_gen pinned (see test_gpu_parity.py)"""
+    monkeypatch.setenv("BVCF_PATH", "2" if request.param.startswith("streaming") else "1")
+    monkeypatch.setenv("BVCF_GEN_STREAM", "1" if request.param == "streaming-general" else "0")
     if request.param == "census-wide":
         monkeypatch.setenv("BVCF_WIDE", "1")
         monkeypatch.setenv("BVCF_WIDE_WIN", "1000")  # the general scan of one line in 1000-byte shares
