@@ -1,0 +1,199 @@
+"""k_stream_gen (bvcf_streamgen.hip.h), the streaming kernel for files whose sample fields carry more than GT
+(/root/reference main.go:1042-1194, the general branch of makeHetHomozygotes): crafted inputs for what its packed-flag
+fast path, its byte-parallel medium path and its exact handler each have to get right, compared with the oracle through
+the C-ABI.  Every case also runs on k_stream (+ k_gt for the lines it defers) and on the census path."""
+import os
+import random
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle_lib as orc
+import vcfgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["streaming-general", "streaming", "census"])
+def bvcf_path(request, monkeypatch):
+    monkeypatch.setenv("BVCF_PATH", "2" if request.param.startswith("streaming") else "1")
+    monkeypatch.setenv("BVCF_GEN_STREAM", "1" if request.param == "streaming-general" else "0")
+    return request.param
+
+
+@pytest.fixture(scope="module")
+def bv():
+    import bystro_vcf_amd as b
+    return b
+
+
+def both(bv, vcf, cfg=None, **kw):
+    rc_o, out_o, log_o, n_o = orc.run(vcf, cfg)
+    rc_g, out_g, log_g, n_g = bv.run_buffer(vcf, cfg, **kw)
+    assert (rc_g != 0) == (rc_o != 0), (rc_g, rc_o, log_g)
+    assert n_g == n_o
+    if out_g != out_o:
+        a, b = out_o.split(b"\n"), out_g.split(b"\n")
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert x == y, "row %d differs:\noracle: %r\nhip:    %r" % (i, x[:300], y[:300])
+        assert len(a) == len(b)
+    assert log_g == log_o
+    return out_g
+
+
+def _line(pos, fields, alt="G", info="AC=1", fmt="GT:DP:GQ", chrom="1", filt="PASS"):
+    return "\t".join([chrom, str(pos), ".", "A", alt, "50", filt, info, fmt] + fields) + "\n"
+
+
+def _ref_fields(rng, n, sep="/"):
+    return ["0%s0:%d:%d" % (sep, rng.randint(0, 99), rng.randint(0, 99)) for _ in range(n)]
+
+
+@pytest.mark.parametrize("seed,n_lines,n_samples,weird,eol", [
+    (101, 60, 2504, 0.001, "\n"), (102, 60, 700, 0.02, "\n"), (103, 200, 64, 0.2, "\n"), (104, 10, 16384, 0.0005, "\n"),
+    (105, 10, 16385, 0.0005, "\n"),  # one sample past the LDS stage: left to k_stream + k_gt
+    (106, 80, 300, 0.01, "\r\n"), (107, 50, 1000, 0.0, "\n"), (108, 300, 256, 0.05, "\n"),
+])
+def test_fuzz_fields_beyond_gt(bv, seed, n_lines, n_samples, weird, eol):
+    vcf = vcfgen.gen_vcf(seed, n_lines, n_samples, True, weird, eol=eol)
+    both(bv, vcf, {"allow": ""})
+    both(bv, vcf, {"keepId": True, "keepInfo": True, "exclude": "q10"})
+
+
+@pytest.mark.parametrize("ns", [300, 1100])
+def test_reference_word_variants_and_carrier_density(bv, ns):
+    """lines whose reference genotype is written "0/0:", "0|0:", "0/0<TAB>" (fields without sub-fields) or a mix; no
+    carriers, one, a list's worth (15 map bytes), one more, and most samples"""
+    rng = random.Random(ns)
+    rows = []
+    pos = 100
+    for sep in ["/", "|", "mix"]:
+        for n_car in [0, 1, 2, 15, 16, 40, ns // 2, ns]:
+            f = []
+            for i in range(ns):
+                s = sep if sep != "mix" else rng.choice("/|")
+                f.append("0%s0:%d:%d" % (s, rng.randint(0, 99), rng.randint(0, 99)))
+            for i in rng.sample(range(ns), n_car):
+                s = sep if sep != "mix" else rng.choice("/|")
+                f[i] = "%s%s%s:%d:%d" % (rng.choice("01."), s, rng.choice("01."), rng.randint(0, 9), rng.randint(0, 99))
+            pos += 7
+            rows.append(_line(pos, f))
+    # sub-fields dropped in some samples (VCF allows trailing ones to be left out): "0/0<TAB>", and at the line's end
+    for k in range(6):
+        f = _ref_fields(rng, ns)
+        for i in rng.sample(range(ns), ns // 3):
+            f[i] = rng.choice(["0/0", "0/1", "1/1", "./."])
+        if k % 2:
+            f[-1] = rng.choice(["0/0", "0/1", "1|1", "./."])
+        pos += 7
+        rows.append(_line(pos, f))
+    vcf = (vcfgen.header(ns) + "".join(rows)).encode()
+    both(bv, vcf, {"allow": ""})
+
+
+def test_fields_the_fast_gate_does_not_take(bv):
+    """haploid, polyploid, multi-digit and empty fields, further ALT indices: such lines are listed as deferred by
+    k_stream_gen (or get a dense map and k_gt tasks for the further indices) -- results as the reference's general branch"""
+    ns = 400
+    rng = random.Random(5)
+    odd = ["1", "0", ".", "", "0/1/1", "1|1|1", "10/1", "1/10", "0|2", "2/2", "3|1", "./1", "1/.", "0/0/0", "00/1", "+1/1",
+           "1/ 1", "a/b", "0-0", "0/0;", ":", "0/:", "0"]
+    rows = []
+    pos = 500
+    for o in odd:
+        for where in [0, 1, 63, 64, 65, ns - 2, ns - 1]:
+            f = _ref_fields(rng, ns)
+            f[where] = o + (":5:6" if rng.random() < 0.5 and o != ":" else "")
+            pos += 3
+            rows.append(_line(pos, f, alt="G,T,C,GA,AT,ACC,TT,GG,CC,AG,TG"))
+    vcf = (vcfgen.header(ns) + "".join(rows)).encode()
+    both(bv, vcf, {"allow": ""})
+
+
+def test_field_counts_terminators_and_heads(bv):
+    """too few / too many sample fields, a TAB at the end of the line, lines of fewer than ten fields and comments in
+    between, heads longer than a chunk (a 5 KB INFO), bytes >= 0x80 in the head and in a sample field, CRLF"""
+    ns = 320
+    rng = random.Random(9)
+    for eol in ["\n", "\r\n"]:
+        rows = []
+        pos = 900
+        for k in range(40):
+            f = _ref_fields(rng, ns)
+            for i in rng.sample(range(ns), rng.choice([0, 1, 3, 30])):
+                f[i] = "0/1:3:4"
+            info = "AC=1"
+            kind = k % 10
+            if kind == 1:
+                f = f[:-1]
+            elif kind == 2:
+                f = f + ["0/0:1:1"]
+            elif kind == 3:
+                f[-1] = ""
+            elif kind == 4:
+                info = "CSQ=" + vcfgen.rand_bases(rng, 5000, "ACGT|,")
+            elif kind == 5:
+                info = "NOTE=caféü"
+            elif kind == 6:
+                f[rng.randrange(ns)] = "0/1:é:4"
+            elif kind == 7:
+                rows.append("1\t5\tshort\n")
+                rows.append("#a comment\n")
+            elif kind == 8:
+                f = f[:ns // 2]
+            pos += 11
+            rows.append(_line(pos, f, info=info))
+        text = vcfgen.header(ns) + "".join(rows)
+        if eol != "\n":
+            text = text.replace("\n", eol)
+        both(bv, text.encode("utf-8"), {"allow": "", "keepInfo": True})
+
+
+def test_every_alignment_of_a_carrier(bv):
+    """one carrier per line, moved sample by sample through two chunks' worth of fields of uneven length: every byte
+    offset of a field start inside a dword, a lane and across the chunk edge (the word then comes from the next chunk)"""
+    ns = 260
+    rng = random.Random(13)
+    widths = [rng.choice(["%d", "%d%d", "%d%d%d"]) for _ in range(ns)]
+    rows = []
+    for who in range(ns):
+        f = ["0/0:" + (w.replace("%d", "7")) + ":9" for w in widths]
+        f[who] = "1|0:" + f[who][4:] if who % 2 else "1/1:" + f[who][4:]
+        rows.append(_line(1000 + who, f))
+    vcf = (vcfgen.header(ns) + "".join(rows)).encode()
+    both(bv, vcf, {"allow": ""})
+
+
+def test_regular_file_through_the_general_kernel_and_back(bv, monkeypatch):
+    """left alone (no BVCF_GEN_STREAM) a ctx picks the kernel for the next batch by the shape of the last one: batches of
+    GT-only lines, then GT:DP lines, then GT-only again, through one ctx -- every batch equal to the census path's"""
+    monkeypatch.delenv("BVCF_GEN_STREAM", raising=False)
+    ns = 300
+    texts = [vcfgen.gen_vcf(200 + i, 60, ns, fmt_extra=(i // 2) % 2 == 1, weird=0.0) for i in range(8)]
+    bodies = [t[t.index(b"#CHROM"):] for t in texts]
+    bodies = [b[b.index(b"\n") + 1:] for b in bodies]
+
+    def run(path):
+        ctx = bv.Ctx(9 + ns, path=path)
+        got = []
+        for b in bodies:
+            r = ctx.process(b)
+            cols = ["pos", "alt_idx", "ac", "an", "n_het", "n_hom", "n_miss", "kind", "site_type", "trtv"]
+            recs = []
+            for i, L in enumerate(r.lines):
+                if int(L["status"]) != 0:
+                    continue
+                for a in r.records(i):
+                    recs.append((i, tuple(int(a[c]) for c in cols), tuple(int(x) for x in r.classes(a))))
+            got.append((recs, [(int(L["off"]), int(L["len"]), int(L["status"]), int(L["n_rec"])) for L in r.lines]))
+        ctx.close()
+        return got
+
+    monkeypatch.setenv("BVCF_PATH", "2")
+    a = run(2)
+    monkeypatch.setenv("BVCF_PATH", "1")
+    b = run(1)
+    assert len(a) == len(b) == len(bodies)
+    for x, y in zip(a, b):
+        assert x == y
