@@ -295,7 +295,7 @@ def main():
         # every row (4 bytes per sample).  Streaming path, k_stream, and sites-only input, k_sites: every byte of
         # every row (it is also the pass that finds the lines).
         streaming = ctx.path() == 2
-        kernel = "k_stream" if streaming else ("k_gt" if ns else "k_sites")
+        kernel = ctx.stream_kernel() if streaming else ("k_gt" if ns else "k_sites")
         alg_bytes = int(mean_bytes) if (streaming or not ns) else args.rows * 4 * ns
         achieved = alg_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms else None
         pmc = None

@@ -38,7 +38,7 @@ ALT_BASE, ALT_INS, ALT_DEL = 0, 1, 2
 CLS_NONE, CLS_HET, CLS_HOM, CLS_MISSING = 0, 1, 2, 3
 
 # the measurement hooks of include/bvcf_bench.h (not part of the drop-in ABI)
-BENCH_EXPORTS = ["bvcf_bench_device", "bvcf_bench_device_slots"]
+BENCH_EXPORTS = ["bvcf_bench_device", "bvcf_bench_device_slots", "bvcf_bench_stream_kernel"]
 
 # every symbol include/bvcf.h declares
 EXPORTS = [
@@ -406,6 +406,13 @@ class Ctx:
     def path(self):
         """1 = census path, 2 = streaming path"""
         return lib.bvcf_path(self.h)
+
+    def stream_kernel(self):
+        """the streaming kernel the next batch goes through: "k_stream", "k_stream_gen", or None off the streaming path"""
+        lib.bvcf_bench_stream_kernel.argtypes = [C.c_void_p]
+        lib.bvcf_bench_stream_kernel.restype = C.c_int
+        k = lib.bvcf_bench_stream_kernel(self.h)
+        return None if k < 0 else ("k_stream_gen" if k else "k_stream")
 
     def counters(self):
         out = (C.c_uint64 * 8)()

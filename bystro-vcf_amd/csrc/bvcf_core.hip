@@ -422,7 +422,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     hipMemsetAsync(a.counters, 0, sizeof(BatchCounters), st);
     if (ev_gt0) hipEventRecord(ev_gt0, st);
     if (a.gen_stream)
-      hipLaunchKernelGGL(k_stream_gen, dim3(c->gen_grid), dim3(kWgThreads), 0, st, a);
+      hipLaunchKernelGGL(k_stream_gen, dim3(c->gen_grid), dim3(kWgThreads), gen_lds_bytes(a.n_samples), st, a);
     else
       hipLaunchKernelGGL(k_stream, dim3(c->stream_grid), dim3(kWgThreads), 0, st, a);
     if (ev_gt1) hipEventRecord(ev_gt1, st);
@@ -738,11 +738,12 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   }
   c->stream_grid = c->n_cu * per_cu;
   per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream_gen, kWgThreads, 0) != hipSuccess || per_cu < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream_gen, kWgThreads, gen_lds_bytes(c->n_samples)) != hipSuccess || per_cu < 1)
     per_cu = 2;
+  per_cu = std::min(per_cu, 6);  // (7 fit a cohort of a few thousand samples; 6 measured best)
   if (const char *e = getenv("BVCF_GEN_WGS")) {  // experiment: workgroups per CU
     const int w = atoi(e);
-    if (w >= 1 && w <= 8) per_cu = w;
+    if (w >= 1 && w <= 8) per_cu = std::min(per_cu, w);
   }
   c->gen_grid = c->n_cu * per_cu;
   // sites-only input takes the fused kernel (BVCF_SITES=0: the census chain with k_head, for A/B and parity tests)
@@ -1160,6 +1161,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
 }
 
 int bvcf_path(const bvcf_ctx *c) { return c ? (c->fused ? 2 : 1) : BVCF_E_ARG; }
+int bvcf_bench_stream_kernel(const bvcf_ctx *c) { return (c && c->fused) ? (c->gen_mode ? 1 : 0) : -1; }
 
 int bvcf_counters(bvcf_ctx *c, uint64_t out[8]) {
   if (!c || !out) return BVCF_E_ARG;

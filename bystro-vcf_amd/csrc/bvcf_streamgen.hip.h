@@ -36,7 +36,14 @@
 
 namespace bvcf_dev {
 
-constexpr int kGenRing = 8;  // chunks of the LDS ring: one being read, the others in flight
+// (measured on the GT:DP:GQ profile, 2 504 samples: a ring of 8 with the 4 workgroups per CU its LDS allows reads
+// 3.4 TB/s, a ring of 4 with 6 workgroups 3.8 TB/s -- the kernel is bound by instruction issue, more waves hide more)
+#ifndef BVCF_GEN_RING
+#define BVCF_GEN_RING 4
+#endif
+constexpr int kGenRing = BVCF_GEN_RING;  // chunks of the LDS ring: one being read, the others in flight
+// s_waitcnt immediate of gfx9: vmcnt(n), nothing asked of expcnt / lgkmcnt
+constexpr int vmcnt_imm(int n) { return (n & 0xF) | 0x70 | 0xF00 | ((n >> 4) << 14); }
 
 constexpr uint32_t kNoneGen = kNone;
 
@@ -429,17 +436,17 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
   auto slot = [&](uint32_t c) -> u32x4 {
     return *reinterpret_cast<const u32x4 *>(ring + (c % (uint32_t)kGenRing) * kChunk + 16u * (uint32_t)lane);
   };
-  static_assert(kGenRing == 8, "the counted waits below are written for a ring of 8");
+  static_assert((kGenRing & (kGenRing - 1)) == 0 && kGenRing >= 2 && kGenRing <= 16, "ring: a power of two");
 #pragma unroll
   for (int j = 0; j < kGenRing; j++) issue((uint32_t)j);
-  __builtin_amdgcn_s_waitcnt(0x0F77);  // vmcnt(7): chunk 0 has landed
+  __builtin_amdgcn_s_waitcnt(vmcnt_imm(kGenRing - 1));  // chunk 0 has landed
   u32x4 v = slot(0);
   uint32_t since_fold = 0;
 #pragma nounroll
   for (uint32_t c = 0; !done; c++) {
     const uint32_t cs = chunk_start(c);
     if (cs >= nb) break;  // the unterminated tail of the block: dropped (main.go:354-358)
-    __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): chunk c + 1 has landed
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(kGenRing - 2));  // chunk c + 1 has landed
     const u32x4 nv = slot(c + 1u);
     issue(c + (uint32_t)kGenRing);  // into the slot of chunk c, which is in `v` since the last round
     bool handled = false;
@@ -484,17 +491,27 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
       since_fold = 0;
     }
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no LDS-DMA may land after the wave has gone
+  __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));  // no LDS-DMA may land after the wave has gone
 }
 
 // ------------------------------------------------------------------ k_stream_gen: k_stream's frame around the general stream
 // (runs of tiles per wave, tile-local entries, per-wave class-map slot ranges: all as in k_stream, whose k_order /
 // k_head_lean / k_gt / k_finish follow unchanged)
+// LDS of a workgroup, sized at launch (gen_lds_bytes): per wave the chunk ring, the stage of a dense class map -- 1 KiB
+// per 4 096 samples, so that cohorts of a few thousand leave room for a fourth workgroup per CU -- and the carrier list
+__host__ __device__ inline uint32_t gen_stage_bytes(uint32_t n_samples) {
+  const uint32_t n_chunks = (n_samples * 4u + kChunk - 1u) / kChunk;
+  return ((n_chunks + 15u) / 16u) * 1024u;
+}
+__host__ __device__ inline uint32_t gen_lds_bytes(uint32_t n_samples) {
+  return (uint32_t)kWavesPerWg * ((uint32_t)kGenRing * kChunk + gen_stage_bytes(n_samples) + 64u * 4u);
+}
 __global__ __launch_bounds__(kWgThreads) void k_stream_gen(KernelArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[kWavesPerWg][kGenRing * kChunk];
-  __shared__ uint32_t s_list[kWavesPerWg][64];
-  uint8_t *stage = s_stage[wave_in_wg()];
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_gen[];
+  const uint32_t stage_bytes = gen_stage_bytes(a.n_samples);
+  const uint8_t *ring = s_gen + wave_in_wg() * ((uint32_t)kGenRing * kChunk);
+  uint8_t *stage = s_gen + (uint32_t)kWavesPerWg * ((uint32_t)kGenRing * kChunk) + wave_in_wg() * stage_bytes;
+  uint32_t *list = reinterpret_cast<uint32_t *>(s_gen + (uint32_t)kWavesPerWg * ((uint32_t)kGenRing * kChunk + stage_bytes)) + wave_in_wg() * 64u;
   const int lane = lane_id();
   const uint32_t wave = wave_in_grid();
   const uint32_t n_waves = gridDim.x * kWavesPerWg;
@@ -557,7 +574,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream_gen(KernelArgs a) {
     if (maps && !deferred) cm_next++;
   };
   uint32_t seen = 0, n_regular = 0;
-  if (p != kNone && p < r1) stream_general_run(a, p, r1, n_chunks, stage, s_list[wave_in_wg()], s_ring[wave_in_wg()], seen, n_regular, commit, map_slot);
+  if (p != kNone && p < r1) stream_general_run(a, p, r1, n_chunks, stage, list, ring, seen, n_regular, commit, map_slot);
   for (; tile < tile_hi; tile++) {
     if (lane == 0) a.census[tile] = n_local;
     n_local = 0;

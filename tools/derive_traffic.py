@@ -35,4 +35,20 @@ for k, v in raw.items():
 c3["traffic_bytes_per_launch_per_row"] = c3["k_gt_traffic_bytes_per_launch_per_row"]
 c3["algorithmic"] = {"k_stream_read_bytes_per_row": "the whole line, ~10166 B", "k_gt_read_bytes_per_row": 10016,
                      "write_bytes_per_row": 672}
+# the general-format profile (c5), k_stream_gen: optional pair of files from the same script
+import os
+if os.path.exists("%s/pmc_fetch_size_c5.csv" % d):
+    rows5 = 98304  # bench.py SHAPES["c5"]
+    v = {}
+    for ctr, tagc in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open("%s/pmc_%s_size_c5.csv" % (d, tagc)))
+                if "bvcf_dev::k_stream_gen(" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+        v[ctr] = sum(vals) / len(vals)
+    rd, wr = 2 * v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
+    out["raw_KiB_per_dispatch"]["k_stream_gen (c5, %d rows per dispatch)" % rows5] = v
+    out["c5"] = {"rows_per_dispatch": rows5, "k_stream_gen_read_bytes_per_launch": rd, "k_stream_gen_write_bytes_per_launch": wr,
+                 "k_stream_gen_traffic_bytes_per_launch": rd + wr,
+                 # (the key bench.py looks up for the streaming path's dominant kernel)
+                 "k_stream_traffic_bytes_per_launch_per_row": (rd + wr) / rows5,
+                 "algorithmic": {"k_stream_gen_read_bytes_per_row": "the whole line, ~24361 B"}}
 print(json.dumps(out, indent=1))

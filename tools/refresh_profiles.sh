@@ -32,14 +32,17 @@ for w in $WHAT; do
       stats bench_c4_auto --profile c4
       stats bench_c2_sites_only --profile c2
       stats bench_c2_sites_only_one_block_at_a_time --profile c2 --slots 1
-      stats bench_c5_general_scan --profile c5
-      stats bench_c5_general_scan_one_block_at_a_time --profile c5 --slots 1
+      stats bench_c5_general_stream --profile c5
+      stats bench_c5_general_stream_one_block_at_a_time --profile c5 --slots 1
+      BVCF_GEN_STREAM=0 stats bench_c5_k_stream_plus_k_gt --profile c5
       ;;
     pmc)
       pmc FETCH_SIZE pmc_fetch_size_streaming --path 2
       pmc WRITE_SIZE pmc_write_size_streaming --path 2
       pmc FETCH_SIZE pmc_fetch_size_census --path 1
       pmc WRITE_SIZE pmc_write_size_census --path 1
+      BVCF_GEN_STREAM=1 pmc FETCH_SIZE pmc_fetch_size_c5 --profile c5
+      BVCF_GEN_STREAM=1 pmc WRITE_SIZE pmc_write_size_c5 --profile c5
       ;;
     line)
       cd $R
