@@ -401,8 +401,13 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
     if (n_sp < kDenseMode) {
       // entries of the lanes in lane order, a lane's fields in field order
       const uint32_t mine = __popc(any);
-      uint32_t n_new;
-      uint32_t at = n_sp + wave_excl_scan(mine, &n_new);
+      uint32_t n_new, at;
+      if ((bl & (bl - 1ull)) == 0) {  // one lane (the usual case): no prefix sum
+        n_new = lane_value(mine, __ffsll((long long)bl) - 1);
+        at = n_sp;
+      } else {
+        at = n_sp + wave_excl_scan(mine, &n_new);
+      }
       if (n_sp + n_new <= BVCF_CMAP_SPARSE_MAX) {
         if (any & 0x00000080u) glist[at++] = (s0 << 2) | cls_of(0);
         if (any & 0x00008000u) glist[at++] = (s1 << 2) | cls_of(1);
@@ -463,20 +468,30 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
       const uint32_t pt = (uint32_t)__builtin_amdgcn_update_dpp((int)pl, (int)t3, 0x138, 0xF, 0xF, false);
       const uint32_t S0 = __builtin_amdgcn_alignbyte(t0, pt, 3u), S1 = __builtin_amdgcn_alignbyte(t1, t0, 3u);
       const uint32_t S2 = __builtin_amdgcn_alignbyte(t2, t1, 3u), S3 = __builtin_amdgcn_alignbyte(t3, t2, 3u);
+      // the four bytes at the first start of a dword: its flag sits at bit 8 r + 7 (no flag: any r will do, the word is
+      // not looked at)
       auto at_start = [](uint32_t hi, uint32_t lo, uint32_t S) -> uint32_t {
-        return __builtin_amdgcn_alignbyte(hi, lo, ((uint32_t)__builtin_ctz(S | 0x80000000u) >> 3) & 3u);
+        uint32_t bit;  // (v_ffbl_b32 of 0 is -1, which C's ctz cannot say: the byte picked then is 3, and not looked at)
+        asm("v_ffbl_b32 %0, %1" : "=v"(bit) : "v"(S));
+        return __builtin_amdgcn_alignbyte(hi, lo, __builtin_amdgcn_ubfe(bit, 3u, 2u));
       };
       const uint32_t u0 = at_start(v.y, v.x, S0), u1 = at_start(v.z, v.y, S1), u2 = at_start(v.w, v.z, S2);
       // (the next chunk's first dword is asked for last: its LDS read has had the lines above to arrive)
       const uint32_t nx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nv.x);
       const uint32_t d4 = (uint32_t)__builtin_amdgcn_update_dpp((int)nx0, (int)v.x, 0x130, 0xF, 0xF, false);
       const uint32_t u3 = at_start(d4, v.w, S3);
+      // (the kernel is bound by instructions issued, of any kind: selecting u ^ R costs one instruction less per dword
+      // than two compares and the scalar logic on their masks)
       const uint32_t mis = (S0 ? u0 ^ R : 0u) | (S1 ? u1 ^ R : 0u) | (S2 ? u2 ^ R : 0u) | (S3 ? u3 ^ R : 0u);
+      const bool is_hard = hard != 0;
       if (!__any((mis | hard) != 0)) {
-        tabs_lane += __popc(t0) + __popc(t1) + __popc(t2) + __popc(t3);
+        tabs_lane = (uint32_t)__builtin_popcount(t0) + tabs_lane;
+        tabs_lane = (uint32_t)__builtin_popcount(t1) + tabs_lane;
+        tabs_lane = (uint32_t)__builtin_popcount(t2) + tabs_lane;
+        tabs_lane = (uint32_t)__builtin_popcount(t3) + tabs_lane;
         pl = lane_value(t3, kWave - 1) & 0x80000000u;
         handled = true;
-      } else if (!__any(hard != 0)) {
+      } else if (!__any(is_hard)) {
         medium(t0, t1, t2, t3, S0, S1, S2, S3, u0, u1, u2, u3);
         pl = lane_value(t3, kWave - 1) & 0x80000000u;
         handled = true;
