@@ -53,7 +53,7 @@ SHAPES = {"c2": (1_000_000, 8), "c3": (311_296, 8), "c4": (262_144, 8), "c5": (9
 WORKLOADS = {"c2": "BASELINE configs[1]: sites-only, biallelic SNPs, 0 samples",
              "c3": "BASELINE configs[2]: 1KG-Phase3 chr1-shaped, 2504 samples, biallelic SNPs",
              "c4": "BASELINE configs[3]: 2504 samples, 20% multiallelic + 15% indels",
-             "c5": "not a BASELINE config: 2504 samples with GT:DP:GQ fields (general scan path)"}
+             "c5": "not a BASELINE config: 2504 samples with GT:DP:GQ fields (k_stream_gen once the ctx has seen the shape)"}
 
 
 def rank_blocks(rank, n_blocks, rows):
