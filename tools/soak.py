@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential soak (not part of the test suite): many random VCF shapes through the HIP path and the
-oracle, both device paths and the split scans of very wide lines, TSV + log + dosage rows compared.  usage: python tools/soak.py [n_cases] [seed0]"""
+oracle, both device paths (the streaming one with k_stream, with k_stream_gen, and choosing per batch) and the split
+scans of very wide lines, TSV + log + dosage rows compared.  usage: python tools/soak.py [n_cases] [seed0]"""
 import os
 import random
 import sys
@@ -22,15 +23,19 @@ for i in range(n_cases):
                      2559, 2560, 2561, 3000, rng.randint(1, 3500)])
     n_lines = rng.randint(20, 160 if ns > 1000 else 400)
     weird = rng.choice([0.0, 0.0, 0.001, 0.01, 0.05, 0.3])
-    fmt_extra = rng.random() < 0.25
+    fmt_extra = rng.random() < 0.4
     eol = "\r\n" if rng.random() < float(os.environ.get("SOAK_CRLF", "0.1")) else "\n"
     vcf = vcfgen.gen_vcf(seed0 + i, n_lines, ns, fmt_extra, weird, eol)
     cfg = rng.choice([{"allow": ""}, {}, {"keepId": True, "keepInfo": True, "keepPos": True, "exclude": "q10"}])
     rc_o, out_o, log_o, n_o = orc.run(vcf, cfg)
     want_dos = orc.run_dosage(vcf, cfg) if ns else []
-    for path in ("1", "2", "wide"):
-        # "wide": the census path with the scans of one line split over waves, as for cohorts of >= 32 768 samples
-        os.environ["BVCF_PATH"] = "1" if path == "wide" else path
+    for path in ("1", "2", "2g", "2a", "wide"):
+        # "wide": the census path with the scans of one line split over waves, as for cohorts of >= 32 768 samples;
+        # "2g": the streaming path with k_stream_gen pinned; "2a": the ctx picks k_stream / k_stream_gen per batch
+        os.environ["BVCF_PATH"] = "1" if path == "wide" else path[0]
+        os.environ.pop("BVCF_GEN_STREAM", None)
+        if path in ("2", "2g"):
+            os.environ["BVCF_GEN_STREAM"] = "1" if path == "2g" else "0"
         os.environ.pop("BVCF_WIDE", None)
         os.environ.pop("BVCF_WIDE_WIN", None)
         os.environ["BVCF_DEVICE_NAMES"] = rng.choice(["0", "1"])  # host join / device-rendered name lists
@@ -55,5 +60,5 @@ for i in range(n_cases):
                 i, seed0 + i, path, ns, n_lines, weird, fmt_extra, eol, cfg), flush=True)
     if i % 20 == 19:
         print("%d cases done, %d mismatches" % (i + 1, bad), flush=True)
-print("soak: %d cases x 3 modes, %d mismatches" % (n_cases, bad))
+print("soak: %d cases x 5 modes, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)
