@@ -96,6 +96,7 @@ struct bvcf_ctx {
   // left to k_gt) or k_stream_gen (any fields, one pass).  Adaptive: a batch whose lines were mostly of the other
   // kernel's shape switches (the results are the same either way); BVCF_GEN_STREAM=0 / 1 pins it.
   bool gen_mode = false;
+  bool shape_seen = false;  // gen_mode has had its first hint (peek_line_shape) or a batch's counters
   int gen_policy = -1;  // -1 adaptive, 0 never, 1 always
   uint32_t gen_grid = 0;
   bool wide = false;  // census path with k_gt_wide in front of k_gt (see kWideSamples)
@@ -413,6 +414,7 @@ void launch_names(bvcf_ctx *c, const KernelArgs &a, const NameArgs &na, hipStrea
 // a batch's counters are in: should the next one go through the other streaming kernel?
 void adapt_stream_kernel(bvcf_ctx *c, bool was_gen, const BatchCounters &ctr) {
   if (c->gen_policy >= 0 || !c->fused || ctr.n_lines < 16) return;
+  c->shape_seen = true;
   if ((uint64_t)ctr.n_other_shape * 2u > ctr.n_lines) c->gen_mode = !was_gen;
 }
 
@@ -840,9 +842,34 @@ int bvcf_reserve(bvcf_ctx *c, uint64_t lines, uint64_t alleles, uint64_t cmap_by
   return BVCF_OK;
 }
 
+// The very first batch of a ctx has no predecessor to tell the shape of the file's lines: when its text is on the host
+// anyway, the first line with ten fields says it (a single-batch run of a GATK file would otherwise go through k_stream +
+// k_gt).  Only a hint -- either kernel handles every line.
+static void peek_line_shape(bvcf_ctx *c, const uint8_t *block, size_t nbytes) {
+  c->shape_seen = true;
+  if (c->gen_policy >= 0 || !c->fused || !c->n_samples) return;
+  const uint8_t eol = (uint8_t)c->p.eol_byte;
+  size_t ls = 0;
+  for (int tries = 0; tries < 8 && ls < nbytes; tries++) {
+    const uint8_t *e = (const uint8_t *)memchr(block + ls, eol, nbytes - ls);
+    if (!e) return;
+    const size_t le = (size_t)(e - block);  // the terminator
+    size_t pos = ls;
+    int tabs = 0;
+    for (; pos < le && tabs < 9; pos++) tabs += block[pos] == '\t';
+    if (tabs == 9) {
+      const size_t cend = le + 1 - c->p.eol_chars;  // content end
+      c->gen_mode = !(cend >= pos && cend - pos + 1 == 4ull * c->n_samples);
+      return;
+    }
+    ls = le + 1;
+  }
+}
+
 int bvcf_submit(bvcf_ctx *c, const uint8_t *block, size_t nbytes, uint64_t batch_seq) {
   if (!c || (!block && nbytes)) return BVCF_E_ARG;
   static const uint8_t empty = 0;
+  if (!c->shape_seen && block && nbytes) peek_line_shape(c, block, nbytes);
   return submit_common(c, block ? block : &empty, nullptr, nbytes, batch_seq);
 }
 

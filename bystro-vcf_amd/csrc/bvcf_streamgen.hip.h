@@ -57,14 +57,14 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
   const uint32_t nb = a.nbytes;
   const bool maps = a.want_cmap != 0;
   const bool list_ok = maps && a.cmap_stride >= 4u * kSparseWords;
-  // glist: list mode, (sample << 2 | class) of the carriers
+  // glist: list mode, (sample << 8 | first allele digit << 4 | second allele digit) of every field that is not the
+  // reference genotype -- digits as the byte ^ '0' & 15, i.e. 14 for '.' (the classes of every ALT index follow from them)
   uint32_t *stage32 = reinterpret_cast<uint32_t *>(stage);  // dense mode: the 2-bit map
   const uint32_t base = p0 & ~3u;
   const uint32_t cap_off = (a.cap - 16u) & ~3u;
   // (32-bit offsets do not wrap: a block ends below 4 GiB - 1 MiB, the stream stops at the first chunk past it and
   // loads run kGenRing chunks ahead)
   auto chunk_start = [&](uint32_t c) -> uint32_t { return base + c * kChunk; };
-  auto fetch = [&](uint32_t c) -> u32x4 { return ld_stream(a.buf + min(chunk_start(c) + 16u * (uint32_t)lane, cap_off)); };
 
   // ---- state (wave-uniform unless said otherwise)
   enum : uint32_t { kHead = 0, kSamples = 1 };
@@ -78,7 +78,6 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
   uint32_t het = 0, hom = 0, miss = 0;  // per lane
   uint32_t n_sp = 0;       // list entries; kDenseMode once the map is dense
   uint32_t bad = 0;        // the line has a field this scan does not take: deferred (per lane until the line ends)
-  uint32_t multi = 0;      // some sample carries an ALT index above 1 (per lane)
   uint32_t pl = 0;         // 0x80000000 if the last byte of the previous chunk was a TAB
   uint32_t R = 0x3A302F30u;  // "0/0:" -- the reference genotype word of this file, adopted as seen
   bool done = false;
@@ -90,9 +89,13 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
     tabs_lane = 0;
     het = hom = miss = 0;
     bad = 0;
-    multi = 0;
     n_sp = list_ok ? 0u : kDenseMode;
     if (maps && !list_ok) zero_stage(stage, n_map_chunks);
+  };
+  // class of a list entry for ALT index k: '.' in either place makes the sample missing, else one point per allele == k
+  auto entry_class = [](uint32_t e, uint32_t k) -> uint32_t {
+    const uint32_t a4 = (e >> 4) & 15u, b4 = e & 15u;
+    return (a4 == 14u || b4 == 14u) ? 3u : (a4 == k ? 1u : 0u) + (b4 == k ? 1u : 0u);
   };
   auto to_dense = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -102,12 +105,29 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
     if ((uint32_t)lane < n) e = glist[lane];
     zero_stage(stage, n_map_chunks);
     if ((uint32_t)lane < n) {
-      const uint32_t s = e >> 2;
-      atomicOr(stage32 + (s >> 4), (e & 3u) << (2u * (s & 15u)));
+      const uint32_t s = e >> 8;  // (a line with more fields than samples lists them too; it ends up deferred)
+      if (s < ns) atomicOr(stage32 + (s >> 4), entry_class(e, 1u) << (2u * (s & 15u)));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     n_sp = kDenseMode;
+  };
+  // one field per lane that is not the reference genotype (wave-uniform control flow): into the list while it lasts,
+  // else -- ALT #1's class only -- into the stage
+  auto record = [&](bool nonref, uint32_t sidx, uint32_t digits, uint32_t cls) {
+    const unsigned long long br = __ballot(nonref);
+    if (!br) return;
+    if (n_sp < kDenseMode) {
+      const uint32_t n_new = (uint32_t)__popcll(br);
+      if (n_sp + n_new <= BVCF_CMAP_SPARSE_MAX) {
+        const uint32_t at = n_sp + __builtin_amdgcn_mbcnt_hi((uint32_t)(br >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)br, 0u));
+        if (nonref) glist[at] = (sidx << 8) | digits;
+        n_sp = bcast0(n_sp + n_new);
+        return;
+      }
+      to_dense();
+    }
+    if (nonref && cls != 0 && sidx < ns) atomicOr(stage32 + (sidx >> 4), cls << (2u * (sidx & 15u)));
   };
   // the line ended at terminator position e
   auto finish_line = [&](uint32_t e, bool last_is_tab) {
@@ -137,37 +157,64 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
       const uint32_t slot = bcast0(map_slot());
       if (slot != BVCF_NO_CMAP) {
         uint8_t *cm = a.cmap + slot;
-        const bool any_multi = __any(multi != 0);
-        if (n_sp < kDenseMode && !any_multi) {
-          // ---- the list, ascending, one entry per map byte
+        // lists fit the slot for ALT #1 .. #max_k
+        const uint32_t max_k = min(kListAlleles, a.cmap_stride / (4u * kSparseWords));
+        uint32_t kmax = 0;  // 0: a dense map after all
+        uint32_t ent = 0xFFFFFFFFu;
+        if (n_sp < kDenseMode) {
+          // ---- the entries in sample order (they were appended chunk by chunk, but field by field inside a chunk)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           const uint32_t n = n_sp;
           const uint32_t my = (uint32_t)lane < n ? glist[lane] : 0xFFFFFFFFu;
-          const uint32_t my_idx = my >> 4;
-          uint32_t byte = 0;
-          bool leader = (uint32_t)lane < n;
-#pragma nounroll
-          for (uint32_t j = 0; j < n; j++) {
-            const uint32_t ej = lane_value(my, (int)j);
-            if ((ej >> 4) == my_idx) {
-              byte |= (ej & 3u) << (2u * ((ej >> 2) & 3u));
-              if (ej < my) leader = false;
-            }
-          }
-          unsigned long long lb = __ballot(leader);
-          const uint32_t count = (uint32_t)__popcll(lb);
           uint32_t rank = 0;
 #pragma nounroll
-          while (lb) {
-            const int j = __ffsll((long long)lb) - 1;
-            lb &= lb - 1ull;
-            rank += lane_value(my_idx, j) < my_idx ? 1u : 0u;
+          for (uint32_t j = 0; j < n; j++) rank += lane_value(my, (int)j) < my ? 1u : 0u;
+          __builtin_amdgcn_wave_barrier();
+          if ((uint32_t)lane < n) glist[rank] = my;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if ((uint32_t)lane < n) ent = glist[lane];
+          // the highest ALT index a sample carries
+          const uint32_t a4 = (ent >> 4) & 15u, b4 = ent & 15u;
+          const uint32_t top = (uint32_t)lane < n ? max(a4 <= 9u ? a4 : 0u, b4 <= 9u ? b4 : 0u) : 0u;
+          kmax = 1;
+#pragma nounroll
+          for (uint32_t k = 9; k >= 2; k--) {
+            if (__any(top == k)) {
+              kmax = k;
+              break;
+            }
           }
-          uint32_t *list = reinterpret_cast<uint32_t *>(cm);
-          if (leader) __builtin_nontemporal_store((my_idx << 8) | byte, list + 1u + rank);
-          if (lane == 0) __builtin_nontemporal_store(count, list);
-          cm_off = slot | 1u;  // a list; kmax = 1: no further ALT index is carried
+          if (kmax > max_k) kmax = 0;  // no room for that many lists: ALT #1 as a map, the others through k_gt
+        }
+        if (kmax) {
+          // ---- one class list per ALT index (BVCF_ALLELE_CMAP_SPARSE): ascending, one entry per map byte; k_head takes
+          // the counts of the further indices from them and no wave reads the line again (main.go:549-556 rescans)
+          const uint32_t n = n_sp;
+          const uint32_t smp = ent >> 8, idx = smp >> 2, sh = 2u * (smp & 3u);
+          const bool have = (uint32_t)lane < n;
+          // (n <= 15: the entries sit in lanes 0..14, one DPP row)
+          const uint32_t prev_idx = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(have ? idx : 0xFFFFFFFEu), 0x111, 0xF, 0xF, false);
+          const bool leader = have && idx != prev_idx;
+#pragma nounroll
+          for (uint32_t k = 1; k <= kmax; k++) {
+            const uint32_t key = have ? (idx << 8) | (entry_class(ent, k) << sh) : 0xFFFFFFFFu;
+            uint32_t merged = key & 0xFFu;
+            const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key, 0x101, 0xF, 0xF, false);  // row_shl:1
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key, 0x102, 0xF, 0xF, false);
+            const uint32_t n3 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key, 0x103, 0xF, 0xF, false);
+            if ((n1 >> 8) == idx) merged |= n1 & 0xFFu;
+            if ((n2 >> 8) == idx) merged |= n2 & 0xFFu;
+            if ((n3 >> 8) == idx) merged |= n3 & 0xFFu;
+            const bool w = leader && merged != 0;
+            const unsigned long long bw = __ballot(w);
+            uint32_t *list = reinterpret_cast<uint32_t *>(cm + 64u * (k - 1u));
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(bw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bw, 0u));
+            if (w) __builtin_nontemporal_store((idx << 8) | merged, list + 1u + at);
+            if (lane == 0) __builtin_nontemporal_store((uint32_t)__popcll(bw), list);
+          }
+          cm_off = slot | 1u | ((kmax - 1u) << 1);  // bit 0: lists; bits 1-3: ALT #2..#kmax have theirs, none is higher
         } else {
           if (n_sp < kDenseMode) to_dense();
           flush_stage(stage, cm, 0u, n_map_chunks * 64u, a.cmap_stride);
@@ -237,23 +284,8 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
             het += cls == BVCF_CLS_HET;
             hom += cls == BVCF_CLS_HOM;
             miss += cls == BVCF_CLS_MISSING;
-            if ((v0 >= 2u && v0 <= 9u) || (v2 >= 2u && v2 <= 9u)) multi = 1;
           }
-          const bool rec = maps && cls != 0 && s < ns;
-          const unsigned long long br = __ballot(rec);
-          if (br) {
-            if (n_sp < kDenseMode) {
-              const uint32_t cnt = (uint32_t)__popcll(br);
-              if (n_sp + cnt <= BVCF_CMAP_SPARSE_MAX) {
-                const uint32_t at = n_sp + __builtin_amdgcn_mbcnt_hi((uint32_t)(br >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)br, 0u));
-                if (rec) glist[at] = (s << 2) | cls;
-                n_sp = bcast0(n_sp + cnt);
-              } else {
-                to_dense();
-              }
-            }
-            if (n_sp >= kDenseMode && rec) atomicOr(stage32 + (s >> 4), cls << (2u * (s & 15u)));
-          }
+          record(maps && take && !isref, s, ((v0 & 15u) << 4) | (v2 & 15u), cls);
         }
         tabs_base += tot;
         const unsigned long long bc = __ballot(cand != 0);
@@ -332,21 +364,6 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
     const uint32_t s0 = sample_of(S0, before), s1 = sample_of(S1, before + c0), s2 = sample_of(S2, before + c1),
                    s3 = sample_of(S3, before + c2);
     uint32_t x0 = S0 ? u0 ^ R : 0u, x1 = S1 ? u1 ^ R : 0u, x2 = S2 ? u2 ^ R : 0u, x3 = S3 ? u3 ^ R : 0u;
-    auto record = [&](bool rec, uint32_t sidx, uint32_t cls) {  // (called in wave-uniform control flow)
-      const unsigned long long br = __ballot(rec);
-      if (!br) return;
-      if (n_sp < kDenseMode) {
-        const uint32_t n_new = (uint32_t)__popcll(br);
-        if (n_sp + n_new <= BVCF_CMAP_SPARSE_MAX) {
-          const uint32_t at = n_sp + __builtin_amdgcn_mbcnt_hi((uint32_t)(br >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)br, 0u));
-          if (rec) glist[at] = (sidx << 2) | cls;
-          n_sp = bcast0(n_sp + n_new);
-        } else {
-          to_dense();
-        }
-      }
-      if (n_sp >= kDenseMode && rec) atomicOr(stage32 + (sidx >> 4), cls << (2u * (sidx & 15u)));
-    };
     // ---- fields whose separator / end byte differ from R's, or whose allele bytes are not '0' ^ [0, 31]
     if (__any(((x0 | x1 | x2 | x3) & 0xFFE0FFE0u) != 0)) {
       uint32_t cand = 0;
@@ -370,9 +387,8 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
           het += cls == BVCF_CLS_HET;
           hom += cls == BVCF_CLS_HOM;
           miss += cls == BVCF_CLS_MISSING;
-          if ((v0 >= 2u && v0 <= 9u) || (v2 >= 2u && v2 <= 9u)) multi = 1;
         }
-        record(maps && cls != 0 && sidx < ns, sidx, cls);
+        record(maps && take && !isref, sidx, ((v0 & 15u) << 4) | (v2 & 15u), cls);
         if (m) x = 0;  // settled here
       };
       odd(x0, u0, s0);
@@ -391,16 +407,17 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
     het += __popc(LO & ~HI);
     hom += __popc(HI & ~LO);
     miss += __popc(LO & HI);
-    // an allele digit of 2 or more (dots, 0x1E, do not count)
-    multi |= (((g.A + 0x7E7E7E7Eu) & ~g.dA) | ((g.B + 0x7E7E7E7Eu) & ~g.dB)) & 0x80808080u;
     if (!maps) return;
-    const uint32_t any = LO | HI;  // bit 8q + 7: field q has a class
-    const unsigned long long bl = __ballot(any != 0);
-    if (!bl) return;
+    const uint32_t cls_any = LO | HI;                                       // bit 8q + 7: field q has a class for ALT #1
+    const uint32_t nz = g.A | g.B;
+    const uint32_t nonref = ((nz + 0x7F7F7F7Fu) | nz) & 0x80808080u;        // ... is not the reference genotype
     auto cls_of = [&](uint32_t q) -> uint32_t { return ((LO >> (8u * q + 7u)) & 1u) | (((HI >> (8u * q + 7u)) & 1u) << 1); };
+    auto digits_of = [&](uint32_t q) -> uint32_t { return (((g.A >> (8u * q)) & 15u) << 4) | ((g.B >> (8u * q)) & 15u); };
     if (n_sp < kDenseMode) {
+      const unsigned long long bl = __ballot(nonref != 0);
+      if (!bl) return;
       // entries of the lanes in lane order, a lane's fields in field order
-      const uint32_t mine = __popc(any);
+      const uint32_t mine = __popc(nonref);
       uint32_t n_new, at;
       if ((bl & (bl - 1ull)) == 0) {  // one lane (the usual case): no prefix sum
         n_new = lane_value(mine, __ffsll((long long)bl) - 1);
@@ -409,19 +426,20 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
         at = n_sp + wave_excl_scan(mine, &n_new);
       }
       if (n_sp + n_new <= BVCF_CMAP_SPARSE_MAX) {
-        if (any & 0x00000080u) glist[at++] = (s0 << 2) | cls_of(0);
-        if (any & 0x00008000u) glist[at++] = (s1 << 2) | cls_of(1);
-        if (any & 0x00800000u) glist[at++] = (s2 << 2) | cls_of(2);
-        if (any & 0x80000000u) glist[at++] = (s3 << 2) | cls_of(3);
+        if (nonref & 0x00000080u) glist[at++] = (s0 << 8) | digits_of(0);
+        if (nonref & 0x00008000u) glist[at++] = (s1 << 8) | digits_of(1);
+        if (nonref & 0x00800000u) glist[at++] = (s2 << 8) | digits_of(2);
+        if (nonref & 0x80000000u) glist[at++] = (s3 << 8) | digits_of(3);
         n_sp = bcast0(n_sp + n_new);
         return;
       }
       to_dense();
     }
-    if ((any & 0x00000080u) && s0 < ns) atomicOr(stage32 + (s0 >> 4), cls_of(0) << (2u * (s0 & 15u)));
-    if ((any & 0x00008000u) && s1 < ns) atomicOr(stage32 + (s1 >> 4), cls_of(1) << (2u * (s1 & 15u)));
-    if ((any & 0x00800000u) && s2 < ns) atomicOr(stage32 + (s2 >> 4), cls_of(2) << (2u * (s2 & 15u)));
-    if ((any & 0x80000000u) && s3 < ns) atomicOr(stage32 + (s3 >> 4), cls_of(3) << (2u * (s3 & 15u)));
+    if (!__any(cls_any != 0)) return;
+    if ((cls_any & 0x00000080u) && s0 < ns) atomicOr(stage32 + (s0 >> 4), cls_of(0) << (2u * (s0 & 15u)));
+    if ((cls_any & 0x00008000u) && s1 < ns) atomicOr(stage32 + (s1 >> 4), cls_of(1) << (2u * (s1 & 15u)));
+    if ((cls_any & 0x00800000u) && s2 < ns) atomicOr(stage32 + (s2 >> 4), cls_of(2) << (2u * (s2 & 15u)));
+    if ((cls_any & 0x80000000u) && s3 < ns) atomicOr(stage32 + (s3 >> 4), cls_of(3) << (2u * (s3 & 15u)));
   };
 
   // ---- the stream: a ring of kGenRing chunks in LDS, filled by LDS-DMA loads (global_load_lds_dwordx4: no register

@@ -92,6 +92,33 @@ def test_reference_word_variants_and_carrier_density(bv, ns):
     both(bv, vcf, {"allow": ""})
 
 
+@pytest.mark.parametrize("ns", [260, 900, 2600])  # class-map slots with room for 1, 3 and 8 lists
+def test_multiallelic_lines_carry_every_alt_index_in_lists(bv, ns):
+    """1-9 ALTs (and 11: two-digit indices are outside the fast gate), carriers of any index, few (class lists for every
+    index, k_head takes the counts from them) and many (a dense map for ALT #1, k_gt for the rest), missing samples
+    (listed for every index), several carriers inside one map byte"""
+    rng = random.Random(77 + ns)
+    alts_all = ["G", "T", "C", "GA", "AT", "ACC", "TT", "GG", "CC", "AG", "TG"]
+    rows = []
+    pos = 3000
+    for n_alt in [1, 2, 3, 4, 5, 8, 9, 11]:
+        for n_car in [0, 1, 3, 10, 15, 16, 30, ns // 3]:
+            for sep in "/|":
+                f = ["0%s0:%d:%d" % (sep, rng.randint(0, 99), rng.randint(0, 99)) for _ in range(ns)]
+                who = rng.sample(range(ns), n_car)
+                if n_car >= 3:  # neighbours: the same map byte
+                    who[1] = (who[0] // 4) * 4 + (who[0] + 1) % 4
+                    who[2] = (who[0] // 4) * 4 + (who[0] + 2) % 4
+                for i in who:
+                    a = rng.choice([str(rng.randint(0, n_alt)), "."]) if rng.random() < 0.9 else "."
+                    b = str(rng.randint(0, n_alt))
+                    f[i] = "%s%s%s:%d:%d" % (a, sep, b, rng.randint(0, 9), rng.randint(0, 99))
+                pos += 5
+                rows.append(_line(pos, f, alt=",".join(alts_all[:n_alt])))
+    vcf = (vcfgen.header(ns) + "".join(rows)).encode()
+    both(bv, vcf, {"allow": ""})
+
+
 def test_fields_the_fast_gate_does_not_take(bv):
     """haploid, polyploid, multi-digit and empty fields, further ALT indices: such lines are listed as deferred by
     k_stream_gen (or get a dense map and k_gt tasks for the further indices) -- results as the reference's general branch"""
