@@ -105,15 +105,20 @@ def write_e2e_file(header, blocks, sizes, want_rows, rows_per_block):
     return path, n_blk * rows_per_block, need, base
 
 
-def e2e_leg(path, rows, nbytes, where, prefix_path, prefix_rows, devices, runs=2):
-    """the CLI over the file, wall clock around the process; BVCF_TIMING=json gives the stage split"""
+def e2e_leg(path, rows, nbytes, where, prefix_path, prefix_rows, devices, runs=2, timeout_s=300):
+    """the CLI over the file, wall clock around the process; BVCF_TIMING=json gives the stage split.  A run that does
+    not come back within timeout_s is reported, not waited for: the bench line must not depend on this leg."""
     env = dict(os.environ, BVCF_TIMING="json")
     best = None
     walls = []
     for _ in range(runs):
         t0 = time.perf_counter()
-        with open(os.devnull, "wb") as out:
-            p = subprocess.run([CLI, "--in", path, "--devices", devices], stdout=out, stderr=subprocess.PIPE, env=env)
+        try:
+            with open(os.devnull, "wb") as out:
+                p = subprocess.run([CLI, "--in", path, "--devices", devices], stdout=out, stderr=subprocess.PIPE, env=env,
+                                   timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return {"error": "CLI --devices %s did not finish within %d s" % (devices, timeout_s)}
         wall = time.perf_counter() - t0
         if p.returncode != 0:
             return {"error": "CLI rc %d: %s" % (p.returncode, p.stderr[-300:].decode(errors="replace"))}
@@ -138,7 +143,8 @@ def e2e_leg(path, rows, nbytes, where, prefix_path, prefix_rows, devices, runs=2
         out["steady_variants_per_s"] = rows / stages["steady_s"]
         out["steady_variants_per_min"] = rows / stages["steady_s"] * 60
         out["steady_text_GBps"] = nbytes / stages["steady_s"] / 1e9
-        assert stages["lines_in"] == rows, (stages["lines_in"], rows)
+        if stages["lines_in"] != rows:
+            out["error"] = "the CLI saw %d lines, the file has %d" % (stages["lines_in"], rows)
     if not prefix_path:
         return out
     # parity on a prefix of the same stream: md5 of the CLI's stdout == md5 of the oracle CLI's
@@ -156,7 +162,8 @@ def cpu_baseline(path, rows, profile):
     def run(threads):
         t0 = time.perf_counter()
         with open(os.devnull, "wb") as out:
-            p = subprocess.run([ORACLE, "--in", path, "--threads", str(threads), "--timing"], stdout=out, stderr=subprocess.PIPE)
+            p = subprocess.run([ORACLE, "--in", path, "--threads", str(threads), "--timing"], stdout=out, stderr=subprocess.PIPE,
+                               timeout=900)
         wall = time.perf_counter() - t0
         m = re.search(r"\[oracle timing\] rows (\d+) threads (\d+) read ([\d.]+) process ([\d.]+) write ([\d.]+)", p.stderr.decode(errors="replace"))
         assert p.returncode == 0 and m and int(m.group(1)) == rows, p.stderr[-300:]
@@ -367,9 +374,11 @@ def main():
                         # (not part of `value`, which is this rank's GPU alone) the same file dealt block by block to every
                         # visible device by the one CLI process
                         line["e2e_all_devices"] = e2e_leg(path, f_rows, f_bytes, where, None, 0,
-                                                          ",".join(str(d) for d in range(n_vis)), runs=2)
+                                                          ",".join(str(d) for d in range(n_vis)), runs=2, timeout_s=180)
                 if not args.no_cpu_baseline:
                     line["cpu_baseline"] = cpu_baseline(path, f_rows, args.profile)
+            except Exception as exc:  # the host legs inform; the measured line above stands without them
+                line.setdefault("host_legs_error", repr(exc)[:400])
             finally:
                 for q in (path, prefix):
                     if q and os.path.exists(q):
