@@ -49,6 +49,7 @@ long bgzf_block_size(const uint8_t *p, size_t n, uint32_t *xlen_out) {
 }  // namespace
 
 ByteSource::ByteSource(int fd, unsigned n_threads) : fd_(fd), n_threads_(n_threads ? n_threads : 1) {
+  if (const char *e = getenv("BVCF_INFLATE_THREADS")) n_threads_ = (unsigned)std::max(1, atoi(e));  // tuning
   // `pigz -dc in.vcf.gz | bystro-vcf`: a pipe hands over 64 KiB per read() by default; ask for the most the system
   // gives an unprivileged process (1 MiB, /proc/sys/fs/pipe-max-size) -- fewer system calls and context switches
   struct stat st;
