@@ -116,7 +116,10 @@ typedef struct {
                                  1 = census path (separate newline census, every line listed; from
                                  BVCF_WIDE_SAMPLES samples up the genotype scan of one line is split over waves);
                                  2 = streaming path when there are samples (lines found and ALT #1 scanned
-                                 in one pass; only lines with the right field count are listed) */
+                                 in one pass; only lines with the right field count are listed).  The ctx
+                                 walks a batch with the kernel made for the shape of the previous batch's
+                                 lines -- bare "x|y" sample fields, or fields with sub-fields beyond GT --
+                                 the results do not depend on which */
 } bvcf_params;
 
 /* one input line; 64 bytes */
