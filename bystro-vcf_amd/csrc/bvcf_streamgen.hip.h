@@ -179,11 +179,13 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
           const uint32_t a4 = (ent >> 4) & 15u, b4 = ent & 15u;
           const uint32_t top = (uint32_t)lane < n ? max(a4 <= 9u ? a4 : 0u, b4 <= 9u ? b4 : 0u) : 0u;
           kmax = 1;
+          if (__any(top >= 2u)) {  // (a biallelic line never gets here)
 #pragma nounroll
-          for (uint32_t k = 9; k >= 2; k--) {
-            if (__any(top == k)) {
-              kmax = k;
-              break;
+            for (uint32_t k = 9; k >= 2; k--) {
+              if (__any(top == k)) {
+                kmax = k;
+                break;
+              }
             }
           }
           if (kmax > max_k) kmax = 0;  // no room for that many lists: ALT #1 as a map, the others through k_gt
