@@ -17,6 +17,9 @@ PROFILES = {
     # not a BASELINE config: every row a common variant (AF ~ 0.3, ~1 300 sample names per output row, ~11 KB of TSV
     # per row) -- the worst case for the host formatter
     "c3d": dict(n_samples=2504, p_multi=0, p_indel=0, p_bad=0, dense=1),
+    # not BASELINE configs: small cohorts (a trio-sized and a panel-sized GATK-style file; census path, k_gt's general scan)
+    "g10": dict(n_samples=10, p_multi=500, p_indel=1500, p_bad=0, fmt_extra=1),
+    "g100": dict(n_samples=100, p_multi=500, p_indel=1500, p_bad=0, fmt_extra=1),
 }
 SEED = 20130502
 
