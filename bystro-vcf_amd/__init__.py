@@ -27,7 +27,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DEVICE_PAD = 64
 NO_CMAP = 0xFFFFFFFF
 
@@ -42,9 +42,9 @@ BENCH_EXPORTS = ["bvcf_bench_device", "bvcf_bench_device_slots", "bvcf_bench_str
 
 # every symbol include/bvcf.h declares
 EXPORTS = [
-    "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_set_sample_names", "bvcf_alloc_pinned",
+    "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_set_sample_names", "bvcf_alloc_pinned", "bvcf_alloc_pinned_near", "bvcf_warmup",
     "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_submit_bgzf", "bvcf_collect", "bvcf_counters", "bvcf_sum_counters",
-    "bvcf_allreduce_counters", "bvcf_device_count", "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_bgzf_inflate_device", "bvcf_free",
+    "bvcf_allreduce_counters", "bvcf_device_count", "bvcf_device_pci_bus_id", "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_bgzf_inflate_device", "bvcf_free",
     "bvcf_arrow_open", "bvcf_arrow_append", "bvcf_arrow_close",
 ]
 

@@ -123,6 +123,8 @@ struct bvcf_ctx {
 namespace {
 
 thread_local std::string g_create_err;
+// where HIP_TRY leaves its message when several threads work for one ctx (bvcf_create allocates the slots side by side)
+thread_local std::string *g_err_sink = nullptr;
 
 // Offsets into a block are 32-bit; the kernels read up to a few KiB past the last line (clamped loads, tile
 // rounding), so a block stays a megabyte short of 4 GiB.
@@ -132,7 +134,7 @@ constexpr uint64_t kMaxBlockBytes = 0xFFF00000ull;
   do {                                                                                   \
     hipError_t e_ = (expr);                                                              \
     if (e_ != hipSuccess) {                                                              \
-      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+      *(g_err_sink ? g_err_sink : &(ctx)->err) = std::string(#expr) + ": " + hipGetErrorString(e_); \
       return BVCF_E_HIP;                                                                 \
     }                                                                                    \
   } while (0)
@@ -635,6 +637,36 @@ void *bvcf_alloc_pinned(size_t nbytes) {
   return p;
 }
 
+void *bvcf_alloc_pinned_near(int device, size_t nbytes) {
+  // (the runtime places pinned memory on the NUMA node closest to the calling thread's current device)
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev || hipSetDevice(device) != hipSuccess) return nullptr;
+  return bvcf_alloc_pinned(nbytes);
+}
+
+int bvcf_device_pci_bus_id(int device, char *out, int cap) {
+  if (!out || cap < 16) return BVCF_E_ARG;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return BVCF_E_NODEV;
+  return hipDeviceGetPCIBusId(out, cap, device) == hipSuccess ? BVCF_OK : BVCF_E_HIP;
+}
+
+__global__ void k_warm(uint32_t *p) {
+  if (p) *p = 1u;
+}
+
+int bvcf_warmup(int device) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) return BVCF_E_NODEV;
+  if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) return BVCF_E_HIP;
+  // the first query about a kernel loads the library's code object onto the device
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_finish, kWgThreads, 0) != hipSuccess) return BVCF_E_HIP;
+  // ... and the first launch sets up the queue behind the stream (0.16 s in a bare HIP program: tools/hostreg_bench.hip)
+  hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, 0, (uint32_t *)nullptr);
+  return hipDeviceSynchronize() == hipSuccess ? BVCF_OK : BVCF_E_HIP;
+}
+
 void bvcf_free_pinned(void *p) {
   if (p) hipHostFree(p);
 }
@@ -775,9 +807,30 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
     return fail(BVCF_E_HIP);
   }
   c->slots.resize(c->p.n_slots);
-  for (auto &s : c->slots) {
-    int rc = alloc_slot(c, s);
-    if (rc) return fail(rc);
+  {
+    // the slots' buffers side by side: pinning the result arrays is most of what creating a ctx costs
+    std::vector<int> rcs(c->slots.size(), BVCF_OK);
+    std::vector<std::string> errs(c->slots.size());
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < c->slots.size(); i++)
+      th.emplace_back([c, i, &rcs, &errs]() {
+        g_err_sink = &errs[i];
+        if (hipSetDevice(c->device) != hipSuccess) {
+          rcs[i] = BVCF_E_HIP;
+          errs[i] = "hipSetDevice failed";
+          return;
+        }
+        rcs[i] = alloc_slot(c, c->slots[i]);
+      });
+    g_err_sink = &errs[0];
+    rcs[0] = alloc_slot(c, c->slots[0]);
+    g_err_sink = nullptr;
+    for (auto &t : th) t.join();
+    for (size_t i = 0; i < rcs.size(); i++)
+      if (rcs[i]) {
+        c->err = errs[i];
+        return fail(rcs[i]);
+      }
   }
   *out = c;
   return BVCF_OK;
@@ -878,9 +931,10 @@ int bvcf_submit_device(bvcf_ctx *c, const void *dblock, size_t nbytes, uint64_t 
   return submit_common(c, nullptr, dblock, nbytes, batch_seq);
 }
 
-int bvcf_submit_bgzf(bvcf_ctx *c, const uint8_t *comp, size_t n_comp, size_t n_own, int skip_first_line, uint32_t first_off,
+int bvcf_submit_bgzf(bvcf_ctx *c, const uint8_t *comp, size_t n_comp, size_t n_own, int flags, uint32_t first_off,
                      uint64_t batch_seq) {
   if (!c || !comp || !n_comp || n_own > n_comp) return BVCF_E_ARG;
+  const bool skip_first_line = (flags & BVCF_BGZF_SKIP_FIRST_LINE) != 0;
   if (c->in_flight == c->slots.size()) {
     c->err = "all slots in flight";
     return BVCF_E_BUSY;
@@ -998,6 +1052,7 @@ int bvcf_submit_bgzf(bvcf_ctx *c, const uint8_t *comp, size_t n_comp, size_t n_o
   ca.total = (uint32_t)total;
   ca.own = (uint32_t)own;
   ca.skip_first = skip_first_line ? 1u : 0u;
+  ca.at_eof = (flags & BVCF_BGZF_END_OF_STREAM) ? 1u : 0u;
   ca.first_off = first_off;
   ca.eol_byte = c->p.eol_byte;
   ca.n_blocks = (uint32_t)nb;

@@ -595,6 +595,7 @@ struct CutArgs {
   uint32_t total;        // bytes of text (own + look-ahead blocks)
   uint32_t own;          // bytes the batch's own blocks inflate to
   uint32_t skip_first;   // 1: start after the first terminator; 0: start at first_off
+  uint32_t at_eof;       // the look-ahead reaches the end of the stream: a last line without a terminator ends the batch
   uint32_t first_off;
   uint32_t eol_byte;
   uint32_t n_blocks;
@@ -652,7 +653,9 @@ __global__ __launch_bounds__(kWave) void k_cuts(CutArgs c) {
     // this batch's own text happens to end on a line boundary, the following line is this batch's)
     const uint32_t e = first_eol(c.own);
     if (e == kNoPos) {
-      flags |= kCutNoTerminator;
+      // (the stream's last line has no terminator: the text ends the batch, the scans ignore the unterminated tail,
+      // main.go:354-358; otherwise the caller gave too little look-ahead)
+      if (!c.at_eof) flags |= kCutNoTerminator;
     } else {
       end = e + 1u;
     }

@@ -21,7 +21,9 @@ struct Cli {
   std::string in, out, err, dosage, sample, fam, empty = "!", delim = ";", cpu_profile;
   std::string allow = "PASS,.", exclude;
   bool no_out = false, keep_id = false, keep_qual = false, keep_pos = false, keep_info = false;
-  std::string devices = "all";  // extension: "all" or a comma-separated list of HIP device ordinals
+  // extension: a comma-separated list of HIP device ordinals, or "all" (every visible device).  The default is ONE
+  // device: a tool that is dropped into a pipeline on a shared node must not take GPUs it was not given.
+  std::string devices = "0";
   unsigned long long batch_mb = 0;
 };
 
@@ -158,7 +160,7 @@ int main(int argc, char **argv) {
   cfg.keep_info = c.keep_info;
   cfg.keep_pos = c.keep_pos;
   cfg.keep_qual = c.keep_qual;
-  // --devices all (default): every visible HIP device; a device only gets a ctx once a block is dealt to it
+  // --devices all: every visible HIP device; a device only gets a ctx once a block reaches it
   std::vector<int32_t> devs;
   if (c.devices == "all") {
     const int n = bvcf_device_count();
@@ -198,7 +200,11 @@ int main(int argc, char **argv) {
   cfg.leave_teardown_to_exit = 1;
   uint64_t n_lines = 0;
   rc = bvcf_run_fd(&cfg, fd_in, fd_out, fd_err, &n_lines);
-  if (fd_out != 1) close(fd_out);
+  // (a write error the file system reports late -- quota, a network file system -- shows up at close)
+  if (fd_out != 1 && close(fd_out) != 0 && rc == BVCF_OK) {
+    dprintf(fd_err, "close %s: %s\n", c.out.c_str(), strerror(errno));
+    rc = BVCF_E_IO;
+  }
   fflush(nullptr);
   // (a profiler writes its results from exit handlers: leave normally under rocprofv3)
   const char *pre = getenv("LD_PRELOAD");

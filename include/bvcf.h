@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BVCF_ABI_VERSION 4
+#define BVCF_ABI_VERSION 5
 
 typedef enum {
   BVCF_OK = 0,
@@ -238,7 +238,13 @@ int bvcf_set_sample_names(bvcf_ctx *ctx, const char *const *names, const uint32_
 
 /* pinned host memory for blocks handed to bvcf_submit (hipHostMalloc) */
 void *bvcf_alloc_pinned(size_t nbytes);
+/* the same, placed near `device` (on a multi-socket host: the NUMA node the device hangs off); NULL if there is no
+ * such device */
+void *bvcf_alloc_pinned_near(int device, size_t nbytes);
 void bvcf_free_pinned(void *p);
+/* optional: brings up the HIP runtime on `device` and loads the library's kernels onto it, so that a later
+ * bvcf_create does not pay for that (bvcf_run_fd calls it while it reads the header of its input) */
+int bvcf_warmup(int device);
 
 /* ---- the hot path ---- */
 /* block: whole lines only (ends with a terminator; an unterminated tail is ignored, cf. main.go:354-358).
@@ -253,14 +259,18 @@ int bvcf_submit_device(bvcf_ctx *ctx, const void *dblock, size_t nbytes, uint64_
  * so their text begins and ends inside lines; the rule that makes every line belong to exactly one batch:
  *   - the batch's text ends after the first terminator at or past the end of its own blocks' text (found in the
  *     look-ahead; without look-ahead -- the stream's last batch -- it ends where the text ends);
- *   - skip_first_line != 0: the text before the batch's first terminator belongs to the previous batch and is skipped;
- *     skip_first_line == 0: the batch starts at byte first_off of its text (the stream's first batch: first_off is
- *     where the data lines begin).
+ *   - flags & BVCF_BGZF_SKIP_FIRST_LINE: the text before the batch's first terminator belongs to the previous batch
+ *     and is skipped; otherwise the batch starts at byte first_off of its text (the stream's first batch: first_off
+ *     is where the data lines begin);
+ *   - flags & BVCF_BGZF_END_OF_STREAM: the look-ahead blocks are the last of the stream, so a final line without a
+ *     terminator simply ends the batch (it is dropped, main.go:354-358) instead of counting as too little look-ahead.
  * bvcf_collect then also returns the text the line offsets refer to (bvcf_result.text: a pinned host copy).  Errors
  * surface at bvcf_collect: BVCF_E_FATAL for a corrupt block (inflate error or CRC mismatch) and for a line that does
  * not end within the look-ahead (give more look-ahead blocks).  The text of own + look-ahead blocks must fit
  * max_batch_bytes. */
-int bvcf_submit_bgzf(bvcf_ctx *ctx, const uint8_t *comp, size_t n_comp, size_t n_own, int skip_first_line,
+#define BVCF_BGZF_SKIP_FIRST_LINE 1
+#define BVCF_BGZF_END_OF_STREAM 2
+int bvcf_submit_bgzf(bvcf_ctx *ctx, const uint8_t *comp, size_t n_comp, size_t n_own, int flags,
                      uint32_t first_off, uint64_t batch_seq);
 /* blocks until the oldest submitted batch is done */
 int bvcf_collect(bvcf_ctx *ctx, bvcf_result *r);
@@ -281,6 +291,9 @@ int bvcf_sum_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8]);
 int bvcf_allreduce_counters(bvcf_ctx *const *ctxs, int n, uint64_t out[8], int *used_rccl);
 /* HIP devices visible to the process (0 when there is none or no runtime) */
 int bvcf_device_count(void);
+/* "domain:bus:device.function" of a device, as under /sys/bus/pci/devices (bvcf_run_fd keeps a device worker's host
+ * threads on the NUMA node its GPU hangs off); cap >= 16 */
+int bvcf_device_pci_bus_id(int device, char *out, int cap);
 
 /* ---- host side of the path: header, TSV assembly, whole-stream driver ---- */
 
