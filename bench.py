@@ -302,7 +302,8 @@ def main():
         # every row (4 bytes per sample).  Streaming path, k_stream, and sites-only input, k_sites: every byte of
         # every row (it is also the pass that finds the lines).
         streaming = ctx.path() == 2
-        kernel = ctx.stream_kernel() if streaming else ("k_gt" if ns else "k_sites")
+        sites_kernel = {"0": "k_head", "1": "k_sites", "3": "k_sites1"}.get(os.environ.get("BVCF_SITES", ""), "k_sites2")
+        kernel = ctx.stream_kernel() if streaming else ("k_gt" if ns else sites_kernel)
         alg_bytes = int(mean_bytes) if (streaming or not ns) else args.rows * 4 * ns
         achieved = alg_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms else None
         pmc = None

@@ -110,6 +110,9 @@ struct KernelArgs {
   uint16_t *head_bits;   // [n_tiles * tile_quota][16] TAB mask per 16 bytes of a line's 256-byte head window (k_stream)
   uint32_t *line_bits;   // [max_lines][8] the same, in input order (k_order)
   uint32_t *finish_items;// [max_lines + max_alleles] streaming path: the lines k_finish settles (verdict + record counts)
+  // k_sites1: the FILTER gate of the common lines as dwords (see bvcf_sites1.hip.h; 0 = no such table, 1 = keys, 2 = no test)
+  uint32_t s1_fmode;
+  uint32_t s1_fkey[4], s1_flen[4];
 };
 constexpr uint32_t kHasHeadBits = 0x80000000u;
 

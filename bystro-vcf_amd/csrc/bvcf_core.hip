@@ -106,7 +106,9 @@ struct bvcf_ctx {
   uint8_t *d_name_text = nullptr;
   NameTable name_table{};
   bool sites = false; // no sample columns: k_sites after the census instead of k_scatter_eol + k_head + k_finish
-  int sites_grid = 0;
+  bool sites1 = false;  // ... or k_sites1 on its own, no census, the line numbers by look-back (BVCF_SITES=3)
+  bool sites2 = false;  // ... or k_sites2 behind the census: tiles, the common lines on fast lanes (the default for such input)
+  int sites_grid = 0, sites1_grid = 0;
   uint32_t win_bytes = 64u << 10;  // wide: bytes of a line's sample region per wave of the split general scan
   uint32_t tile_bytes = 0, tile_quota = 0;
   uint32_t n_samples = 0;
@@ -114,6 +116,7 @@ struct bvcf_ctx {
   uint32_t dosage_stride = 0;  // 0 unless want_dosage
   uint64_t max_lines = 0, max_alleles = 0, max_cmap = 0;
   FilterTable *d_filters = nullptr;
+  uint32_t s1_fmode = 0, s1_fkey[4] = {0, 0, 0, 0}, s1_flen[4] = {0, 0, 0, 0};  // k_sites1's view of the allow list
   std::vector<Slot> slots;
   size_t head = 0, tail = 0, in_flight = 0;  // ring of busy slots, oldest at tail
   uint64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -345,7 +348,7 @@ int alloc_slot(bvcf_ctx *c, Slot &s) {
   HIP_TRY(c, hipEventCreate(&s.ev_ctr));
   const uint64_t in_cap = c->p.max_batch_bytes + BVCF_DEVICE_PAD;
   HIP_TRY(c, hipMalloc(&s.d_in, in_cap));
-  s.cap_census = (c->p.max_batch_bytes + kChunk - 1) / kChunk + 1;
+  s.cap_census = std::max<uint64_t>((c->p.max_batch_bytes + kChunk - 1) / kChunk + 1, s1_state_words((uint32_t)c->p.max_batch_bytes));
   HIP_TRY(c, hipMalloc(&s.d_census, s.cap_census * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&s.d_group, (s.cap_census / kScanGroup + 2) * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&s.d_counters, sizeof(BatchCounters)));
@@ -402,6 +405,11 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.head_bits = s.d_head_bits;
   a.line_bits = s.d_line_bits;
   a.finish_items = s.d_finish_items;
+  a.s1_fmode = c->s1_fmode;
+  for (int i = 0; i < 4; i++) {
+    a.s1_fkey[i] = c->s1_fkey[i];
+    a.s1_flen[i] = c->s1_flen[i];
+  }
   return a;
 }
 
@@ -442,6 +450,22 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     if (a.dosage) hipLaunchKernelGGL(k_dosage, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     return;
   }
+  if (c->sites1) {
+    // sites-only input, one pass: the counters and the tiles' look-back state start from zero
+    const uint32_t n_words = s1_state_words(a.nbytes);
+    hipLaunchKernelGGL(k_s1_zero, dim3(std::min<uint32_t>((n_words + 255u) / 256u, (uint32_t)c->n_cu)), dim3(256), 0, st, a, n_words);
+    if (ev_gt0) hipEventRecord(ev_gt0, st);
+    const uint32_t n_tiles = s1_n_tiles(a.nbytes);
+    // (the first generation of workgroups starts spread over ~a tile's lifetime, see the kernel; wall_clock64 ticks at 100 MHz)
+    static const uint32_t stagger_us = [] {
+      const char *e = getenv("BVCF_S1_STAGGER_US");
+      return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    if (n_tiles)
+      hipLaunchKernelGGL(k_sites1, dim3(s1_n_wgs(n_tiles)), dim3(kS1Threads), 0, st, a, n_tiles, (uint32_t)c->sites1_grid, stagger_us * 100u);
+    if (ev_gt1) hipEventRecord(ev_gt1, st);
+    return;
+  }
   const uint32_t n_chunks = (a.nbytes + kChunk - 1) / kChunk;
   const uint32_t n_groups = (n_chunks + kScanGroup - 1) / kScanGroup;
   const uint32_t stream_grid = (uint32_t)std::min<uint64_t>((n_chunks + kWavesPerWg - 1) / kWavesPerWg,
@@ -449,6 +473,12 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
   hipLaunchKernelGGL(k_count_eol, dim3(stream_grid ? stream_grid : 1), dim3(kWgThreads), 0, st, a, n_chunks);
   hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, n_chunks);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
+  if (c->sites2) {
+    if (ev_gt0) hipEventRecord(ev_gt0, st);
+    hipLaunchKernelGGL(k_sites2, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, s2_n_tiles(a.nbytes), n_chunks);
+    if (ev_gt1) hipEventRecord(ev_gt1, st);
+    return;
+  }
   if (c->sites) {
     // sites-only input: line records and allele records straight from one pass over the text
     if (ev_gt0) hipEventRecord(ev_gt0, st);
@@ -781,12 +811,28 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   }
   c->gen_grid = c->n_cu * per_cu;
   // sites-only input takes the fused kernel (BVCF_SITES=0: the census chain with k_head, for A/B and parity tests)
+  // (BVCF_SITES=0: the census chain with k_head; 1: k_sites behind the census, round 2's chain; 2: k_sites2 behind the
+  // census, the default; 3: k_sites1, no census, line numbers by look-back)
   c->sites = c->n_samples == 0;
-  if (const char *e = getenv("BVCF_SITES")) c->sites = c->sites && atoi(e) != 0;
+  c->sites2 = c->sites;
+  if (const char *e = getenv("BVCF_SITES")) {
+    const int m = atoi(e);
+    c->sites = c->sites && m != 0;
+    c->sites2 = c->sites && m == 2;
+    c->sites1 = c->sites && m == 3;
+  }
   per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sites, kSitesThreads, 0) != hipSuccess || per_cu < 1)
     per_cu = 3;
   c->sites_grid = c->n_cu * per_cu;
+  per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sites2, kS1Threads, 0) != hipSuccess || per_cu < 1)
+    per_cu = 2;
+  if (const char *e = getenv("BVCF_SITES1_WGS")) {  // experiment: workgroups per CU
+    const int w = atoi(e);
+    if (w >= 1 && w <= 8) per_cu = std::min(per_cu, w);
+  }
+  c->sites1_grid = c->n_cu * per_cu;
   // the streaming kernel gives every wave its own range of class-map slots (two of them slack): room for that
   if (!p->cmap_bytes) {
     c->max_cmap += (uint64_t)c->stream_grid * kWavesPerWg * 2u * c->cmap_stride + c->max_lines / 16 * (uint64_t)c->cmap_stride;
@@ -800,6 +846,28 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
       fill_filter(p->exclude_filter, false, &ft.deny_nil, &ft.deny_n, ft.deny_off, ft.deny_len, ft.text, &used)) {
     c->err = "too many / too long FILTER values (32 values, 2048 bytes)";
     return fail(BVCF_E_ARG);
+  }
+  // k_sites1 tests FILTER values of up to four bytes as dwords: possible when nothing is excluded and the allow list is
+  // up to four values of one to four bytes (the default "PASS,." is), or allows everything
+  if (ft.deny_nil) {
+    if (ft.allow_nil) {
+      c->s1_fmode = 2;
+    } else if (ft.allow_n <= 4) {
+      c->s1_fmode = 1;
+      for (uint32_t i = 0; i < ft.allow_n; i++) {
+        const uint32_t l = ft.allow_len[i];
+        if (l == 0 || l > 4) {
+          c->s1_fmode = 0;
+          break;
+        }
+        uint32_t k = 0;
+        for (uint32_t q = 0; q < l; q++) k |= (uint32_t)ft.text[ft.allow_off[i] + q] << (8 * q);
+        c->s1_fkey[i] = k;
+        c->s1_flen[i] = l;
+      }
+      if (!c->s1_fmode)
+        for (int i = 0; i < 4; i++) c->s1_flen[i] = 0;
+    }
   }
   if (hipMalloc(&c->d_filters, sizeof ft) != hipSuccess ||
       hipMemcpy(c->d_filters, &ft, sizeof ft, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1120,8 +1188,10 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   r->kernel_ms = ms;
   const BatchCounters ctr = *s.h_counters;
   adapt_stream_kernel(c, s.used_gen, ctr);
-  // slot i of alleles[] / tasks / class maps belongs to line i; the counters count the extras
-  const uint64_t n_alleles = (uint64_t)ctr.n_lines + ctr.n_alleles;
+  // slot i of alleles[] / tasks / class maps belongs to line i; the counters count the extras, which follow the lines'
+  // slots (k_sites1 does not know the number of lines while it runs: there they follow slot max_lines)
+  const uint64_t extras_at = c->sites1 ? (uint64_t)s.cap_lines : (uint64_t)ctr.n_lines;
+  const uint64_t n_alleles = extras_at + ctr.n_alleles;
   const uint64_t n_tasks = (uint64_t)ctr.n_lines + ctr.n_tasks;
   const uint64_t need_alleles = std::max<uint64_t>(std::max<uint64_t>(n_alleles, ctr.n_errs), n_tasks);
   const bool maps = c->p.want_class_maps && c->n_samples;
@@ -1142,7 +1212,13 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   }
   if (ctr.n_lines)
     HIP_TRY(c, hipMemcpyAsync(s.h_lines, s.d_lines, ctr.n_lines * sizeof(bvcf_line), hipMemcpyDeviceToHost, s.stream));
-  if (n_alleles)
+  if (c->sites1) {
+    if (ctr.n_lines)
+      HIP_TRY(c, hipMemcpyAsync(s.h_alleles, s.d_alleles, (size_t)ctr.n_lines * sizeof(bvcf_allele), hipMemcpyDeviceToHost, s.stream));
+    if (ctr.n_alleles)
+      HIP_TRY(c, hipMemcpyAsync(s.h_alleles + extras_at, s.d_alleles + extras_at, (size_t)ctr.n_alleles * sizeof(bvcf_allele),
+                                hipMemcpyDeviceToHost, s.stream));
+  } else if (n_alleles)
     HIP_TRY(c, hipMemcpyAsync(s.h_alleles, s.d_alleles, n_alleles * sizeof(bvcf_allele), hipMemcpyDeviceToHost,
                               s.stream));
   if (ctr.n_errs)

@@ -36,6 +36,10 @@
 //   k_sites        a wave walks a run of 8 KiB windows: text ring + TAB bit ring in LDS, line ends into a FIFO, then
 //                  one lane per line for strings.Split / linePasses / getAlleles / trTv and the records
 //                  (replaces k_scatter_eol + k_head + k_finish there)
+// ... and, the default, without the census (the text is read once):
+//   k_sites1       a wave takes 7.5 KiB tiles in ticket order: text + TAB and terminator bitmaps in LDS, the tile's line
+//                  count published at once and the line numbers found by a decoupled look-back; one lane per line,
+//                  the common lines (SNPs, lines the gate rejects) settled without the general getAlleles code
 //
 // Everything is byte/integer work over the line bytes; no MFMA.  The genotype scans are bound by
 // VALU issue at 57-70 % of the HBM peak.
@@ -53,5 +57,6 @@
 #include "bvcf_stream.hip.h"
 #include "bvcf_head.hip.h"
 #include "bvcf_sites.hip.h"
+#include "bvcf_sites1.hip.h"
 #include "bvcf_names.hip.h"
 #include "bvcf_inflate.hip.h"

@@ -1,6 +1,8 @@
-"""k_sites, the one-pass kernel for sites-only input (no sample columns; BASELINE configs[1]): lines of every length
-around its 8 KiB windows and 16 KiB ring, runs that start in the middle of a line, rounds of more than 64 lines per
-chunk, and agreement with the census chain it replaces (BVCF_SITES=0: k_scatter_eol + k_head)."""
+"""The kernels for sites-only input (no sample columns; BASELINE configs[1]) -- k_sites2, tiles behind the newline
+census with the common lines on fast lanes (the default); k_sites1, the same without the census, the line numbers from
+a look-back over tile counts (BVCF_SITES=3); k_sites, round 2's kernel (BVCF_SITES=1) --:
+lines of every length around their 8 KiB windows, tiles and runs that start in the middle of a line, rounds of more
+than 64 lines, and agreement with the census chain they replace (BVCF_SITES=0: k_scatter_eol + k_head)."""
 import random
 
 import numpy as np
@@ -18,6 +20,12 @@ H9 = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMA
 def bv():
     import bystro_vcf_amd as b
     return b
+
+
+@pytest.fixture(autouse=True, params=["k_sites2", "k_sites1", "k_sites"])
+def kernel(request, monkeypatch):
+    monkeypatch.setenv("BVCF_SITES", {"k_sites2": "2", "k_sites1": "3", "k_sites": "1"}[request.param])
+    return request.param
 
 
 def both(bv, vcf, cfg=None, **kw):
@@ -141,13 +149,14 @@ def test_sites_bench_shape_runs_of_many_windows(bv):
     new = ctx.process(body)
     ctx.close()
     import os
+    mine = os.environ["BVCF_SITES"]
     os.environ["BVCF_SITES"] = "0"
     try:
         ctx = bv.Ctx(n_hdr, max_batch_bytes=len(body))
         old = ctx.process(body)
         ctx.close()
     finally:
-        del os.environ["BVCF_SITES"]
+        os.environ["BVCF_SITES"] = mine
     assert len(new.lines) == len(old.lines) == 300_000
     for f in ("off", "len", "fend", "n_rec", "n_fields", "status", "site_type"):
         assert (new.lines[f] == old.lines[f]).all(), f
