@@ -84,25 +84,36 @@ def _md5_stdout(cmd, stdin_path=None):
     return p.returncode, h.hexdigest()
 
 
-def write_e2e_file(header, blocks, sizes, want_rows, rows_per_block):
-    """header + the first blocks of the resident set (device -> host) into /dev/shm (page cache if it does not fit)"""
-    n_blk = max(1, min(len(blocks), -(-want_rows // rows_per_block)))
-    need = len(header) + sum(sizes[:n_blk])
-    base = "/dev/shm"
-    try:
-        st = os.statvfs(base)
-        if st.f_bavail * st.f_frsize < need * 1.15:
-            base = "/tmp"
-    except OSError:
-        base = "/tmp"
+def write_e2e_file(header, blocks, sizes, want_rows, rows_per_block, make_block):
+    """header + `want_rows` rows of the rank's stream (whole blocks: the resident ones first, the rest generated on the
+    device as they are written) into /dev/shm, or /tmp when that is too small.  The row count is cut to what half of the
+    free space holds.  -> (path, rows, bytes, where)"""
+    import torch
+    per_block = max(sizes)
+    base, n_blk = "/tmp", 1
+    for cand in ("/dev/shm", "/tmp"):
+        try:
+            st = os.statvfs(cand)
+        except OSError:
+            continue
+        fit = int(st.f_bavail * st.f_frsize * 0.5 // per_block)
+        if fit >= 1:
+            base, n_blk = cand, max(1, min(-(-want_rows // rows_per_block), fit))
+            break
     path = os.path.join(base, "bvcf_bench_e2e_%d.vcf" % os.getpid())
+    stage = torch.empty(1 << 28, dtype=torch.uint8, pin_memory=True)
+    total = len(header)
     with open(path, "wb") as f:
         f.write(header)
-        for t, nb in zip(blocks[:n_blk], sizes[:n_blk]):
-            step = 1 << 30
-            for off in range(0, nb, step):
-                f.write(memoryview(t[off:min(off + step, nb)].cpu().numpy()))
-    return path, n_blk * rows_per_block, need, base
+        for b in range(n_blk):
+            t, nb = (blocks[b], sizes[b]) if b < len(blocks) else make_block(b)
+            for off in range(0, nb, stage.numel()):
+                n = min(stage.numel(), nb - off)
+                stage[:n].copy_(t[off:off + n])
+                f.write(memoryview(stage[:n].numpy()))
+            total += nb
+            del t
+    return path, n_blk * rows_per_block, total, base
 
 
 def e2e_leg(path, rows, nbytes, where, prefix_path, prefix_rows, devices, runs=2, timeout_s=300):
@@ -154,6 +165,44 @@ def e2e_leg(path, rows, nbytes, where, prefix_path, prefix_rows, devices, runs=2
     return out
 
 
+def real_data_leg(bv, bg, cfg, device, args, kernel, synthetic_GBps):
+    """the same kernel over REAL 1000-Genomes lines (the reference's regression input, tests/golden/: 19 747 rows x 2 504
+    samples, replicated to one block), one block at a time: the synthetic row model lets the scan skip 53 % of its
+    chunks as all-reference -- this shows what the real allele-count spectrum and real line heads do to the rate"""
+    import gzip
+    import torch
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "1kg_chr1_20klines.vcf.gz"), "rb") as f:
+        raw = f.read()
+    body = raw[raw.index(b"\n", raw.index(b"#CHROM")) + 1:]
+    n_body = body.count(b"\n")
+    reps = max(1, args.rows // n_body)
+    rows = reps * n_body
+    dev = torch.frombuffer(bytearray(body), dtype=torch.uint8).cuda()
+    t = torch.full((len(body) * reps + bv.DEVICE_PAD,), 10, dtype=torch.uint8, device="cuda")
+    for r in range(reps):
+        t[r * len(body):(r + 1) * len(body)] = dev
+    nbytes = len(body) * reps
+    ns = cfg.n_samples
+    stride = ((ns + 3) // 4 + 15) & ~15
+    n_alt_cap = rows * 4 + 1024
+    ctx = bv.Ctx(bg.n_header_fields(cfg), device=device, max_batch_bytes=nbytes, n_slots=1, max_lines=rows + 16, max_alleles=n_alt_cap,
+                 cmap_bytes=min((n_alt_cap + nbytes // (4 * ns + 8) + 16 * 8192) * stride + 4096, 0xFFFFFF00), path=args.path)
+    try:
+        ctx.bench_device([t.data_ptr()], [nbytes], 2, slots=1)
+        chain, scan, counts = ctx.bench_device([t.data_ptr()], [nbytes], 8, slots=1)
+    finally:
+        ctx.close()
+    ms = sum(scan) / len(scan)
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    return {
+        "input": "tests/golden/1kg_chr1_20klines.vcf.gz: %d real rows x %d = %d rows, %.2f GB per block, resident in HBM" % (n_body, reps, rows, nbytes / 1e9),
+        "kernel": kernel, "mean_launch_ms": ms, "GBps": gbps, "frac": gbps / HBM_PEAK_GBPS,
+        "chain_ms_one_block_at_a_time": sum(chain) / len(chain),
+        "variants_per_s_one_block_at_a_time": rows / (sum(chain) / len(chain) * 1e-3),
+        "ratio_to_synthetic_kernel_rate": gbps / synthetic_GBps if synthetic_GBps else None,
+    }
+
+
 def cpu_baseline(path, rows, profile):
     """oracle/bvcf_oracle (the CLI of the C restatement: N workers over 64-line batches, split-then-scan, per-allele
     rescan) over the e2e file, output to /dev/null as in README.md:49: all host cores, and 4 threads"""
@@ -194,7 +243,10 @@ def main():
     ap.add_argument("--samples", type=int, default=0, help="experiment: another sample count for the profile (e.g. 100000 with --rows 640)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-rows", type=int, default=1_200_000, help="rows of the end-to-end / cpu_baseline file (rounded up to whole blocks)")
+    ap.add_argument("--no-real-data", action="store_true", help="skip the cross-check on real 1000-Genomes lines")
+    ap.add_argument("--e2e-rows", type=int, default=6_200_000,
+                    help="rows of the end-to-end / cpu_baseline file (rounded up to whole blocks; BASELINE configs[2] is 6.2 M rows = "
+                         "63 GB, written to /dev/shm -- fewer when it does not hold them)")
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
     ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
     ap.add_argument("--path", type=int, default=0, help="0 choose, 1 census path, 2 streaming path")
@@ -349,17 +401,26 @@ def main():
                 # informational: the kernel's duration inside the timed region, where it shares the CUs with the
                 # previous block's tail kernels -- two launches overlap, so this is longer than ms_per_block
                 "in_timed_region_mean_launch_ms": gt_mean_ms,
+                "in_timed_region_frac": alg_bytes / (gt_mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if gt_mean_ms else None,
                 "in_timed_region_chain_latency_ms": chain_mean_ms,
             },
             "text_GBps": sum(sizes) * world / (elapsed / args.steps) / 1e9,
             "variants_per_min": total_variants / elapsed * 60,
         }
+        if world == 1 and streaming and args.profile == "c3" and not args.golden and not args.no_real_data:
+            try:
+                line["real_data"] = real_data_leg(bv, bg, cfg, local_rank, args, kernel, achieved)
+            except Exception as exc:
+                line["real_data"] = {"error": repr(exc)[:300]}
         want_host_legs = world == 1 and not args.golden and not (args.no_e2e and args.no_cpu_baseline)
         if want_host_legs:
             path = prefix = None
             try:
                 hdr = bg.header(cfg)
-                path, f_rows, f_bytes, where = write_e2e_file(hdr, blocks, sizes, args.e2e_rows, args.rows)
+                first0 = rank_blocks(rank, args.blocks, args.rows)[0]
+                path, f_rows, f_bytes, where = write_e2e_file(
+                    hdr, blocks, sizes, args.e2e_rows, args.rows,
+                    lambda b: bg.rows_device(cfg, first0 + b * args.rows, args.rows, pad=bv.DEVICE_PAD))
                 if not args.no_e2e:
                     # prefix of the same stream for the md5 check: rows [first, first + n) of block 0
                     p_rows = min(args.rows, 65_536 if ns else 1_000_000)

@@ -117,6 +117,7 @@ constexpr int kFastGroup = 5;  // chunks per buffer; two buffers => 10 KiB in fl
 struct FastAcc {
   uint32_t bad, het, hom, miss;
   uint32_t n_sp;  // wave-uniform: entries in the raw list of the line; > BVCF_CMAP_SPARSE_MAX once the line went dense
+  uint32_t hi = 0;  // dense mode: allele bytes seen that may be a digit >= 2 (or a dot): bits of tor & 0x000E000E
 };
 
 // Most alleles of a cohort file are carried by a handful of samples.  A line therefore starts in LIST MODE: a lane
@@ -204,17 +205,21 @@ __device__ __forceinline__ uint32_t class_byte(uint32_t LO, uint32_t HI) {
 __device__ __forceinline__ void list_to_stage(const RawList *sp, uint32_t n, uint32_t ka, uint8_t *stage, uint32_t n_chunks,
                                               FastAcc &acc) {
   zero_stage(stage, n_chunks);
+  u32x4 e = {0u, 0u, 0u, 0u};
+  uint32_t idx = 0;
   if ((uint32_t)lane_id() < n) {
-    const u32x4 e = sp->t[lane_id()];
-    const Alleles4 g = gather4(e.x, e.y, e.z, e.w);
-    uint32_t LO, HI;
-    classes4(g, ka, &LO, &HI);
-    acc.bad |= alphabet_bad(g);
-    acc.het += __popc(LO & ~HI);
-    acc.hom += __popc(HI & ~LO);
-    acc.miss += __popc(LO & HI);
-    stage[sp->idx[lane_id()] % kStageBytes] = (uint8_t)class_byte(LO, HI);
+    e = sp->t[lane_id()];
+    idx = sp->idx[lane_id()] % kStageBytes;
   }
+  acc.hi |= e.x | e.y | e.z | e.w;
+  const Alleles4 g = gather4(e.x, e.y, e.z, e.w);
+  uint32_t LO, HI;
+  classes4(g, ka, &LO, &HI);
+  acc.bad |= alphabet_bad(g);
+  acc.het += __popc(LO & ~HI);
+  acc.hom += __popc(HI & ~LO);
+  acc.miss += __popc(LO & HI);
+  if ((uint32_t)lane_id() < n) stage[idx] = (uint8_t)class_byte(LO, HI);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
@@ -267,6 +272,7 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
       }
     }
     if (dense) {
+      acc.hi |= tor;
       const Alleles4 g = gather4(t[0], t[1], t[2], t[3]);
       uint32_t LO, HI;
       classes4(g, ka, &LO, &HI);
@@ -283,14 +289,22 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
   }
 }
 
-// End of a line that stayed in list mode (n = acc.n_sp <= kRawMax entries): lane i classifies entry i.
-// With at most BVCF_CMAP_SPARSE_MAX entries the class list of ALT #1 goes to cmap, and -- when the entries carry
-// allele digits 2..kmax -- the class lists of ALT #2..#kmax to cmap + 64 * (k - 1); returns kmax (1: no further
-// allele is carried).  Otherwise the entries become the dense map of ALT #1 and 0 is returned: more entries than a
-// list holds, or a digit above max_k (no room in the slot, or above kListAlleles) -- further ALT indices of such a
-// line go to k_gt.
+// End of a line that stayed in list mode (n = acc.n_sp <= kRawMax entries): lane i classifies entry i.  Returns what
+// k_head is told about the line in the low bits of its class-map offset (offsets are multiples of 16):
+//   bit 0 = 1, bits 1-3 = kmax - 1   at most BVCF_CMAP_SPARSE_MAX entries: the class list of ALT #1 is at cmap and --
+//                                    when the entries carry allele digits 2..kmax -- the lists of ALT #2..#kmax at
+//                                    cmap + 64 * (k - 1); no sample carries a higher allele
+//   bit 0 = 0, bits 1-3 = kmax       more entries than a list holds: cmap is the dense map of ALT #1.  kmax (1..7) is the
+//                                    highest allele digit a sample carries; for kmax >= 2 the class lists of ALT
+//                                    #2..#kmax (each within BVCF_CMAP_SPARSE_MAX entries) are in the NEXT slot, at
+//                                    cmap_extra + 64 * (k - 2), and *used_extra is set
+//   0                                a dense map of ALT #1 and nothing known about further alleles (k_gt scans them):
+//                                    a digit above max_k / 7, a further allele with too many carriers, no spare slot
+// Either way a multiallelic line whose non-reference samples fit the raw list is read once (the reference rescans the
+// line once per allele, main.go:549-556).
 __device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc, uint8_t *cmap, uint32_t max_k,
-                                                uint8_t *stage, uint32_t n_chunks, uint32_t stride) {
+                                                uint8_t *stage, uint32_t n_chunks, uint32_t stride, uint8_t *cmap_extra,
+                                                bool *used_extra) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int lane = lane_id();
@@ -326,13 +340,31 @@ __device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc,
       }
     }
   }
-  if (n > BVCF_CMAP_SPARSE_MAX || kmax > max_k) {
-    // a dense map of ALT #1 after all (k_gt scans the further ALT indices, if any)
+  const bool sparse1 = n <= BVCF_CMAP_SPARSE_MAX && kmax <= max_k;
+  uint32_t enc;
+  uint8_t *lists = cmap;  // where the list of ALT #k goes: lists + 64 * (k - 1)
+  if (sparse1) {
+    enc = 1u | ((kmax - 1u) << 1);
+  } else {
+    // a dense map of ALT #1 after all
     zero_stage(stage, n_chunks);
     if ((uint32_t)lane < n) stage[idx % kStageBytes] = (uint8_t)byte1;
     flush_stage(stage, cmap, 0u, n_chunks * 64u, stride);
     acc.n_sp = bcast0(kDenseMode);
-    return 0u;
+    if (kmax == 1u) return 1u << 1;  // nobody carries a further allele
+    // every further allele's carriers must fit a list (else k_gt scans them).  Tried instead: dense maps of ALT #2..#4
+    // grown beside ALT #1's in the stage during the scan -- no rescans at all, but k_stream, which is bound by
+    // instruction issue, took 23 % longer on configs[3] (and 1-5 % on biallelic files), more than k_gt's rescans cost
+    if (kmax > 7u || !cmap_extra || 64u * (kmax - 1u) > stride) return 0u;
+#pragma nounroll
+    for (uint32_t k = 2; k <= kmax; k++) {
+      uint32_t lo_k, hi_k;
+      classes4(g, k * 0x01010101u, &lo_k, &hi_k);
+      if (__popcll(__ballot(class_byte(lo_k, hi_k) != 0)) > (int)BVCF_CMAP_SPARSE_MAX) return 0u;
+    }
+    enc = kmax << 1;
+    lists = cmap_extra - 64u;  // (ALT #2's list at the start of the extra slot)
+    *used_extra = true;
   }
 #pragma nounroll
   for (uint32_t k = 2; k <= kmax; k++) {
@@ -340,16 +372,18 @@ __device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc,
     classes4(g, k * 0x01010101u, &lo_k, &hi_k);
     const uint32_t byte_k = class_byte(lo_k, hi_k);
     const unsigned long long nz = __ballot(byte_k != 0);
-    uint32_t *list = reinterpret_cast<uint32_t *>(cmap + 64u * (k - 1u));
+    uint32_t *list = reinterpret_cast<uint32_t *>(lists + 64u * (k - 1u));
     const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
     if (byte_k) __builtin_nontemporal_store((idx << 8) | byte_k, list + 1u + at);
     if (lane == 0) __builtin_nontemporal_store((uint32_t)__popcll(nz), list);
   }
-  // the list of ALT #1: count, then the entries (an entry may carry a zero byte: a lane whose fields only hold
-  // other alleles)
-  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((idx << 8) | byte1), 0x138, 0xF, 0xF, false);  // wave_shr:1
-  if ((uint32_t)lane <= n) __builtin_nontemporal_store(lane == 0 ? n : prev, reinterpret_cast<uint32_t *>(cmap) + lane);
-  return kmax;
+  if (sparse1) {
+    // the list of ALT #1: count, then the entries (an entry may carry a zero byte: a lane whose fields only hold
+    // other alleles)
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((idx << 8) | byte1), 0x138, 0xF, 0xF, false);  // wave_shr:1
+    if ((uint32_t)lane <= n) __builtin_nontemporal_store(lane == 0 ? n : prev, reinterpret_cast<uint32_t *>(cmap) + lane);
+  }
+  return enc;
 }
 
 // check_term: also require the byte after the last sample to be the line terminator (the caller

@@ -74,7 +74,7 @@ __device__ inline void write_allele(const KernelArgs &a, uint32_t idx, uint32_t 
   r.n_miss = gr ? gr->n_miss : 0u;
   // offsets are multiples of 16; k_stream sets bit 0 when the slot holds a class list (bits 1-3: see finish_list)
   const bool sparse = cmap_off != BVCF_NO_CMAP && (cmap_off & 1u);
-  r.cmap_off = sparse ? cmap_off & ~15u : cmap_off;
+  r.cmap_off = cmap_off != BVCF_NO_CMAP ? cmap_off & ~15u : cmap_off;
   r.ref = ref;
   r.alt_base = alt_base;
   r.kind = e.mnp ? (uint8_t)BVCF_ALT_BASE : e.kind;
@@ -482,8 +482,12 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
             // the class list of every further ALT index they carry (finish_list), so the line is not read again
             // (the reference rescans it once per allele, main.go:549-556).  The counts come from the list.
             bool resolved = false;
-            if (a.fused && !deferred && cm0 != BVCF_NO_CMAP && (cm0 & 1u) && task < a.max_tasks) {
-              const uint32_t kmax = ((cm0 >> 1) & 7u) + 1u;
+            if (a.fused && !deferred && cm0 != BVCF_NO_CMAP && (cm0 & 15u) && task < a.max_tasks) {
+              // bit 0: ALT #1 is a class list and the lists of ALT #2..#kmax follow it in the slot (kmax - 1 in bits 1-3).
+              // Otherwise ALT #1 is a dense map and bits 1-3 = kmax, the highest allele a sample carries (finish_list,
+              // k_stream): the class lists of ALT #2..#kmax are in the next slot
+              const bool in_slot = (cm0 & 1u) != 0;
+              const uint32_t kmax = ((cm0 >> 1) & 7u) + (in_slot ? 1u : 0u);
               const GtResult first = g0;
               r.ac = 0;
               r.an = first.an;
@@ -493,7 +497,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
               r.regular = 1;
               r.pad = 0;
               if (k + 1u <= kmax) {
-                cm_off = ((cm0 & ~15u) + 64u * k) | 1u;
+                cm_off = ((cm0 & ~15u) + (in_slot ? 64u * k : a.cmap_stride + 64u * (k - 1u))) | 1u;
                 const uint32_t *list = reinterpret_cast<const uint32_t *>(a.cmap + (cm_off & ~15u));
                 const uint32_t n = min(list[0], (uint32_t)BVCF_CMAP_SPARSE_MAX);
 #pragma nounroll

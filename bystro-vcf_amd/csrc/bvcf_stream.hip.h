@@ -197,7 +197,10 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   // arena stays within a few percent of compact.  (Asking a device counter for slots cost 8 % of this kernel
   // either way: 16 at a time, every request drains the loads in flight; a whole run at a time, 3 072 waves
   // hit one address when the kernel starts, and a single address serves about 90 atomics per microsecond.)
-  const uint32_t slots_per_wave = (uint32_t)(((unsigned long long)per_wave * T) / (4ull * ns + 8ull)) + 2u;
+  // (a quarter more: a multiallelic line whose further alleles get class lists of their own takes a second slot; a wave
+  // that runs out of them leaves such lines' further alleles to k_gt)
+  const uint32_t lines_bound = (uint32_t)(((unsigned long long)per_wave * T) / (4ull * ns + 8ull)) + 2u;
+  const uint32_t slots_per_wave = lines_bound + lines_bound / 4u;
   cm_next = wave * slots_per_wave;
   cm_end = cm_next + slots_per_wave;
   if (maps && wave == 0 && lane == 0)  // only waves that own tiles own slots; k_head's maps follow
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   // list a line (in input order) in the tile it starts in
   // bits_ok: `bits` is the TAB mask of the line's head window (head_window16), one 16-bit piece per lane 0..15
   auto commit = [&](uint32_t ls, uint32_t cend, const GtStats &st, bool deferred, uint32_t cm_off, bool bits_ok = false,
-                    uint32_t bits = 0u) {
+                    uint32_t bits = 0u, uint32_t n_slots = 1u) {
     // (a deferred line gets its class map with its k_gt task, not here)
     while (ls >= (tile + 1) * T) {  // ls moved into a later tile of the run
       if (lane == 0) a.census[tile] = n_local;
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
     }
     if (bits_ok && lane < 16) a.head_bits[((size_t)tile * a.tile_quota + n_local) * 16u + (uint32_t)lane] = (uint16_t)bits;
     n_local++;
-    if (maps && !deferred) cm_next++;
+    if (maps && !deferred) cm_next += n_slots;
   };
   // chunk loads are dword-aligned and realigned in registers; geometries whose last field would
   // need a dword past the chunks (ns % 256 == 0) load unaligned instead (see gt_scan_fast)
@@ -349,10 +352,22 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
             va[g] = chunk_at(s_next, g);
           }
           STAMP(3);
-          // a line that ends in list mode: its few entries classified now, for ALT #1 and every further ALT index
-          uint32_t kmax = 0;
-          if (sparse_ok && acc.n_sp < kDenseMode)
-            kmax = finish_list(sparse, acc, cm, min(kListAlleles, a.cmap_stride / (4u * kSparseWords)), stage, nc, a.cmap_stride);
+          // a line that ends in list mode: its entries classified now, for ALT #1 and every further ALT index; a line that
+          // went dense on the way: all that is known is whether anything but 0 and 1 was seen at all.  A second slot (for
+          // the lists of the further alleles of a line whose ALT #1 became a map) only while the wave's range still covers
+          // one slot for every line that may follow in its run (a regular line is at least 4 ns + 8 bytes long).
+          uint32_t enc = 0, n_slots = 1;
+          if (sparse_ok && acc.n_sp < kDenseMode) {
+            const bool spare = acc.n_sp > BVCF_CMAP_SPARSE_MAX && cm_next + 2u <= cm_end &&
+                               cm_end - (cm_next + 2u) >= (r1 - min(r1, peA)) / (4u * ns + 8u) + 2u &&
+                               cmap_of(a, cm_next + 1u, true) != BVCF_NO_CMAP;
+            bool two = false;
+            enc = finish_list(sparse, acc, cm, min(kListAlleles, a.cmap_stride / (4u * kSparseWords)), stage, nc, a.cmap_stride,
+                              spare ? cm + a.cmap_stride : nullptr, &two);
+            if (two) n_slots = 2;
+          } else if (sparse_ok && !__any((acc.hi & 0x000E000Eu) != 0)) {
+            enc = 1u << 1;
+          }
           if (__any(acc.bad != 0)) {
             // A is not regular after all: B was predicted from a wrong line end.  Leave the
             // pipeline (the loads in flight are simply dropped) and take A the slow way.
@@ -362,9 +377,8 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           }
           finish_stats(acc, &st);
           seen++;
-          // (offsets are multiples of 16.  Bit 0 tells k_head that the slot holds a list, BVCF_ALLELE_CMAP_SPARSE;
-          // bits 1-3 = kmax - 1: the slot also holds the lists of ALT #2..#kmax, and no sample carries a higher one)
-          commit(pA, peA, st, false, kmax ? cmA | 1u | ((kmax - 1u) << 1) : cmA, bitsA, mtA);
+          // (offsets are multiples of 16: the low bits tell k_head what finish_list left in the slot, see there)
+          commit(pA, peA, st, false, cmA == BVCF_NO_CMAP ? cmA : cmA | enc, bitsA, mtA, n_slots);
           p = peA + 1u;
           if (!b_ok) {
             s_begin = kNone;  // nothing pending: rediscover from p
