@@ -55,6 +55,7 @@ struct Slot {
   uint64_t cap_bgzf_blocks = 0;
   uint32_t *d_cuts = nullptr, *h_cuts = nullptr;  // {start, end, flags, first bad block}
   uint8_t *h_text = nullptr;
+  uint64_t cap_h_text = 0;
   // ... of which only the line heads come back when there are samples (k_heads_*)
   uint32_t *d_head_off = nullptr, *h_head_off = nullptr;
   uint8_t *d_heads = nullptr;
@@ -551,9 +552,26 @@ static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_de
     if (getenv("BVCF_DEBUG")) fprintf(stderr, "[bvcf debug] k_inflate_w16: %d workgroups per CU\n", n);
     return n;
   }();
-  if (const char *e = getenv("BVCF_INFLATE_W16")) w16 = *e == '1';  // tests / tuning: force the variant
-  const uint32_t grid = std::min<uint32_t>(n_blocks, (uint32_t)n_cu * (uint32_t)(w16 ? per_cu16 : per_cu32));
-  if (w16)
+  static const int per_cu4 = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_inflate_w4, kInfThreads, 0) != hipSuccess || n < 1) n = 12;
+    if (getenv("BVCF_DEBUG")) fprintf(stderr, "[bvcf debug] k_inflate_w4: %d workgroups per CU\n", n);
+    return n;
+  }();
+  // The 4 KiB window is the default: the decoder is a serial chain of ~250 instructions per symbol, so what counts is
+  // how many blocks a SIMD interleaves -- 15 waves per CU against 7 (16 KiB) and 4 (32 KiB): 117 / 80 / 64 GB/s of text
+  // on configs[2] rows, although most of its matches (a line repeats the one before it, 10 KB back) are then read back
+  // from memory.  (`w16` is what the caller knows about the lines; kept for the A/B switch.)
+  bool w4 = true;
+  w16 = false;
+  if (const char *e = getenv("BVCF_INFLATE_W16")) {  // tests / tuning: force the variant (0: 32 KiB, 1: 16 KiB, 2: 4 KiB)
+    w16 = *e == '1';
+    w4 = *e == '2';
+  }
+  const uint32_t grid = std::min<uint32_t>(n_blocks, (uint32_t)n_cu * (uint32_t)(w4 ? per_cu4 : (w16 ? per_cu16 : per_cu32)));
+  if (w4)
+    hipLaunchKernelGGL(k_inflate_w4, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
+  else if (w16)
     hipLaunchKernelGGL(k_inflate_w16, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
   else
     hipLaunchKernelGGL(k_inflate, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
@@ -1043,13 +1061,17 @@ int bvcf_submit_bgzf(bvcf_ctx *c, const uint8_t *comp, size_t n_comp, size_t n_o
   const size_t nb = blocks.size();
   if (!s.ev_cut) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_cut, hipEventDisableTiming));
   if (!s.h_text) {
-    // the host copies of the text, for every slot at once and side by side (pinning 64 MiB takes ~25 ms)
+    // the host copies of the text, for every slot at once and side by side (pinning 64 MiB takes 13-25 ms).  With
+    // samples only the line heads come back, a few percent of the text: a sixteenth of a batch to start with (bvcf_collect
+    // grows a slot's buffer when a batch needs more)
+    const uint64_t want = c->n_samples ? c->p.max_batch_bytes / 16 + (1u << 20) : c->p.max_batch_bytes + BVCF_DEVICE_PAD;
     std::vector<std::thread> th;
     for (auto &q : c->slots)
       if (!q.h_text)
-        th.emplace_back([c, &q]() {
+        th.emplace_back([c, &q, want]() {
           hipSetDevice(c->device);
-          if (hipHostMalloc(&q.h_text, c->p.max_batch_bytes + BVCF_DEVICE_PAD, hipHostMallocDefault) != hipSuccess) q.h_text = nullptr;
+          if (hipHostMalloc(&q.h_text, want, hipHostMallocDefault) != hipSuccess) q.h_text = nullptr;
+          q.cap_h_text = q.h_text ? want : 0;
         });
     for (auto &t : th) t.join();
     if (!s.h_text) {
@@ -1235,6 +1257,19 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
       c->err = "internal error: line heads larger than the batch";
       release();
       return BVCF_E_HIP;
+    }
+    if (text_bytes > s.cap_h_text) {  // (the caller is done with what this slot returned n_slots collects ago)
+      hipHostFree(s.h_text);
+      s.h_text = nullptr;
+      s.cap_h_text = 0;
+      const uint64_t want = std::min<uint64_t>(text_bytes + text_bytes / 2, c->p.max_batch_bytes + BVCF_DEVICE_PAD);
+      if (hipHostMalloc(&s.h_text, want, hipHostMallocDefault) != hipSuccess) {
+        s.h_text = nullptr;
+        c->err = "hipHostMalloc failed (text copy of a BGZF batch)";
+        release();
+        return BVCF_E_NOMEM;
+      }
+      s.cap_h_text = want;
     }
     if (ctr.n_lines) HIP_TRY(c, hipMemcpyAsync(s.h_head_off, s.d_head_off, ctr.n_lines * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
     if (text_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_text, s.d_heads, text_bytes, hipMemcpyDeviceToHost, s.stream));

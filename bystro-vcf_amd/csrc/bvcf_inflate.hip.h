@@ -190,7 +190,9 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
         // four bytes at any alignment, across the ring's end
         const uint32_t w0 = *reinterpret_cast<const uint32_t *>(&S.in[a & ~3u]);
         const uint32_t w1 = *reinterpret_cast<const uint32_t *>(&S.in[(a + 4u) & (kInfInRing - 1u) & ~3u]);
-        const uint32_t w = __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+        // (every lane reads the same word; saying so keeps the whole decoder state -- bit buffer, positions, symbols --
+        // in scalar registers and its branches scalar: a value that comes out of LDS is a vector value to the compiler)
+        const uint32_t w = bcast0(__builtin_amdgcn_alignbyte(w1, w0, a & 3u));
         bb |= (unsigned long long)w << nb;
         nb += 32u;
         in_pos += 4u;
@@ -303,7 +305,7 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
         const uint32_t want = n_lit + n_dist;
         while (got < want && err == kInfOk) {
           refill();
-          const uint32_t e = S.dist[(uint32_t)bb & 127u];
+          const uint32_t e = bcast0(S.dist[(uint32_t)bb & 127u]);
           const uint32_t l = e >> 5, sym = e & 31u;
           if (l == 0) {
             err = kInfBadCodeLengths;
@@ -340,7 +342,7 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
       }
       const uint8_t *lit_lens = type == 1 ? S.lens : S.lens + 32;
       const uint8_t *dist_lens = type == 1 ? S.lens + 288 : S.lens + 32 + n_lit;
-      if (type == 2 && lit_lens[256] == 0) {
+      if (type == 2 && bcast0(lit_lens[256]) == 0) {
         err = kInfBadCodeLengths;  // no end-of-block code
         break;
       }
@@ -356,10 +358,10 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
         for (uint32_t l = 1; l <= 15; l++) {
           code |= (uint32_t)b & 1u;
           b >>= 1;
-          const uint32_t c = count[l];
+          const uint32_t c = bcast0(count[l]);
           if (code < first + c) {
             take(l);
-            return sorted[index + (code - first)];
+            return bcast0(sorted[index + (code - first)]);
           }
           index += c;
           first += c;
@@ -372,7 +374,7 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
       for (;;) {
         refill();
         if (err != kInfOk) break;
-        uint32_t e = S.lit[(uint32_t)bb & ((1u << kInfLitBits) - 1u)];
+        uint32_t e = bcast0(S.lit[(uint32_t)bb & ((1u << kInfLitBits) - 1u)]);
         uint32_t sym;
         if (e) {
           take(e >> 9);
@@ -389,7 +391,7 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
             err = kInfOutputOverrun;
             break;
           }
-          if (lane == 0) S.win[pos & (kInfWindow - 1u)] = (uint8_t)sym;
+          S.win[pos & (kInfWindow - 1u)] = (uint8_t)sym;  // (every lane the same byte to the same place: no exec mask to set up)
           pos++;
           if ((pos & (kInfSegment - 1u)) == 0u) flush_segments(false);
           continue;
@@ -403,7 +405,7 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
         uint32_t len = inf_len_base(sym - 257u, &extra);
         len += take(extra);
         refill();
-        e = S.dist[(uint32_t)bb & ((1u << kInfDistBits) - 1u)];
+        e = bcast0(S.dist[(uint32_t)bb & ((1u << kInfDistBits) - 1u)]);
         uint32_t dsym;
         if (e) {
           take(e >> 5);
@@ -444,33 +446,74 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
             }
             return S.win[p & (kInfWindow - 1u)];
           };
-          for (uint32_t base = 0; base < len; base += 4u * kWave) {
-            const uint32_t j0 = base + 4u * lane;
-            if (j0 < len) {
-              uint32_t w;
-              if (!periodic && !far) {
-                // source and destination do not overlap: four source bytes from two aligned words of the ring
-                const uint32_t a = (from + j0) & (kInfWindow - 1u);
-                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(&S.win[a & ~3u]);
-                const uint32_t w1 = *reinterpret_cast<const uint32_t *>(&S.win[(a + 4u) & (kInfWindow - 1u) & ~3u]);
-                w = __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
-              } else {
-                // j mod dist for j < 260, dist < 258 from a float reciprocal ((j + 0.5) / dist is never within 0.002
-                // of an integer, the product's error stays below 0.0004); the next three by stepping
-                uint32_t k = periodic ? j0 - dist * (uint32_t)(((float)j0 + 0.5f) * inv) : j0;
-                w = src_byte(from + k);
-                k = (periodic && k + 1u == dist) ? 0u : k + 1u;
-                w |= src_byte(from + k) << 8;
-                k = (periodic && k + 1u == dist) ? 0u : k + 1u;
-                w |= src_byte(from + k) << 16;
-                k = (periodic && k + 1u == dist) ? 0u : k + 1u;
-                w |= src_byte(from + k) << 24;
+          // four bytes of the window at any alignment: two aligned words of the ring
+          auto load4u = [&](uint32_t p) -> uint32_t {
+            const uint32_t a = p & (kInfWindow - 1u);
+            const uint32_t w0 = *reinterpret_cast<const uint32_t *>(&S.win[a & ~3u]);
+            const uint32_t w1 = *reinterpret_cast<const uint32_t *>(&S.win[(a + 4u) & (kInfWindow - 1u) & ~3u]);
+            return __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+          };
+          // ... of the match's source: from the ring, or -- small windows, a match that reaches further back than the ring
+          // will hold once it is written -- from memory, where the finished segments are (a match that overlaps its own
+          // output is never that far back)
+          auto src4 = [&](uint32_t p) -> uint32_t {
+            if (kInfWindow < kInfWindowFull && far) {
+              if (p + 3u + kInfWindow < pos + len) {
+                // (cache-bypassing: this CU's L1 may hold an older copy of the line from before its segment was written)
+                const uintptr_t g = reinterpret_cast<uintptr_t>(dst + p);
+                const uint32_t *wp = reinterpret_cast<const uint32_t *>(g & ~(uintptr_t)3);
+                const uint32_t w0 = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t w1 = __hip_atomic_load(wp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)(g & 3u));
               }
-              const uint32_t o = pos + j0;
-              S.win[o & (kInfWindow - 1u)] = (uint8_t)w;
-              if (j0 + 1u < len) S.win[(o + 1u) & (kInfWindow - 1u)] = (uint8_t)(w >> 8);
-              if (j0 + 2u < len) S.win[(o + 2u) & (kInfWindow - 1u)] = (uint8_t)(w >> 16);
-              if (j0 + 3u < len) S.win[(o + 3u) & (kInfWindow - 1u)] = (uint8_t)(w >> 24);
+              if (p + kInfWindow < pos + len)  // the piece that straddles the ring's oldest byte
+                return src_byte(p) | (src_byte(p + 1u) << 8) | (src_byte(p + 2u) << 16) | (src_byte(p + 3u) << 24);
+            }
+            return load4u(p);
+          };
+          {
+            // A lane writes one ALIGNED dword of the destination per step (whole dwords with one store; only the match's
+            // first and last dword byte by byte).  Genotype text is mostly matches that overlap their own output --
+            // "0|0<TAB>" 64 times over is distance 4, length 258 -- i.e. a period of `dist` bytes: the dword at match
+            // offset j is the period rotated by j mod dist, read with one or two unaligned loads (three bytes or fewer:
+            // from a 64-bit repetition of the period).
+            const uint32_t a0 = pos & 3u;
+            const uint32_t n_dw = (a0 + len + 3u) >> 2;
+            unsigned long long rep = 0;
+            if (periodic && dist < 4u) {
+              const unsigned long long p = bcast0(load4u(from)) & ((1u << (8u * dist)) - 1u);
+              rep = dist == 1u ? p * 0x0101010101010101ull : (dist == 2u ? p * 0x0001000100010001ull : (p | (p << 24) | (p << 48)));
+            }
+            for (uint32_t base = 0; base < n_dw; base += kWave) {
+              const uint32_t dwi = base + lane;
+              if (dwi < n_dw) {
+                const int j0 = (int)(4u * dwi) - (int)a0;  // match offset of the dword's first byte (-3..-1 for the first dword)
+                const uint32_t js = j0 < 0 ? 0u : (uint32_t)j0;
+                uint32_t w;
+                if (!periodic) {
+                  w = src4(from + js);
+                } else {
+                  // js mod dist for js < 262, dist < 258 from a float reciprocal ((j + 0.5) / dist is never within 0.002
+                  // of an integer, the product's error stays below 0.0004)
+                  const uint32_t k = js - dist * (uint32_t)(((float)js + 0.5f) * inv);
+                  if (dist < 4u) {
+                    w = (uint32_t)(rep >> (8u * k));
+                  } else {
+                    const uint32_t n1 = dist - k;  // bytes to the end of the period
+                    w = load4u(from + k);
+                    if (n1 < 4u) w = (w & ((1u << (8u * n1)) - 1u)) | (load4u(from) << (8u * n1));
+                  }
+                }
+                if (j0 < 0) w <<= 8u * (uint32_t)(-j0);  // (byte q of w belongs to match offset j0 + q)
+                const uint32_t o = ((pos & ~3u) + 4u * dwi) & (kInfWindow - 1u);
+                if (j0 >= 0 && (uint32_t)j0 + 4u <= len) {
+                  *reinterpret_cast<uint32_t *>(&S.win[o]) = w;
+                } else {
+#pragma unroll
+                  for (uint32_t q = 0; q < 4; q++)
+                    if (j0 + (int)q >= 0 && (uint32_t)(j0 + (int)q) < len) S.win[o + q] = (uint8_t)(w >> (8u * q));
+                }
+              }
             }
           }
         }
@@ -500,6 +543,13 @@ __global__ __launch_bounds__(kInfThreads) void k_inflate_w16(const uint8_t *comp
                                                              uint8_t *out, uint32_t *status) {
   __shared__ __attribute__((aligned(16))) InfLds<16384> S;
   k_inflate_body<16384>(comp, desc, n_blocks, out, status, S);
+}
+
+// the 4 KiB-window variant: fifteen waves per CU
+__global__ __launch_bounds__(kInfThreads) void k_inflate_w4(const uint8_t *comp, const BgzfDesc *desc, uint32_t n_blocks,
+                                                            uint8_t *out, uint32_t *status) {
+  __shared__ __attribute__((aligned(16))) InfLds<4096> S;
+  k_inflate_body<4096>(comp, desc, n_blocks, out, status, S);
 }
 
 // ------------------------------------------------------------------ CRC-32 of the inflated blocks

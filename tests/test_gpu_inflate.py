@@ -18,10 +18,10 @@ def bv():
     return b
 
 
-@pytest.fixture(autouse=True, params=["w32", "w16"])
+@pytest.fixture(autouse=True, params=["w32", "w16", "w4"])
 def window(request, monkeypatch):
-    """both inflate kernels: the 32 KiB window, and the 16 KiB one that reads older bytes back from memory"""
-    monkeypatch.setenv("BVCF_INFLATE_W16", "1" if request.param == "w16" else "0")
+    """the three inflate kernels: the 32 KiB window, and the 16 and 4 KiB ones that read older bytes back from memory"""
+    monkeypatch.setenv("BVCF_INFLATE_W16", {"w32": "0", "w16": "1", "w4": "2"}[request.param])
     return request.param
 
 

@@ -18,12 +18,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import benchgen as bg  # noqa: E402
 
 
+# zlib level of --bgzf: 6 is what bgzip writes by default (--level=1: half the ratio, twice the symbols)
+LEVEL = int(([a.split('=')[1] for a in sys.argv if a.startswith('--level=')] or ['6'])[0])
+
+
 def _bgzf_part(args):
     import bgzf
     path, off, n = args
     with open(path, "rb") as f:
         f.seek(off)
-        return bgzf.bgzf_compress(f.read(n), level=1, eof_marker=False)
+        return bgzf.bgzf_compress(f.read(n), level=LEVEL, eof_marker=False)
 
 
 def bgzf_file(src, dst, part=0xFF00 * 256):
