@@ -471,7 +471,13 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
             }
             return load4u(p);
           };
-          {
+          if (!far && len <= (uint32_t)kWave) {
+            // a short match (most of them, between the long runs): one byte per lane
+            if ((uint32_t)lane < len) {
+              const uint32_t k = periodic ? (uint32_t)lane - dist * (uint32_t)(((float)lane + 0.5f) * inv) : (uint32_t)lane;
+              S.win[(pos + lane) & (kInfWindow - 1u)] = S.win[(from + k) & (kInfWindow - 1u)];
+            }
+          } else {
             // A lane writes one ALIGNED dword of the destination per step (whole dwords with one store; only the match's
             // first and last dword byte by byte).  Genotype text is mostly matches that overlap their own output --
             // "0|0<TAB>" 64 times over is distance 4, length 258 -- i.e. a period of `dist` bytes: the dword at match
@@ -548,8 +554,11 @@ __global__ __launch_bounds__(kInfThreads) void k_inflate_w16(const uint8_t *comp
 // the 4 KiB-window variant: fifteen waves per CU
 __global__ __launch_bounds__(kInfThreads) void k_inflate_w4(const uint8_t *comp, const BgzfDesc *desc, uint32_t n_blocks,
                                                             uint8_t *out, uint32_t *status) {
-  __shared__ __attribute__((aligned(16))) InfLds<4096> S;
-  k_inflate_body<4096>(comp, desc, n_blocks, out, status, S);
+#ifndef BVCF_INF_SMALL
+#define BVCF_INF_SMALL 4096
+#endif
+  __shared__ __attribute__((aligned(16))) InfLds<BVCF_INF_SMALL> S;
+  k_inflate_body<BVCF_INF_SMALL>(comp, desc, n_blocks, out, status, S);
 }
 
 // ------------------------------------------------------------------ CRC-32 of the inflated blocks
