@@ -49,11 +49,12 @@ CLI = os.path.join(ROOT, "bystro-vcf_amd", "bystro-vcf")
 ORACLE = os.path.join(ROOT, "oracle", "bvcf_oracle")
 
 # per profile: rows per block, resident blocks (a step visits all of them)
-SHAPES = {"c2": (1_000_000, 8), "c3": (311_296, 8), "c4": (262_144, 8), "c5": (98_304, 8)}
+SHAPES = {"c2": (1_000_000, 8), "c3": (311_296, 8), "c4": (262_144, 8), "c5": (98_304, 8), "c5h": (98_304, 8)}
 WORKLOADS = {"c2": "BASELINE configs[1]: sites-only, biallelic SNPs, 0 samples",
              "c3": "BASELINE configs[2]: 1KG-Phase3 chr1-shaped, 2504 samples, biallelic SNPs",
              "c4": "BASELINE configs[3]: 2504 samples, 20% multiallelic + 15% indels",
-             "c5": "not a BASELINE config: 2504 samples with GT:DP:GQ fields (k_stream_gen once the ctx has seen the shape)"}
+             "c5": "not a BASELINE config: 2504 samples with GT:DP:GQ fields (k_stream_gen once the ctx has seen the shape)",
+             "c5h": "not a BASELINE config: as c5, one sample in twenty with haploid calls (chrX-like)"}
 
 
 def rank_blocks(rank, n_blocks, rows):
@@ -239,7 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=0, help="rows per block per GPU (0 = the profile's default)")
     ap.add_argument("--blocks", type=int, default=0, help="resident blocks per GPU; a step visits all of them (0 = default)")
-    ap.add_argument("--profile", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--profile", default="c3", choices=["c2", "c3", "c4", "c5", "c5h"])
     ap.add_argument("--samples", type=int, default=0, help="experiment: another sample count for the profile (e.g. 100000 with --rows 640)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -307,7 +308,7 @@ def main():
     max_bytes = max(sizes)
     stride = ((ns + 3) // 4 + 15) & ~15
     # (c5: the first launches go through k_stream, which leaves every line of this shape to a k_gt task of its own)
-    n_alt_cap = args.rows * (4 if args.profile == "c4" or args.golden else 2 if args.profile == "c5" else 1) + 1024
+    n_alt_cap = args.rows * (4 if args.profile == "c4" or args.golden else 2 if args.profile.startswith("c5") else 1) + 1024
     ctx = bv.Ctx(bg.n_header_fields(cfg), device=local_rank, max_batch_bytes=max_bytes, n_slots=max(1, args.slots),
                  max_lines=args.rows + 16, max_alleles=n_alt_cap,
                  # (the streaming path hands every wave a range of map slots sized by bytes, one per 4 ns + 8 of them,

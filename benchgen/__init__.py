@@ -14,6 +14,8 @@ PROFILES = {
     # not a BASELINE config: GATK-style sample fields "x|y:DP:GQ" (9-10 B, no fixed stride) — the
     # general (ballot / prefix-sum) scan path
     "c5": dict(n_samples=2504, p_multi=0, p_indel=0, p_bad=0, fmt_extra=1),
+    # ... with one sample in twenty haploid ("x:DP:GQ": the males of a chrX file)
+    "c5h": dict(n_samples=2504, p_multi=0, p_indel=0, p_bad=0, fmt_extra=1, haploid=1),
     # not a BASELINE config: every row a common variant (AF ~ 0.3, ~1 300 sample names per output row, ~11 KB of TSV
     # per row) -- the worst case for the host formatter
     "c3d": dict(n_samples=2504, p_multi=0, p_indel=0, p_bad=0, dense=1),
@@ -62,7 +64,7 @@ def make_cfg(profile="c3", seed=SEED, **over):
     c.n_samples = p["n_samples"]
     c.p_multi, c.p_indel, c.p_bad = p["p_multi"], p["p_indel"], p["p_bad"]
     c.pos0 = 10177
-    c.reserved = int(p.get("align16", 0)) | (2 if p.get("fmt_extra", 0) else 0) | (4 if p.get("dense", 0) else 0)
+    c.reserved = int(p.get("align16", 0)) | (2 if p.get("fmt_extra", 0) else 0) | (4 if p.get("dense", 0) else 0) | (8 if p.get("haploid", 0) else 0)
     return c
 
 

@@ -230,11 +230,20 @@ HD void put_sample(const SynthCfg &c, uint64_t r, const RowParams &rp, uint32_t 
   const bool is_short = (s + r) % 3u == 0;
   const uint64_t x = splitmix64(c.seed ^ (r * 0x2545F4914F6CDD1Dull) ^ s);
   uint32_t n = 0;
+  // (reserved bit 3: one sample in twenty -- the same ones on every row, as the males of a chrX file -- has haploid
+  // calls, "x:" with two more digits of DP in place of "|y": the field keeps its length)
+  const bool haploid = (c.reserved & 8u) && splitmix64((c.seed + 0x4D414C45ull) ^ ((uint64_t)s * 0x9E3779B97F4A7C15ull)) % 20u == 0;
   p[n++] = '\t';
   p[n++] = hap_allele(c, r, rp, 2 * s);
-  p[n++] = '|';
-  p[n++] = hap_allele(c, r, rp, 2 * s + 1);
-  p[n++] = ':';
+  if (haploid) {
+    p[n++] = ':';
+    p[n++] = (uint8_t)('0' + (x >> 32) % 10);
+    p[n++] = (uint8_t)('0' + (x >> 36) % 10);
+  } else {
+    p[n++] = '|';
+    p[n++] = hap_allele(c, r, rp, 2 * s + 1);
+    p[n++] = ':';
+  }
   if (is_short) {
     p[n++] = (uint8_t)('0' + x % 10);
   } else {

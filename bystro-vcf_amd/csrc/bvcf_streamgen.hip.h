@@ -76,6 +76,16 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
   uint32_t tabs_base = 0;  // samples: TABs of the region counted so far (exact handler) ...
   uint32_t tabs_lane = 0;  // ... plus what each lane counted in fast chunks (per lane)
   uint32_t het = 0, hom = 0, miss = 0;  // per lane
+  // haploid calls (one allele character: chrX / chrY / chrM samples), per lane: how many are not missing (each counts one
+  // allele towards an, not two) | how many of them carry ALT #1 (hom by class: alt == gt, main.go:1186; one allele
+  // towards ac) << 16.  Taken here unless a dosage matrix is asked for (a haploid carrier's dosage is 1, its class 2).
+  uint32_t hap = 0;
+  const bool hap_ok = a.dosage == nullptr;
+  // wave-uniform: a haploid reference call with sub-fields ("0:...") has been seen -- a chrX-like file.  From then on the
+  // packed-flag tiers take such a field for what it is (one allele towards an, nothing else) instead of sending its chunk
+  // to the field-at-a-time code; files without them do not pay for the test
+  bool hapref = false;
+  constexpr uint32_t kHapRef = 0x3A30u;  // "0:"
   uint32_t n_sp = 0;       // list entries; kDenseMode once the map is dense
   uint32_t bad = 0;        // the line has a field this scan does not take: deferred (per lane until the line ends)
   uint32_t pl = 0;         // 0x80000000 if the last byte of the previous chunk was a TAB
@@ -88,13 +98,16 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
     tabs_base = 0;
     tabs_lane = 0;
     het = hom = miss = 0;
+    hap = 0;
     bad = 0;
     n_sp = list_ok ? 0u : kDenseMode;
     if (maps && !list_ok) zero_stage(stage, n_map_chunks);
   };
   // class of a list entry for ALT index k: '.' in either place makes the sample missing, else one point per allele == k
+  // (second digit 15: a haploid call -- its one allele is all its alleles)
   auto entry_class = [](uint32_t e, uint32_t k) -> uint32_t {
     const uint32_t a4 = (e >> 4) & 15u, b4 = e & 15u;
+    if (b4 == 15u) return a4 == 14u ? 3u : (a4 == k ? 2u : 0u);
     return (a4 == 14u || b4 == 14u) ? 3u : (a4 == k ? 1u : 0u) + (b4 == k ? 1u : 0u);
   };
   auto to_dense = [&]() {
@@ -150,8 +163,9 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
       return;
     }
     wave_sum3(het, hom, miss, ns, &st.n_het, &st.n_hom, &st.n_miss);
-    st.ac = st.n_het + 2u * st.n_hom;
-    st.an = 2u * (ns - st.n_miss);
+    const uint32_t hap_all = __any(hap != 0) ? wave_sum(hap) : 0u;  // (ns <= 16 384: both halves stay below 2^16)
+    st.ac = st.n_het + 2u * st.n_hom - (hap_all >> 16);
+    st.an = 2u * (ns - st.n_miss) - (hap_all & 0xFFFFu);
     uint32_t cm_off = BVCF_NO_CMAP;
     if (maps) {
       const uint32_t slot = bcast0(map_slot());
@@ -189,6 +203,8 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
             }
           }
           if (kmax > max_k) kmax = 0;  // no room for that many lists: ALT #1 as a map, the others through k_gt
+          // (k_head takes the counts of a further index from its list as het + 2 hom: not so for a haploid carrier)
+          if (kmax > 1u && hap_all) kmax = 0;
         }
         if (kmax) {
           // ---- one class list per ALT index (BVCF_ALLELE_CMAP_SPARSE): ascending, one entry per map byte; k_head takes
@@ -257,6 +273,7 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
         const uint32_t pre = wave_excl_scan(__popc(mTr), &tot);
         uint32_t st = starts_all & rng;
         uint32_t cand = 0;
+        bool seen_hapref = false;
 #pragma nounroll
         while (__any(st != 0)) {
           const bool act = st != 0;
@@ -276,7 +293,17 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
           const bool take = act && frame && plain;
           const bool isref = take && (v0 | v2) == 0;
           uint32_t cls = 0;
-          if (act && !take) bad = 1;
+          // one allele character, then ':' or the field's end: the general branch's single token (main.go:1130-1190)
+          const bool take_h = act && !take && hap_ok && v0 < 32u && ((0x400003FFu >> v0) & 1u) &&
+                              (bool)((uint32_t)(c1 == ':') | (uint32_t)(c1 == '\t') | (uint32_t)(c1 == a.eol_byte));
+          if (take_h) {
+            cls = v0 == 30u ? 3u : (v0 == 1u ? 2u : 0u);  // ('.' ^ '0' = 30)
+            hom += cls == BVCF_CLS_HOM;
+            miss += cls == BVCF_CLS_MISSING;
+            hap += (v0 != 30u ? 1u : 0u) + (v0 == 1u ? 0x10000u : 0u);
+            if (v0 == 0u && c1 == ':') seen_hapref = true;
+          }
+          if (act && !take && !take_h) bad = 1;
           if (isref && w != R) cand = w;
           if (take && !isref) {
             // digit 1 scores one, '.' makes the sample missing (table of ALT #1, as in gt_scan_general)
@@ -287,11 +314,13 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
             hom += cls == BVCF_CLS_HOM;
             miss += cls == BVCF_CLS_MISSING;
           }
-          record(maps && take && !isref, s, ((v0 & 15u) << 4) | (v2 & 15u), cls);
+          // (one call for the whole wave: record() ballots)
+          record(maps && ((take && !isref) || (take_h && v0 != 0u)), s, ((v0 & 15u) << 4) | (take_h ? 15u : (v2 & 15u)), cls);
         }
         tabs_base += tot;
         const unsigned long long bc = __ballot(cand != 0);
         if (bc) R = lane_value(cand, __ffsll((long long)bc) - 1);
+        if (__any(seen_hapref)) hapref = true;
         if (!be) break;
         // the byte before the line's content end: a TAB there is an empty last field
         const uint32_t cend = e + 1u - a.eol_chars;
@@ -367,8 +396,19 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
                    s3 = sample_of(S3, before + c2);
     uint32_t x0 = S0 ? u0 ^ R : 0u, x1 = S1 ? u1 ^ R : 0u, x2 = S2 ? u2 ^ R : 0u, x3 = S3 ? u3 ^ R : 0u;
     // ---- fields whose separator / end byte differ from R's, or whose allele bytes are not '0' ^ [0, 31]
+    // (a chrX-like file: its haploid reference calls are settled here, four at a time)
+    if (hapref) {
+      const bool h0 = S0 && ((u0 ^ kHapRef) & 0xFFFFu) == 0u, h1 = S1 && ((u1 ^ kHapRef) & 0xFFFFu) == 0u;
+      const bool h2 = S2 && ((u2 ^ kHapRef) & 0xFFFFu) == 0u, h3 = S3 && ((u3 ^ kHapRef) & 0xFFFFu) == 0u;
+      hap += (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
+      x0 = h0 ? 0u : x0;
+      x1 = h1 ? 0u : x1;
+      x2 = h2 ? 0u : x2;
+      x3 = h3 ? 0u : x3;
+    }
     if (__any(((x0 | x1 | x2 | x3) & 0xFFE0FFE0u) != 0)) {
       uint32_t cand = 0;
+      bool seen_hapref = false;
       auto odd = [&](uint32_t &x, uint32_t u, uint32_t sidx) {
         const bool m = (x & 0xFFE0FFE0u) != 0;
         if (!__any(m)) return;
@@ -379,9 +419,18 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
         const bool plain = v0 < 32u && v2 < 32u && ((0x400003FFu >> v0) & (0x400003FFu >> v2) & 1u);
         const bool take = m && frame && plain;
         const bool isref = take && (v0 | v2) == 0;
-        if (m && !take) bad = 1;
+        const bool take_h = m && !take && hap_ok && v0 < 32u && ((0x400003FFu >> v0) & 1u) &&
+                            (bool)((uint32_t)(c1b == ':') | (uint32_t)(c1b == '\t') | (uint32_t)(c1b == a.eol_byte));
+        if (m && !take && !take_h) bad = 1;
         if (isref) cand = u;
         uint32_t cls = 0;
+        if (take_h) {  // a haploid call (see the exact handler)
+          cls = v0 == 30u ? 3u : (v0 == 1u ? 2u : 0u);  // ('.' ^ '0' = 30)
+          hom += cls == BVCF_CLS_HOM;
+          miss += cls == BVCF_CLS_MISSING;
+          hap += (v0 != 30u ? 1u : 0u) + (v0 == 1u ? 0x10000u : 0u);
+          if (v0 == 0u && c1b == ':') seen_hapref = true;
+        }
         if (take && !isref) {
           const uint32_t table = (1u << 2) | (3u << 28);
           const uint32_t code = ((table >> ((v0 & 15u) * 2u)) & 3u) + ((table >> ((v2 & 15u) * 2u)) & 3u);
@@ -390,7 +439,7 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
           hom += cls == BVCF_CLS_HOM;
           miss += cls == BVCF_CLS_MISSING;
         }
-        record(maps && take && !isref, sidx, ((v0 & 15u) << 4) | (v2 & 15u), cls);
+        record(maps && ((take && !isref) || (take_h && v0 != 0u)), sidx, ((v0 & 15u) << 4) | (take_h ? 15u : (v2 & 15u)), cls);
         if (m) x = 0;  // settled here
       };
       odd(x0, u0, s0);
@@ -399,6 +448,7 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
       odd(x3, u3, s3);
       const unsigned long long bc = __ballot(cand != 0);
       if (bc) R = lane_value(cand, __ffsll((long long)bc) - 1);
+      if (__any(seen_hapref)) hapref = true;
     }
     // ---- the rest, four fields at a time
     if (!__any((x0 | x1 | x2 | x3) != 0)) return;
@@ -502,16 +552,28 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
       const uint32_t u3 = at_start(d4, v.w, S3);
       // (the kernel is bound by instructions issued, of any kind: selecting u ^ R costs one instruction less per dword
       // than two compares and the scalar logic on their masks)
-      const uint32_t mis = (S0 ? u0 ^ R : 0u) | (S1 ? u1 ^ R : 0u) | (S2 ? u2 ^ R : 0u) | (S3 ? u3 ^ R : 0u);
+      uint32_t mis = (S0 ? u0 ^ R : 0u) | (S1 ? u1 ^ R : 0u) | (S2 ? u2 ^ R : 0u) | (S3 ? u3 ^ R : 0u);
       const bool is_hard = hard != 0;
+      const uint32_t two_starts = (S0 & (S0 - 1u)) | (S1 & (S1 - 1u)) | (S2 & (S2 - 1u)) | (S3 & (S3 - 1u));
+      uint32_t hq = 0;
+      if (hapref && hap_ok) {
+        // haploid reference calls count as reference here (a dword with two field starts is not looked at twice: exact handler)
+        const bool h0 = S0 && ((u0 ^ kHapRef) & 0xFFFFu) == 0u, h1 = S1 && ((u1 ^ kHapRef) & 0xFFFFu) == 0u;
+        const bool h2 = S2 && ((u2 ^ kHapRef) & 0xFFFFu) == 0u, h3 = S3 && ((u3 ^ kHapRef) & 0xFFFFu) == 0u;
+        mis = ((S0 && !h0) ? u0 ^ R : 0u) | ((S1 && !h1) ? u1 ^ R : 0u) | ((S2 && !h2) ? u2 ^ R : 0u) | ((S3 && !h3) ? u3 ^ R : 0u) | two_starts;
+        hq = (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
+      }
       if (!__any((mis | hard) != 0)) {
+        hap += hq;
         tabs_lane = (uint32_t)__builtin_popcount(t0) + tabs_lane;
         tabs_lane = (uint32_t)__builtin_popcount(t1) + tabs_lane;
         tabs_lane = (uint32_t)__builtin_popcount(t2) + tabs_lane;
         tabs_lane = (uint32_t)__builtin_popcount(t3) + tabs_lane;
         pl = lane_value(t3, kWave - 1) & 0x80000000u;
         handled = true;
-      } else if (!__any(is_hard)) {
+      } else if (!__any(is_hard || two_starts != 0u)) {
+        // (medium() looks at the first field start of a dword only: a dword with two -- a one-character field, i.e. a haploid
+        // call without sub-fields -- sends the chunk to the exact handler)
         medium(t0, t1, t2, t3, S0, S1, S2, S3, u0, u1, u2, u3);
         pl = lane_value(t3, kWave - 1) & 0x80000000u;
         handled = true;

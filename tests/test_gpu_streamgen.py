@@ -224,3 +224,59 @@ def test_regular_file_through_the_general_kernel_and_back(bv, monkeypatch):
     assert len(a) == len(b) == len(bodies)
     for x, y in zip(a, b):
         assert x == y
+
+
+def _hap_rows(rng, ns, n_lines, p_hap, alts=("G",), dots=True):
+    """chrX-style lines: a share of the samples (the same ones on every line: the males) has haploid calls"""
+    males = [rng.random() < p_hap for _ in range(ns)]
+    rows, pos = [], 100
+    for k in range(n_lines):
+        n_alt = len(alts[k % len(alts)].split(","))
+        f = []
+        for i in range(ns):
+            r = rng.random()
+            if males[i]:
+                g = "0" if r < 0.9 else rng.choice([str(x) for x in range(1, n_alt + 1)] + (["."] if dots else []))
+            else:
+                g = "0/0" if r < 0.9 else "%s/%s" % (rng.choice("01." if dots else "01"), rng.choice([str(x) for x in range(0, n_alt + 1)]))
+            f.append("%s:%d:%d" % (g, rng.randint(0, 99), rng.randint(0, 99)))
+        pos += 11
+        rows.append(_line(pos, f, alt=alts[k % len(alts)], chrom="X"))
+    return rows
+
+
+@pytest.mark.parametrize("ns,p_hap", [(300, 0.05), (2504, 0.5), (700, 1.0)])
+def test_haploid_calls(bv, ns, p_hap):
+    """one allele character per call (chrX males, chrY, chrM): the general branch's single token -- hom when it is the
+    allele (alt == gt), one allele towards an (main.go:1130-1190).  Biallelic and multiallelic lines, '.' calls, with and
+    without a dosage matrix asked for (then such lines are left to k_gt: a haploid carrier's dosage is 1)"""
+    rng = random.Random(ns)
+    rows = _hap_rows(rng, ns, 40, p_hap, alts=("G", "G,T", "G,T,C"))
+    # haploid calls at every byte alignment, as the last field, as the only odd field
+    for sh in range(17):
+        f = _ref_fields(rng, ns)
+        f[3] = "1:%s:9" % ("7" * (1 + sh))
+        f[ns - 1] = "1:5:5" if sh % 2 else "1"
+        f[ns // 2] = ".:0:0"
+        rows.append(_line(5000 + sh, f, chrom="X"))
+    vcf = (vcfgen.header(ns) + "".join(rows)).encode()
+    both(bv, vcf, {"allow": ""})
+    both(bv, vcf, {"allow": "", "keepInfo": True}, max_batch_bytes=1 << 20)
+
+
+def test_haploid_lines_are_not_deferred(bv, bvcf_path):
+    """biallelic lines with 5 % haploid calls stay inside k_stream_gen: no line gets a k_gt task"""
+    if bvcf_path != "streaming-general":
+        pytest.skip("k_stream_gen only")
+    import torch
+    ns = 2504
+    rng = random.Random(5)
+    body = "".join(_hap_rows(rng, ns, 64, 0.05, dots=True)).encode()
+    t = torch.frombuffer(bytearray(body + b"\n" * bv.DEVICE_PAD), dtype=torch.uint8).cuda()
+    ctx = bv.Ctx(9 + ns, max_batch_bytes=len(body), allow="")
+    try:
+        chain, scan, counts = ctx.bench_device([t.data_ptr()], [len(body)], 2, slots=1)
+    finally:
+        ctx.close()
+    assert counts[0] == 64          # every line listed
+    assert counts[4] == counts[0]   # ... and no task slot past the lines' own: nothing left to k_gt

@@ -28,7 +28,7 @@ def mods():
     return bg, bv
 
 
-@pytest.mark.parametrize("profile,first,n", [("c2", 0, 5000), ("c3", 123456, 600), ("c4", 999, 600), ("c5", 77, 400)])
+@pytest.mark.parametrize("profile,first,n", [("c2", 0, 5000), ("c3", 123456, 600), ("c4", 999, 600), ("c5", 77, 400), ("c5h", 77, 400)])
 def test_device_rows_equal_host_rows(mods, profile, first, n):
     bg, bv = mods
     cfg = bg.make_cfg(profile)
@@ -43,6 +43,7 @@ def test_device_rows_equal_host_rows(mods, profile, first, n):
     ("c3", 3000, {}),
     ("c4", 3000, {"keepId": True, "keepInfo": True}),
     ("c5", 2000, {}),
+    ("c5h", 2000, {}),
 ])
 def test_parity_on_bench_shapes(mods, profile, n, cfgd):
     bg, bv = mods
