@@ -777,11 +777,15 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   // with one wave per line: the census path then splits the regular scan of a line over several waves, and is
   // what `choose` picks.
   const bool many_samples = c->n_samples >= kWideSamples;
-  c->fused = c->n_samples > 0 && (path == 2 || (path == 0 && p->n_header_fields >= 256 && !many_samples));
+  c->fused = c->n_samples > 0 && (path == 2 || path == 3 || (path == 0 && p->n_header_fields >= 256 && !many_samples));
   c->wide = !c->fused && many_samples;
   if (const char *e = getenv("BVCF_GEN_STREAM")) c->gen_policy = atoi(e) != 0 ? 1 : 0;
   if (!c->fused || c->n_samples > 4u * kStageBytes) c->gen_policy = 0;  // (a line's dense class map is staged in LDS)
   c->gen_mode = c->gen_policy == 1;
+  if (path == 3 && c->gen_policy < 0) {  // the caller has seen a line: its sample fields carry more than GT
+    c->gen_mode = true;
+    c->shape_seen = true;
+  }
   if (const char *e = getenv("BVCF_WIDE")) c->wide = !c->fused && c->n_samples > 0 && atoi(e) != 0;  // test / tuning override
   if (const char *e = getenv("BVCF_WIDE_WIN")) {  // test / tuning: window of the split general scan, bytes
     const long v = atol(e);

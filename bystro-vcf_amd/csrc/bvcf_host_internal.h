@@ -533,7 +533,19 @@ struct Run {
 uint32_t choose_path(const Run &R, const uint8_t *data, size_t n) {
   if (R.pre.header.size() < 256) return 0;  // the library's own rule (census for narrow files)
   if (R.pre.header.size() >= 9 + (size_t)BVCF_WIDE_SAMPLES) return 0;  // very wide lines: the census path's split scan
-  if (R.pre.header.size() <= 9 + 16384u) return 2;
+  if (R.pre.header.size() <= 9 + 16384u) {
+    // the first data line says which streaming kernel the first batch should take (a BGZF batch is launched before anyone
+    // has seen its text): FORMAT is not plain "GT" -> 3
+    size_t pos = 0;
+    for (int tabs = 0; pos < n && tabs < 8; pos++) {
+      if (data[pos] == R.pre.eol_byte) return 2;
+      tabs += data[pos] == '\t';
+    }
+    size_t e = pos;
+    while (e < n && data[e] != '\t' && data[e] != R.pre.eol_byte) e++;
+    if (e >= n || e == pos) return 2;
+    return (e - pos == 2 && data[pos] == 'G' && data[pos + 1] == 'T') ? 2u : 3u;
+  }
   // FORMAT column (index 8) of the first record
   size_t pos = 0;
   for (int tabs = 0; pos < n && tabs < 8; pos++) {

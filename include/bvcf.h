@@ -119,7 +119,11 @@ typedef struct {
                                  in one pass; only lines with the right field count are listed).  The ctx
                                  walks a batch with the kernel made for the shape of the previous batch's
                                  lines -- bare "x|y" sample fields, or fields with sub-fields beyond GT --
-                                 the results do not depend on which */
+                                 the results do not depend on which;
+                                 3 = as 2, and the caller knows that the sample fields carry more than GT (FORMAT
+                                 "GT:DP:..."): the first batch already takes the kernel for such lines.  bvcf_submit
+                                 finds that out from a host block by itself; a device-resident or BGZF first batch
+                                 cannot be looked at before it is launched */
 } bvcf_params;
 
 /* one input line; 64 bytes */

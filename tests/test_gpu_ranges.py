@@ -224,3 +224,15 @@ def test_dosage_rows_keep_input_order_with_range_readers(bv, tmp_path):
         with open(out, "rb") as f:
             tables.append(ipc.open_file(f).read_all())
     assert tables[0].num_rows > 1000 and tables[0].equals(tables[1])
+
+
+def test_bgzf_file_with_fields_beyond_gt(bv, tmp_path):
+    """a GATK-style cohort file (GT:DP:GQ, 700 samples) as BGZF: the first batch is launched before anyone has seen its
+    text, so the driver tells the ctx from the header blocks it inflated itself which streaming kernel to start with"""
+    vcf = vcfgen.gen_vcf(74, 1500, 700, fmt_extra=True, weird=0.01)
+    want, want_log, n = _want(bv, vcf, {"keepId": True})
+    path = _write(tmp_path, "gatk.vcf.gz", bgzf.bgzf_compress(vcf, level=6))
+    for devices in ("0", "0,0"):
+        p, t, log = _cli_file(["--batchMB", "2", "--keepId", "--devices", devices], path)
+        assert p.returncode == 0 and p.stdout == want and log == want_log, devices
+        assert t["lines_in"] == n and "device" in t["input"]
