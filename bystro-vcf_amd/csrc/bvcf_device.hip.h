@@ -36,10 +36,12 @@
 //   k_sites        a wave walks a run of 8 KiB windows: text ring + TAB bit ring in LDS, line ends into a FIFO, then
 //                  one lane per line for strings.Split / linePasses / getAlleles / trTv and the records
 //                  (replaces k_scatter_eol + k_head + k_finish there)
-// ... and, the default, without the census (the text is read once):
-//   k_sites1       a wave takes 7.5 KiB tiles in ticket order: text + TAB and terminator bitmaps in LDS, the tile's line
-//                  count published at once and the line numbers found by a decoupled look-back; one lane per line,
-//                  the common lines (SNPs, lines the gate rejects) settled without the general getAlleles code
+// ... the default since round 3 (bvcf_sites1.hip.h), census + scans as above, then
+//   k_sites2       a wave takes 7 KiB tiles behind 1 KiB of lead-in: text + TAB and terminator bitmaps in LDS, the tile's
+//                  first line number from the census; one lane per line, the common lines (SNPs, lines the gate
+//                  rejects) settled on fast lanes without the general getAlleles code
+// ... and, kept as BVCF_SITES=3, the same body without the census (the text is read once, and it is slower):
+//   k_sites1       the tile's line count published at once, the line numbers found by a decoupled look-back
 //
 // Everything is byte/integer work over the line bytes; no MFMA.  The genotype scans are bound by
 // VALU issue at 57-70 % of the HBM peak.

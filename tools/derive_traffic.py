@@ -51,4 +51,28 @@ if os.path.exists("%s/pmc_fetch_size_c5.csv" % d):
                  # (the key bench.py looks up for the streaming path's dominant kernel)
                  "k_stream_traffic_bytes_per_launch_per_row": (rd + wr) / rows5,
                  "algorithmic": {"k_stream_gen_read_bytes_per_row": "the whole line, ~24361 B"}}
+# sites-only (c2: the census + k_sites2 chain) and configs[3] (c4: k_stream + followers): every kernel of the chain
+for prof, rows_p in (("c2", 1000000), ("c4", 262144)):
+    if not os.path.exists("%s/pmc_fetch_size_%s.csv" % (d, prof)):
+        continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for ctr, tagc in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        for r in csv.DictReader(open("%s/pmc_%s_size_%s.csv" % (d, tagc, prof))):
+            if "bvcf_dev::" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                acc[r["Kernel_Name"].split("(")[0].split("::")[-1]][ctr].append(float(r["Counter_Value"]))
+    sec = {"rows_per_dispatch": rows_p, "kernels": {}}
+    tot_r = tot_w = 0.0
+    for k, v in acc.items():
+        rd = 2 * sum(v["FETCH_SIZE"]) / max(len(v["FETCH_SIZE"]), 1) * 1024
+        wr = sum(v["WRITE_SIZE"]) / max(len(v["WRITE_SIZE"]), 1) * 1024
+        sec["kernels"][k] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr}
+        tot_r += rd
+        tot_w += wr
+    sec["chain_read_bytes_per_block"] = tot_r
+    sec["chain_write_bytes_per_block"] = tot_w
+    dom = "k_sites2" if prof == "c2" else "k_stream"
+    if dom in sec["kernels"]:
+        t = sec["kernels"][dom]["read_bytes_per_launch"] + sec["kernels"][dom]["write_bytes_per_launch"]
+        sec["traffic_bytes_per_launch_per_row" if prof == "c2" else "k_stream_traffic_bytes_per_launch_per_row"] = t / rows_p
+    out[prof] = sec
 print(json.dumps(out, indent=1))

@@ -32,6 +32,10 @@ for w in $WHAT; do
       stats bench_c4_auto --profile c4
       stats bench_c2_sites_only --profile c2
       stats bench_c2_sites_only_one_block_at_a_time --profile c2 --slots 1
+      BVCF_SITES=1 stats bench_c2_k_sites_round2_chain_one_block_at_a_time --profile c2 --slots 1
+      BVCF_SITES=3 stats bench_c2_k_sites1_one_pass_one_block_at_a_time --profile c2 --slots 1
+      stats bench_c5h_haploid_calls --profile c5h
+      stats bench_c5h_haploid_calls_one_block_at_a_time --profile c5h --slots 1
       stats bench_c5_general_stream --profile c5
       stats bench_c5_general_stream_one_block_at_a_time --profile c5 --slots 1
       BVCF_GEN_STREAM=0 stats bench_c5_k_stream_plus_k_gt --profile c5
@@ -43,6 +47,10 @@ for w in $WHAT; do
       pmc WRITE_SIZE pmc_write_size_census --path 1
       BVCF_GEN_STREAM=1 pmc FETCH_SIZE pmc_fetch_size_c5 --profile c5
       BVCF_GEN_STREAM=1 pmc WRITE_SIZE pmc_write_size_c5 --profile c5
+      pmc FETCH_SIZE pmc_fetch_size_c2 --profile c2
+      pmc WRITE_SIZE pmc_write_size_c2 --profile c2
+      pmc FETCH_SIZE pmc_fetch_size_c4 --profile c4
+      pmc WRITE_SIZE pmc_write_size_c4 --profile c4
       ;;
     line)
       cd $R
