@@ -408,7 +408,11 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   else
     dev_list.push_back(c->device);
   const size_t n_dev = dev_list.size();
-  const bool several_devices = std::set<int>(dev_list.begin(), dev_list.end()).size() > 1;
+  // host threads are bound to the CPUs of their device's NUMA node when the run spans devices (BVCF_NUMA=0: never,
+  // BVCF_NUMA=1: also with one device -- the binding code can then be exercised on a one-GPU box)
+  const char *numa_env = getenv("BVCF_NUMA");
+  const bool numa_off = numa_env && *numa_env == '0', numa_force = numa_env && *numa_env == '1';
+  const bool several_devices = (std::set<int>(dev_list.begin(), dev_list.end()).size() > 1 || numa_force) && !numa_off;
 
   // fmt.Fprintln(writer, stringHeader(config)), main.go:196-200
   if (!c->no_out) {
@@ -529,7 +533,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   };
   std::atomic<size_t> max_in_flight{2};  // batches a device worker keeps submitted
   std::atomic<bool> input_is_bgzf_device{mode == kRangeBgzf};
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned hw = usable_cpus();
   unsigned n_read_thr = (unsigned)std::min<size_t>(8, std::max<size_t>(2, hw / (4 * n_dev)));
   if (const char *e = getenv("BVCF_READ_THREADS")) n_read_thr = (unsigned)std::max(1, atoi(e));  // tuning
 
@@ -1323,7 +1327,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   // ---- start: the sink, the workers (their devices warm up while the header is read), the reader(s)
   sink.start();
   for (auto &W : workers) {
-    if (several_devices && !(getenv("BVCF_NUMA") && *getenv("BVCF_NUMA") == '0')) W->cpus = cpus_near_device(W->device);
+    if (several_devices) W->cpus = cpus_near_device(W->device);
     DevWorker *w = W.get();
     W->dev_th = std::thread(device_main, w);
     W->fmt_th = std::thread(formatter_main, w);
@@ -1548,8 +1552,8 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   const double t_end0 = now_s();
 
   // the final count gather.  The sum is formed on the host; the RCCL all-reduce over the devices that took part (the
-  // path's one collective) costs a communicator bring-up and runs when its result is reported: with
-  // BVCF_TIMING, or BVCF_RCCL=1.
+  // path's one collective) costs a communicator bring-up (seconds with eight devices, inside the run's
+  // wall time) and is what a caller asks for with BVCF_RCCL=1; the totals are the same either way.
   uint64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int used_rccl = 0;
   double t_gather = 0;
@@ -1563,11 +1567,22 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
         live.push_back(W->ctx);
       }
     const char *force = getenv("BVCF_RCCL");
-    const bool want_rccl = timing || (force && *force == '1');
+    const bool want_rccl = force && *force == '1';
     const double tg = now_s();
-    if (!live.empty() && rc == BVCF_OK &&
-        (!want_rccl || bvcf_allreduce_counters(live.data(), (int)live.size(), totals, &used_rccl) != BVCF_OK))
-      bvcf_sum_counters(live.data(), (int)live.size(), totals);  // the summary is informational: never fail the run on it
+    if (!live.empty() && rc == BVCF_OK) {
+      // (the summary is informational: never fail the run on it)
+      if (!want_rccl) {
+        bvcf_sum_counters(live.data(), (int)live.size(), totals);
+      } else if (bvcf_allreduce_counters(live.data(), (int)live.size(), totals, &used_rccl) != BVCF_OK) {
+        if (timing) {
+          const std::string m = std::string("[bvcf timing] count gather over RCCL failed (") + bvcf_last_error(live[0]) +
+                                "): summed on the host\n";
+          write_all(fd_err, m.data(), m.size());
+        }
+        used_rccl = 0;
+        bvcf_sum_counters(live.data(), (int)live.size(), totals);
+      }
+    }
     t_gather = now_s() - tg;
     if (!c->leave_teardown_to_exit)
       for (bvcf_ctx *x : live) bvcf_destroy(x);
@@ -1635,10 +1650,11 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
       for (size_t d = 0; d < n_dev; d++)
         j.append(tmp, (size_t)snprintf(tmp, sizeof tmp,
                                        "%s{\"device\": %d, \"blocks\": %llu, \"bytes\": %llu, \"gpu_wait_s\": %.6f, \"starved_s\": %.6f, "
-                                       "\"read_s\": %.6f, \"format_s\": %.6f}",
+                                       "\"read_s\": %.6f, \"format_s\": %.6f, \"cpus_bound\": %d}",
                                        d ? ", " : "", workers[d]->device, (unsigned long long)workers[d]->n_blocks,
                                        (unsigned long long)workers[d]->n_bytes, workers[d]->t_gpu, workers[d]->t_starved,
-                                       workers[d]->t_read, workers[d]->t_fmt));
+                                       workers[d]->t_read, workers[d]->t_fmt,
+                                       workers[d]->cpus.valid ? CPU_COUNT(&workers[d]->cpus.set) : 0));
       j.append("], \"counters\": [");
       for (int k = 0; k < 8; k++) j.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "%s%llu", k ? ", " : "", (unsigned long long)totals[k]));
       j.append("]}\n");

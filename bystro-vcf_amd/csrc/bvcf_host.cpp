@@ -33,7 +33,7 @@ size_t bvcf_string_header(const bvcf_config *c, char *out, size_t cap) {
 void bvcf_free(void *p) { free(p); }
 
 int bvcf_decompress_fd(int fd_in, int fd_out, uint32_t n_threads, char *kind_out) {
-  if (!n_threads) n_threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  if (!n_threads) n_threads = std::min(32u, usable_cpus());
   bvcf_input::ByteSource src(fd_in, n_threads);
   std::vector<uint8_t> buf(8u << 20);
   for (;;) {
@@ -64,7 +64,7 @@ int bvcf_format_tsv(const bvcf_config *c, const bvcf_result *r, const uint8_t *b
   std::string o, l;
   Names nm(sample_names, sample_name_lens, r->n_samples, or_default(c->field_delimiter, ";"));
   const unsigned nt =
-      c->n_format_threads ? c->n_format_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+      c->n_format_threads ? c->n_format_threads : std::min(32u, usable_cpus());
   std::unique_ptr<WorkPool> pool;
   if (nt > 1 && r->n_lines >= 4 * nt) pool.reset(new WorkPool(nt));
   format_batch(c, r, block, nm, nullptr, pool.get(), o, l);

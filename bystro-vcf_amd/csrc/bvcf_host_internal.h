@@ -1,4 +1,5 @@
 #pragma once
+#include <sched.h>
 // bvcf_host_internal.h — what bvcf_host.cpp (TSV assembly, in-memory driver) and bvcf_driver.cpp (the stream driver)
 // share: the counterpart of readVcf's preamble (main.go:241-304) and of processLines' TSV assembly (main.go:566-695).
 // Everything lives in an unnamed namespace: each of the two translation units has its own copy.
@@ -315,6 +316,62 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
       out.push_back('\n');
     }
   }
+}
+
+// CPUs this process may actually use: the smallest of the hardware's count, the affinity mask and the cgroup's CPU
+// quota (a container on a 256-thread host with "cpu.max 1600000 100000" gets 16 cores' worth of time: thread pools sized
+// by the hardware count only buy throttling -- whole scheduling periods in which every thread of the process stands
+// still, readers and device threads included).
+inline unsigned usable_cpus() {
+  static const unsigned cached = [] {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+      const int k = CPU_COUNT(&set);
+      if (k > 0) n = std::min(n, (unsigned)k);
+    }
+    auto apply = [&](double cores) {
+      if (cores > 0) n = std::min(n, std::max(1u, (unsigned)(cores + 0.999)));
+    };
+    // cgroup v2: "<quota|max> <period>" in cpu.max of the process's group and of every group above it
+    std::string rel;
+    if (FILE *f = fopen("/proc/self/cgroup", "r")) {
+      char line[1024];
+      while (fgets(line, sizeof line, f))
+        if (strncmp(line, "0::", 3) == 0) {
+          rel = line + 3;
+          while (!rel.empty() && (rel.back() == '\n' || rel.back() == '/')) rel.pop_back();
+        }
+      fclose(f);
+    }
+    for (;;) {
+      const std::string path = "/sys/fs/cgroup" + rel + "/cpu.max";
+      if (FILE *f = fopen(path.c_str(), "r")) {
+        char q[64];
+        long long period = 0;
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) apply((double)atoll(q) / (double)period);
+        fclose(f);
+      }
+      if (rel.empty()) break;
+      const size_t cut = rel.rfind('/');
+      rel = cut == std::string::npos ? std::string() : rel.substr(0, cut);
+    }
+    // cgroup v1
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (fscanf(f, "%lld", &quota) != 1) quota = -1;
+      fclose(f);
+    }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(f, "%lld", &period) != 1) period = 0;
+      fclose(f);
+    }
+    if (quota > 0 && period > 0) apply((double)quota / (double)period);
+    if (const char *e = getenv("BVCF_CPUS")) n = (unsigned)std::max(1, atoi(e));  // tuning
+    return n;
+  }();
+  return cached;
 }
 
 // Persistent workers for the per-batch TSV assembly: a batch is a few thousand rows, too short to pay for
@@ -646,7 +703,7 @@ int prepare_run(Run &R, std::string *msg, const uint8_t *data = nullptr, size_t 
   R.names.reset(new Names(R.name_ptr.data(), R.name_len.data(), R.name_ptr.size(), or_default(R.cfg->field_delimiter, ";")));
   R.ratios.reset(new Ratios((uint32_t)R.name_ptr.size()));
   R.n_threads = R.cfg->n_format_threads ? R.cfg->n_format_threads
-                                         : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+                                         : std::min(32u, usable_cpus());
   if (make_pool && R.want_rows && R.n_threads > 1) R.pool.reset(new WorkPool(R.n_threads));
   if (R.cfg->dosage_path && *R.cfg->dosage_path) {  // main.go:306-342
     if (R.pre.header.size() <= 9) {

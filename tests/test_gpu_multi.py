@@ -62,6 +62,19 @@ def test_cli_device_lists_give_identical_output(bv, golden_1kg, devices):
     assert t["count_gather"] == "host"  # ctxs that share a device: RCCL has one rank per device
 
 
+def test_cli_count_gather_is_rccl_only_on_request(bv):
+    """the end-of-run count gather: the host sums the ctxs' counters unless BVCF_RCCL=1 asks for the all-reduce (its
+    communicator bring-up is inside the run's wall time); the totals are the same"""
+    vcf = vcfgen.gen_vcf(62, 400, 40, weird=0.02)
+    t_host = _timing(_cli(["--devices", "0"], vcf, {"BVCF_TIMING": "json"}).stderr)
+    p = _cli(["--devices", "0"], vcf, {"BVCF_TIMING": "json", "BVCF_RCCL": "1"})
+    assert p.returncode == 0, p.stderr[-400:]
+    t_rccl = _timing(p.stderr)
+    assert t_host["count_gather"] == "host" and t_rccl["count_gather"] == "rccl"
+    # (the eighth counter is kernel time)
+    assert t_host["counters"][:7] == t_rccl["counters"][:7] and t_host["counters"][0] == t_host["lines_in"]
+
+
 def test_cli_devices_flags_and_small_input(bv):
     vcf = vcfgen.gen_vcf(61, 500, 40, weird=0.02)
     want = (bv.string_header() + "\n").encode() + orc.run(vcf)[1]

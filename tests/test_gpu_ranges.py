@@ -236,3 +236,19 @@ def test_bgzf_file_with_fields_beyond_gt(bv, tmp_path):
         p, t, log = _cli_file(["--batchMB", "2", "--keepId", "--devices", devices], path)
         assert p.returncode == 0 and p.stdout == want and log == want_log, devices
         assert t["lines_in"] == n and "device" in t["input"]
+
+
+@pytest.mark.parametrize("kind", ["text", "bgzf"])
+def test_numa_binding_path(bv, tmp_path, kind):
+    """BVCF_NUMA=1 takes the path a run over several devices takes: every host thread of a worker binds itself to the
+    CPUs of its device's NUMA node (best effort: a box without the sysfs entries binds nothing).  Same bytes either way."""
+    vcf = vcfgen.gen_vcf(314, 3000, 300, weird=0.02)
+    data = vcf if kind == "text" else bgzf.bgzf_compress(vcf, block=0xFF00, level=1)
+    path = _write(tmp_path, "numa.vcf" + ("" if kind == "text" else ".gz"), data)
+    want, want_log, n = _want(bv, vcf)
+    for numa in ("1", "0"):
+        p, t, log = _cli_file(["--batchMB", "1", "--devices", "0,0"], path, {"BVCF_NUMA": numa})
+        assert p.returncode == 0, p.stderr[-400:]
+        assert p.stdout == want and log == want_log and t["lines_in"] == n
+        bound = [d["cpus_bound"] for d in t["devices"]]
+        assert all(b >= 0 for b in bound) and (numa == "1" or not any(bound))
