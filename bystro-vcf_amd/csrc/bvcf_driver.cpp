@@ -394,10 +394,36 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
   const bool timing_json = timing && strcmp(timing_env, "json") == 0;
   const double t_start = now_s();
   double t_init = 0, t_prepare = 0, t_deal = 0, t_wait_read_stream = 0;
+  // ---- how the input is read
+  enum Mode { kStream, kRangeText, kRangeBgzf };
+  Mode mode = kStream;
+  off_t file_base = 0, file_size = 0;
+  {
+    struct stat st;
+    const char *e = getenv("BVCF_RANGE_READ");
+    const off_t at = lseek(fd_in, 0, SEEK_CUR);
+    if (!(e && *e == '0') && at >= 0 && fstat(fd_in, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > at) {
+      uint8_t magic[18];
+      const ssize_t g = pread(fd_in, magic, sizeof magic, at);
+      file_base = at;
+      file_size = st.st_size;
+      if (g >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        uint32_t xlen = 0;
+        const char *di = getenv("BVCF_DEVICE_INFLATE");
+        if (g == 18 && bvcf_bgzf::block_size(magic, 18, &xlen) != -1 && !(di && *di == '0')) mode = kRangeBgzf;
+      } else if (g > 0) {
+        mode = kRangeText;
+      }
+    }
+  }
+
   Run R;
   R.cfg = c;
   R.n_slots = 3;  // two batches on the device, one more being formatted
-  R.max_batch = c->max_batch_bytes ? c->max_batch_bytes : (64ull << 20);
+  // (BGZF inflated on the device: a batch takes as long as its slowest block -- one wave decodes a block from start to
+  // end -- and every batch costs the device thread ~0.8 ms of launches and waits, so the batches are made larger: 256 MiB
+  // of text = ~4 000 blocks fill the decoder's wave slots; 400 k rows of configs[2] then take 0.034 s instead of 0.063)
+  R.max_batch = c->max_batch_bytes ? c->max_batch_bytes : ((mode == kRangeBgzf ? 256ull : 64ull) << 20);
   const size_t cap = R.max_batch;
   std::atomic<uint64_t> lines_in{0};
 
@@ -428,29 +454,6 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     // fail loudly: there is no CPU path
     dprintf(fd_err, "cannot allocate pinned host memory (no usable HIP device?)\n");
     return BVCF_E_NODEV;
-  }
-
-  // ---- how the input is read
-  enum Mode { kStream, kRangeText, kRangeBgzf };
-  Mode mode = kStream;
-  off_t file_base = 0, file_size = 0;
-  {
-    struct stat st;
-    const char *e = getenv("BVCF_RANGE_READ");
-    const off_t at = lseek(fd_in, 0, SEEK_CUR);
-    if (!(e && *e == '0') && at >= 0 && fstat(fd_in, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > at) {
-      uint8_t magic[18];
-      const ssize_t g = pread(fd_in, magic, sizeof magic, at);
-      file_base = at;
-      file_size = st.st_size;
-      if (g >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-        uint32_t xlen = 0;
-        const char *di = getenv("BVCF_DEVICE_INFLATE");
-        if (g == 18 && bvcf_bgzf::block_size(magic, 18, &xlen) != -1 && !(di && *di == '0')) mode = kRangeBgzf;
-      } else if (g > 0) {
-        mode = kRangeText;
-      }
-    }
   }
 
   // ---- first error wins; everything then drains
@@ -532,6 +535,11 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     for (auto &W : workers) W->cv.notify_all();
   };
   std::atomic<size_t> max_in_flight{2};  // batches a device worker keeps submitted
+  // BGZF batches on the device: a block's DEFLATE stream is decoded by one wave from start to end, so a batch takes as
+  // long as its slowest block however few blocks it has, and a batch of ~1 000 blocks fills a fifth of the wave slots the
+  // decoder's LDS footprint allows: several batches inflate side by side while another is in its kernel chain
+  size_t bgzf_in_flight = 3;
+  if (const char *e = getenv("BVCF_BGZF_IN_FLIGHT")) bgzf_in_flight = (size_t)std::min(8, std::max(1, atoi(e)));  // tuning
   std::atomic<bool> input_is_bgzf_device{mode == kRangeBgzf};
   const unsigned hw = usable_cpus();
   unsigned n_read_thr = (unsigned)std::min<size_t>(8, std::max<size_t>(2, hw / (4 * n_dev)));
@@ -1141,8 +1149,8 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     }
     // one more batch in flight per device than for text: two batches' blocks inflate side by side (k_inflate_w16)
     // while a third is in its kernel chain / on its way back
-    R.n_slots = 4;
-    max_in_flight.store(3);
+    R.n_slots = (uint32_t)bgzf_in_flight + 1;
+    max_in_flight.store(bgzf_in_flight);
     if (!adopt_preamble(htext.data() + data_off, htext.size() - data_off)) {
       inflateEnd(&zs);
       return push_end(false, false);
@@ -1354,7 +1362,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     }
     for (auto &W : workers) {
       // being read into, one queued, two (BGZF: three) on the device, up to two with the formatter
-      W->pool.reset(new BufPool(W->device, buf_bytes, mode == kRangeBgzf ? 4 : 7));
+      W->pool.reset(new BufPool(W->device, buf_bytes, mode == kRangeBgzf ? (int)bgzf_in_flight + 2 : 7));
       W->pool->start(mode == kRangeBgzf ? 1 : 2);
       DevWorker *w = W.get();
       if (mode == kRangeBgzf)
@@ -1495,8 +1503,8 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
         plan.data_off = file_base + (off_t)c0;
         const size_t body = total > c0 ? total - c0 : 0;
         plan.n_ranges = (body + plan.range_bytes - 1) / plan.range_bytes;
-        R.n_slots = 4;
-        max_in_flight.store(3);
+        R.n_slots = (uint32_t)bgzf_in_flight + 1;
+        max_in_flight.store(bgzf_in_flight);
         ok = adopt_preamble(htext.data() + data_off, htext.size() - data_off);
       }
       inflateEnd(&zs);

@@ -38,8 +38,23 @@ enum {
 };
 
 constexpr uint32_t kInfWindowFull = 32768;  // the most a DEFLATE match may reach back
-constexpr uint32_t kInfInRing = 2048;
-constexpr uint32_t kInfLitBits = 10, kInfDistBits = 9;
+// LDS per wave decides how many blocks a CU decodes side by side, and the decoder is bound by the latency of one wave's
+// dependent steps: a 1 KiB input ring filled 512 bytes at a time, a 9-bit literal/length table and an 8-bit distance
+// table (longer codes -- under 1 % of the symbols of genotype text at zlib's levels 1..9 -- take the canonical walk).
+#ifndef BVCF_INF_RING
+#define BVCF_INF_RING 1024
+#endif
+#ifndef BVCF_INF_LIT_BITS
+#define BVCF_INF_LIT_BITS 9
+#endif
+#ifndef BVCF_INF_DIST_BITS
+#define BVCF_INF_DIST_BITS 8
+#endif
+constexpr uint32_t kInfInRing = BVCF_INF_RING;
+constexpr uint32_t kInfFetch = kInfInRing / 2;   // compressed bytes per fetch: 8 per lane
+constexpr uint32_t kInfLitBits = BVCF_INF_LIT_BITS, kInfDistBits = BVCF_INF_DIST_BITS;
+static_assert(kInfFetch == 8u * kWave || kInfFetch == 16u * kWave, "a fetch is one 8- or 16-byte load per lane");
+static_assert(kInfDistBits >= 7, "the code-length code's 7-bit table lives in the distance table's storage");
 constexpr int kInfThreads = kWave;  // one wave per workgroup
 
 template <uint32_t kInfWindow>
@@ -166,15 +181,24 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
     uint32_t flushed = 0;      // output bytes written to memory
     uint32_t err = kInfOk;
 
-    // compressed bytes [in_fetched, in_fetched + 1 KiB) into the ring (all lanes; bytes past the payload are zeros)
+    // compressed bytes [in_fetched, in_fetched + kInfFetch) into the ring (all lanes; bytes past the payload are zeros)
     auto fetch = [&]() {
-      const uint32_t q = in_fetched + 16u * lane;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (q + 16u <= d.in_len) v = *reinterpret_cast<const u32x4_u *>(src + q);
-      *reinterpret_cast<u32x4 *>(&S.in[q & (kInfInRing - 1u)]) = v;
-      if (q < d.in_len && q + 16u > d.in_len)  // the payload's last, partial piece: byte by byte over the zeros
+      constexpr uint32_t kPer = kInfFetch / kWave;  // 8 or 16 bytes per lane
+      const uint32_t q = in_fetched + kPer * lane;
+      if (kPer == 16u) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q + 16u <= d.in_len) v = *reinterpret_cast<const u32x4_u *>(src + q);
+        *reinterpret_cast<u32x4 *>(&S.in[q & (kInfInRing - 1u)]) = v;
+      } else {
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        typedef u32x2_t u32x2_unaligned __attribute__((aligned(1)));
+        u32x2_t v = {0u, 0u};
+        if (q + 8u <= d.in_len) v = *reinterpret_cast<const u32x2_unaligned *>(src + q);
+        *reinterpret_cast<u32x2_t *>(&S.in[q & (kInfInRing - 1u)]) = v;
+      }
+      if (q < d.in_len && q + kPer > d.in_len)  // the payload's last, partial piece: byte by byte over the zeros
         for (uint32_t i = 0; i < d.in_len - q; i++) S.in[(q + i) & (kInfInRing - 1u)] = src[q + i];
-      in_fetched += kChunk;
+      in_fetched += kInfFetch;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     };
@@ -260,7 +284,7 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
         in_pos = q + len;
         bb = 0;
         nb = 0;
-        in_fetched = in_pos & ~(kChunk - 1u);
+        in_fetched = in_pos & ~(kInfFetch - 1u);
         fetch();
         continue;
       }

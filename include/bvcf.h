@@ -313,8 +313,8 @@ typedef struct {
                                    ctxs and unpinning the buffers, the OS reclaims them (~0.1 s of a 0.9 s run) */
   uint8_t reserved[2];
   int32_t device;               /* HIP device ordinal */
-  uint32_t n_format_threads;    /* 0 = hardware concurrency */
-  uint64_t max_batch_bytes;     /* 0 = 64 MiB */
+  uint32_t n_format_threads;    /* 0 = the CPUs the process may use (affinity, cgroup quota), at most 32 */
+  uint64_t max_batch_bytes;     /* 0 = 64 MiB (256 MiB of text for a BGZF file inflated on the device) */
   const char *sample_list_path; /* --sample: write the sample names, one per line (main.go:398-445); NULL/"" = no */
   const char *dosage_path;      /* --dosageOutput: Arrow IPC file of the dosage matrix (main.go:306-342); NULL/"" = no */
   uint8_t no_out;               /* --noOut: no TSV rows and no header line (main.go:196-208,502) */

@@ -2,7 +2,7 @@
 """End-to-end CLI timing: synthetic rows -> file -> bystro-vcf (HIP) -> /dev/null, with the stage times of
 BVCF_TIMING, and (optionally) an md5 comparison with the oracle CLI on the same file.
 
-    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH] [--bgzf] [--samples=N] [--pipe] [--json] [--devices=LIST] [--threads=N]
+    python tools/e2e_cli.py [rows=400000] [profile=c3] [--check] [--dosage] [--runs=N] [--keep=PATH] [--bgzf] [--samples=N] [--pipe] [--json] [--devices=LIST] [--batchMB=N] [--threads=N]
 
 Needs a GPU box.  The file is written to /dev/shm when it fits there, else /tmp, and removed afterwards.
 """
@@ -91,6 +91,8 @@ def main():
         for a in sys.argv:
             if a.startswith("--devices="):
                 extra += ["--devices", a.split("=", 1)[1]]
+            if a.startswith("--batchMB="):
+                extra += ["--batchMB", a.split("=", 1)[1]]
         if "--dosage" in sys.argv:
             extra = ["--dosageOutput", path + ".arrow"]
         runs = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--runs=")]

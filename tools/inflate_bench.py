@@ -2,7 +2,7 @@
 """k_inflate / k_inflate_w16 alone: N BGZF blocks of synthetic configs[2] rows (zlib level 6, bgzip's default), inflated
 on the device `reps` times through bvcf_bgzf_inflate_device.  Run it under rocprofv3 --kernel-trace --stats for the
 kernels' durations (the call itself includes the copies over PCIe):
-    python tools/inflate_bench.py [blocks=2000] [reps=5] [level=6]"""
+    python tools/inflate_bench.py [blocks=2000] [reps=5] [level=6] [profile=c3]"""
 import ctypes as C
 import os
 import sys
@@ -18,8 +18,9 @@ import bystro_vcf_amd as bv  # noqa: E402
 n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-cfg = bg.make_cfg("c3")
-rows = n_blocks * 0xFF00 // 10167 + 1
+profile = sys.argv[4] if len(sys.argv) > 4 else "c3"
+cfg = bg.make_cfg(profile)
+rows = n_blocks * 0xFF00 // {"c3": 10167, "c4": 10190, "c5": 24361, "c5h": 24000, "c2": 142}.get(profile, 10167) + 64
 t, nbytes = bg.rows_device(cfg, 0, rows)
 text = bytes(memoryview(t[:n_blocks * 0xFF00].cpu().numpy()))
 import multiprocessing as mp

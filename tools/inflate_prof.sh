@@ -3,11 +3,12 @@
 R=$PWD
 N=${1:-2000}
 LEVEL=${2:-6}
+PROFILE=${3:-c3}
 cd /tmp && export TMPDIR=/tmp
 for lib in ${LIBS:-libbvcf.so}; do
   for w16 in ${VARIANTS:-0 1}; do
     rm -rf /tmp/prof_inf
-    BVCF_LIB=$R/bystro-vcf_amd/$lib BVCF_INFLATE_W16=$w16 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_inf -- python3 $R/tools/inflate_bench.py $N 4 $LEVEL > $R/gpurun_out/inflate_bench_${lib}_$w16.log 2>&1
+    BVCF_LIB=$R/bystro-vcf_amd/$lib BVCF_INFLATE_W16=$w16 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_inf -- python3 $R/tools/inflate_bench.py $N 4 $LEVEL $PROFILE > $R/gpurun_out/inflate_bench_${lib}_$w16.log 2>&1
     f=$(find /tmp/prof_inf -name "*kernel_stats.csv" | head -1)
     echo "$lib w16=$w16: $(grep -m1 '^text' $R/gpurun_out/inflate_bench_${lib}_$w16.log)"
     python3 -c "
