@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -515,8 +516,15 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
   }
 }
 
-// x^(8 * 1024 * 2^l) mod P for l = 0..5 (zlib's x2nmodp / multmodp, reflected CRC-32 polynomial): k_crc32's fold
-static CrcConsts crc_consts() {
+// k_crc32's tables (bvcf_inflate.hip.h), built once and kept on every device that inflates: slicing-by-4, the same
+// tables moved on by 1 008 zero bytes, x^(8 * 16 * (63 - L)) per lane (zlib's multmodp on the reflected CRC-32 polynomial)
+static const CrcTabs *crc_tabs_on_device() {
+  static std::mutex mu;
+  static const CrcTabs *on_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (on_dev[dev]) return on_dev[dev];
   auto mul = [](uint32_t a, uint32_t b) {
     uint32_t p = 0;
     for (int i = 31; i >= 0; i--) {
@@ -525,14 +533,39 @@ static CrcConsts crc_consts() {
     }
     return p;
   };
-  uint32_t x = 0x40000000u;  // x^1
-  for (int k = 0; k < 13; k++) x = mul(x, x);  // x^(2^13)
-  CrcConsts kc;
-  for (int l = 0; l < 6; l++) {
-    kc.k[l] = x;
-    x = mul(x, x);
+  auto xpow = [&](uint64_t n) {  // x^n mod P
+    uint32_t r = 0x80000000u, b = 0x40000000u;  // x^0, x^1
+    for (; n; n >>= 1) {
+      if (n & 1u) r = mul(r, b);
+      b = mul(b, b);
+    }
+    return r;
+  };
+  static CrcTabs t;
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+    t.std4[0][i] = c;
   }
-  return kc;
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = t.std4[0][i];
+    for (int j = 1; j < 4; j++) {
+      c = t.std4[0][c & 0xFFu] ^ (c >> 8);
+      t.std4[j][i] = c;
+    }
+  }
+  const uint32_t k1008 = xpow(8u * 1008u);
+  for (int j = 0; j < 4; j++)
+    for (uint32_t i = 0; i < 256; i++) t.jump[j][i] = mul(k1008, t.std4[j][i]);
+  for (uint32_t L = 0; L < 64; L++) t.lane_k[L] = xpow(8u * 16u * (63u - L));
+  CrcTabs *d = nullptr;
+  if (hipMalloc(&d, sizeof t) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) {
+    hipFree(d);
+    return nullptr;
+  }
+  on_dev[dev] = d;
+  return d;
 }
 
 // inflate + CRC of BGZF blocks whose compressed bytes are at d_comp (device): text to d_text.  desc/crc/status are
@@ -540,7 +573,7 @@ static CrcConsts crc_consts() {
 // w16: the 16 KiB-window kernel (two batches of blocks resident at once), for text whose lines are well under 16 KB
 static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_desc, uint32_t n_blocks, uint8_t *d_text,
                            uint32_t *d_status, uint32_t *d_crc, hipStream_t st, bool w16) {
-  static const CrcConsts kc = crc_consts();
+  const CrcTabs *crc_tabs = crc_tabs_on_device();
   static const int per_cu32 = [] {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_inflate, kInfThreads, 0) != hipSuccess || n < 1) n = 4;
@@ -575,8 +608,10 @@ static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_de
     hipLaunchKernelGGL(k_inflate_w16, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
   else
     hipLaunchKernelGGL(k_inflate, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
-  hipLaunchKernelGGL(k_crc32, dim3(std::min<uint32_t>(n_blocks ? n_blocks : 1, (uint32_t)n_cu * 8u)), dim3(kWave), 0, st,
-                     (const uint8_t *)d_text, d_desc, n_blocks, kc, d_crc);
+  // (no tables: the launch is left out, the status words stay as they were, k_cuts reports the mismatch)
+  if (crc_tabs)
+    hipLaunchKernelGGL(k_crc32, dim3(std::min<uint32_t>(n_blocks ? n_blocks : 1, (uint32_t)n_cu * 16u)), dim3(kWave), 0, st,
+                       (const uint8_t *)d_text, d_desc, n_blocks, crc_tabs, d_crc);
 }
 
 // the kernel chain of the batch in slot s over the resident text src[0 .. nbytes), the counter read-back and the event

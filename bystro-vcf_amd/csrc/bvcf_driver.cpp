@@ -419,7 +419,9 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
 
   Run R;
   R.cfg = c;
-  R.n_slots = 3;  // two batches on the device, one more being formatted
+  size_t text_in_flight = 2;
+  if (const char *e = getenv("BVCF_TEXT_IN_FLIGHT")) text_in_flight = (size_t)std::min(6, std::max(1, atoi(e)));  // tuning
+  R.n_slots = (uint32_t)text_in_flight + 1;  // two batches on the device, one more being formatted
   // (BGZF inflated on the device: a batch takes as long as its slowest block -- one wave decodes a block from start to
   // end -- and every batch costs the device thread ~0.8 ms of launches and waits, so the batches are made larger: 256 MiB
   // of text = ~4 000 blocks fill the decoder's wave slots; 400 k rows of configs[2] then take 0.034 s instead of 0.063)
@@ -534,7 +536,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     plan.cv.notify_all();
     for (auto &W : workers) W->cv.notify_all();
   };
-  std::atomic<size_t> max_in_flight{2};  // batches a device worker keeps submitted
+  std::atomic<size_t> max_in_flight{text_in_flight};  // batches a device worker keeps submitted
   // BGZF batches on the device: a block's DEFLATE stream is decoded by one wave from start to end, so a batch takes as
   // long as its slowest block however few blocks it has, and a batch of ~1 000 blocks fills a fifth of the wave slots the
   // decoder's LDS footprint allows: several batches inflate side by side while another is in its kernel chain
@@ -1362,7 +1364,7 @@ int bvcf_run_fd(const bvcf_config *c, int fd_in, int fd_out, int fd_err, uint64_
     }
     for (auto &W : workers) {
       // being read into, one queued, two (BGZF: three) on the device, up to two with the formatter
-      W->pool.reset(new BufPool(W->device, buf_bytes, mode == kRangeBgzf ? (int)bgzf_in_flight + 2 : 7));
+      W->pool.reset(new BufPool(W->device, buf_bytes, mode == kRangeBgzf ? (int)bgzf_in_flight + 2 : 5 + (int)text_in_flight));
       W->pool->start(mode == kRangeBgzf ? 1 : 2);
       DevWorker *w = W.get();
       if (mode == kRangeBgzf)

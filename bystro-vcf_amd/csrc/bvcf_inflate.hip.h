@@ -586,13 +586,22 @@ __global__ __launch_bounds__(kInfThreads) void k_inflate_w4(const uint8_t *comp,
 }
 
 // ------------------------------------------------------------------ CRC-32 of the inflated blocks
-// BGZF's trailer carries the CRC-32 (IEEE 802.3, reflected) of each block's text.  One wave per block: the block is
-// seen as the tail of a 64 KiB buffer of zeros (leading zeros do not change a CRC that starts from 0; the usual
-// 0xFFFFFFFF start value is the same as inverting the first four bytes), lane i takes the i-th KiB byte by byte from a
-// 256-entry table in LDS, and six scan steps fold the 64 partial CRCs: crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in
-// GF(2)[x] mod P, with the six constants x^(8 * 1024 * 2^l) mod P supplied by the host.
-struct CrcConsts {
-  uint32_t k[6];
+// BGZF's trailer carries the CRC-32 (IEEE 802.3, reflected) of each block's text.  One wave per block, the text read
+// in ROWS of 1 KiB -- lane L takes bytes [16 L, 16 L + 16) of every row, so a row is one coalesced load (a lane that
+// walks its own contiguous KiB instead touches 64 cache lines per load instruction and the kernel runs at a sixth of
+// this one's rate).  A CRC without its start value is linear over GF(2): the block's CRC is the XOR of the CRCs of 64
+// messages, lane L's being its own bytes with zeros everywhere else.  Within a row a lane takes its four dwords by
+// slicing-by-4 (table j: a byte followed by j zero bytes); to get from the end of its chunk to the same place in the
+// next row its state has to pass 1 008 zero bytes, which is another table lookup per state byte (the same tables
+// multiplied by x^(8 * 1008) mod P) and needs no step of its own: T(adv(S) ^ w) = T(adv(S)) ^ T(w).  The block is seen
+// as the TAIL of a whole number of rows (leading zeros do not change a CRC that starts from 0; the usual 0xFFFFFFFF
+// start value is the same as inverting the first four bytes), so every lane's last chunk ends 16 (63 - L) bytes before
+// the end: one multiplication by x^(8 * 16 * (63 - L)) per lane and six XOR steps across the wave finish it.
+// Tables and constants come from the host (CrcTabs, bvcf_core.hip).
+struct CrcTabs {
+  uint32_t std4[4][256];  // std4[j][b]: CRC register after byte b and j zero bytes
+  uint32_t jump[4][256];  // jump[j][b] = std4[j][b] * x^(8 * 1008)
+  uint32_t lane_k[64];    // x^(8 * 16 * (63 - L))
 };
 
 __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {  // zlib's multmodp, branch-free
@@ -605,65 +614,82 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {  // zli
   return p;
 }
 
-__global__ __launch_bounds__(kWave) void k_crc32(const uint8_t *text, const BgzfDesc *desc, uint32_t n_blocks, CrcConsts kc,
+__global__ __launch_bounds__(kWave) void k_crc32(const uint8_t *text, const BgzfDesc *desc, uint32_t n_blocks, const CrcTabs *tabs,
                                                  uint32_t *crc_out) {
-  __shared__ uint32_t s_tab4[4][256];  // slicing-by-4: table j = the CRC of a byte followed by j zero bytes
-  uint32_t *s_tab = s_tab4[0];
+  __shared__ uint32_t s_t[2048];  // std4 then jump
   const int lane = lane_id();
-  for (uint32_t i = lane; i < 256; i += kWave) {
-    uint32_t c = i;
-    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-    s_tab4[0][i] = c;
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(tabs);
+    for (uint32_t i = lane; i < 2048; i += kWave) s_t[i] = g[i];
   }
+  const uint32_t my_k = tabs->lane_k[lane];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = lane; i < 256; i += kWave) {
-    uint32_t c = s_tab4[0][i];
-    for (int j = 1; j < 4; j++) {
-      c = s_tab4[0][c & 0xFFu] ^ (c >> 8);
-      s_tab4[j][i] = c;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  auto fold = [&](uint32_t x, uint32_t base) -> uint32_t {
+    return s_t[base + 768u + (x & 0xFFu)] ^ s_t[base + 512u + ((x >> 8) & 0xFFu)] ^ s_t[base + 256u + ((x >> 16) & 0xFFu)] ^
+           s_t[base + (x >> 24)];
+  };
   for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     const BgzfDesc d = desc[blk];
     const uint8_t *p = text + d.out_off;
-    const uint32_t n = d.isize;           // <= 65536
-    const uint32_t pad = 65536u - n;      // virtual leading zeros
-    const uint32_t v_lo = (uint32_t)lane * 1024u, v_hi = v_lo + 1024u;
-    uint32_t crc = 0;
-    // the lane's real bytes: virtual [max(v_lo, pad), v_hi) -> real offsets - pad
-    uint32_t v = max(v_lo, pad);
-    // up to the first real offset that is a multiple of 4 (and past the inverted first four bytes), byte by byte
-    for (; v < v_hi && (((v - pad) & 3u) != 0u || v - pad < 4u); v++) {
-      const uint32_t r = v - pad;
-      uint32_t b = p[r];
-      if (r < 4u) b ^= 0xFFu;  // the 0xFFFFFFFF start value
-      crc = s_tab[(crc ^ b) & 0xFFu] ^ (crc >> 8);
-    }
-    for (; v + 4u <= v_hi; v += 4u) {  // four bytes per step
-      typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-      const uint32_t w = *reinterpret_cast<const u32_unaligned *>(p + (v - pad)) ^ crc;  // (text + out_off + r: r % 4 == 0; out_off may be odd)
-      crc = s_tab4[3][w & 0xFFu] ^ s_tab4[2][(w >> 8) & 0xFFu] ^ s_tab4[1][(w >> 16) & 0xFFu] ^ s_tab4[0][w >> 24];
-    }
-    for (; v < v_hi; v++) crc = s_tab[(crc ^ p[v - pad]) & 0xFFu] ^ (crc >> 8);
-    // inclusive scan: after step l a lane holds the CRC of up to 2^(l+1) KiB ending with its own
-#pragma unroll
-    for (int l = 0; l < 6; l++) {
-      const uint32_t left = __shfl_up(crc, 1u << l);
-      if (lane >= (1 << l)) crc = gf2_mulmod(kc.k[l], left) ^ crc;
-    }
-    if (lane == kWave - 1) {
-      uint32_t out = crc ^ 0xFFFFFFFFu;
-      if (n < 4u) {
-        // shorter than the start value: the plain definition
+    const uint32_t n = d.isize;  // <= 65536
+    if (n < 4u) {
+      // shorter than the start value: the plain definition
+      if (lane == 0) {
         uint32_t c = 0xFFFFFFFFu;
-        for (uint32_t j = 0; j < n; j++) c = s_tab[(c ^ p[j]) & 0xFFu] ^ (c >> 8);
-        out = c ^ 0xFFFFFFFFu;
+        for (uint32_t j = 0; j < n; j++) c = s_t[(c ^ p[j]) & 0xFFu] ^ (c >> 8);
+        crc_out[blk] = c ^ 0xFFFFFFFFu;
       }
-      crc_out[blk] = out;
+      continue;
     }
+    const uint32_t n_rows = (n + 1023u) >> 10;
+    const int pad = (int)(n_rows * 1024u - n);  // virtual leading zeros
+    uint32_t S = 0;
+    for (uint32_t r = 0; r < n_rows; r++) {
+      const int r0 = (int)(r * 1024u + 16u * (uint32_t)lane) - pad;  // offset in the text of the chunk's first byte
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (r0 >= 0) {
+        const u32x4 v = *reinterpret_cast<const u32x4_u *>(p + r0);
+        w[0] = v.x;
+        w[1] = v.y;
+        w[2] = v.z;
+        w[3] = v.w;
+      } else if (r0 > -16) {
+        // the chunk the text starts in
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int i = -r0; i < 16; i++) {
+          const uint32_t b = (uint32_t)p[r0 + i] << (8u * ((uint32_t)i & 3u));
+          if (i < 4) a0 |= b; else if (i < 8) a1 |= b; else if (i < 12) a2 |= b; else a3 |= b;
+        }
+        w[0] = a0;
+        w[1] = a1;
+        w[2] = a2;
+        w[3] = a3;
+      }
+      if (r0 < 4 && r0 > -16) {
+        // the 0xFFFFFFFF start value: the text's first four bytes inverted
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        for (int t = 0; t < 4; t++) {
+          const int i = t - r0;
+          if (i >= 0 && i < 16) {
+            const uint32_t m = 0xFFu << (8u * ((uint32_t)i & 3u));
+            if (i < 4) m0 |= m; else if (i < 8) m1 |= m; else if (i < 12) m2 |= m; else m3 |= m;
+          }
+        }
+        w[0] ^= m0;
+        w[1] ^= m1;
+        w[2] ^= m2;
+        w[3] ^= m3;
+      }
+      S = fold(S, 1024u) ^ fold(w[0], 0u);
+      S = fold(S ^ w[1], 0u);
+      S = fold(S ^ w[2], 0u);
+      S = fold(S ^ w[3], 0u);
+    }
+    uint32_t c = gf2_mulmod(my_k, S);
+#pragma unroll
+    for (int l = 0; l < 6; l++) c ^= __shfl_xor(c, 1 << l);
+    if (lane == 0) crc_out[blk] = c ^ 0xFFFFFFFFu;
   }
 }
 
