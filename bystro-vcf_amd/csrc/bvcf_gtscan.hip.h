@@ -118,6 +118,9 @@ struct FastAcc {
   uint32_t bad, het, hom, miss;
   uint32_t n_sp;  // wave-uniform: entries in the raw list of the line; > BVCF_CMAP_SPARSE_MAX once the line went dense
   uint32_t hi = 0;  // dense mode: allele bytes seen that may be a digit >= 2 (or a dot): bits of tor & 0x000E000E
+  // wave-uniform, dense mode with a raw list at hand: the list now collects only the lanes that hold a digit >= 2 or a
+  // dot -- what the class lists of the further ALT indices are made of (finish_dense) --; kDenseMode once they outgrew it
+  uint32_t n_oth = 0;
 };
 
 // Most alleles of a cohort file are carried by a handful of samples.  A line therefore starts in LIST MODE: a lane
@@ -202,16 +205,31 @@ __device__ __forceinline__ uint32_t class_byte(uint32_t LO, uint32_t HI) {
 }
 
 // list mode -> dense: the entries classified for ALT #1 into the zeroed stage, their counts into the lanes that replay
-__device__ __forceinline__ void list_to_stage(const RawList *sp, uint32_t n, uint32_t ka, uint8_t *stage, uint32_t n_chunks,
+__device__ __forceinline__ void list_to_stage(RawList *sp, uint32_t n, uint32_t ka, uint8_t *stage, uint32_t n_chunks,
                                               FastAcc &acc) {
   zero_stage(stage, n_chunks);
   u32x4 e = {0u, 0u, 0u, 0u};
   uint32_t idx = 0;
   if ((uint32_t)lane_id() < n) {
     e = sp->t[lane_id()];
-    idx = sp->idx[lane_id()] % kStageBytes;
+    idx = sp->idx[lane_id()];
   }
   acc.hi |= e.x | e.y | e.z | e.w;
+  {
+    // the list goes on as the list of lanes that hold anything but 0 and 1 (every lane has read its entry above; LDS
+    // accesses of a wave complete in order)
+    const bool oth = ((e.x | e.y | e.z | e.w) & 0x000E000Eu) != 0;
+    const unsigned long long nz = __ballot(oth);
+    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (oth) {
+      sp->t[at] = e;
+      sp->idx[at] = idx;
+    }
+    acc.n_oth = bcast0((uint32_t)__popcll(nz));
+  }
+  idx %= kStageBytes;
   const Alleles4 g = gather4(e.x, e.y, e.z, e.w);
   uint32_t LO, HI;
   classes4(g, ka, &LO, &HI);
@@ -273,6 +291,23 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
     }
     if (dense) {
       acc.hi |= tor;
+      if (sp && acc.n_oth < kDenseMode) {
+        // lanes with a digit >= 2 or a dot: the further ALT indices' class lists come from them at the line's end
+        const unsigned long long nz = __ballot((tor & 0x000E000Eu) != 0);
+        if (nz) {
+          const uint32_t cnt = (uint32_t)__popcll(nz);
+          if (acc.n_oth + cnt <= kRawMax) {
+            const uint32_t at = acc.n_oth + __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
+            if (tor & 0x000E000Eu) {
+              sp->t[at] = u32x4{t[0], t[1], t[2], t[3]};
+              sp->idx[at] = c * 64u + (uint32_t)lane;
+            }
+            acc.n_oth = bcast0(acc.n_oth + cnt);
+          } else {
+            acc.n_oth = bcast0(kDenseMode);
+          }
+        }
+      }
       const Alleles4 g = gather4(t[0], t[1], t[2], t[3]);
       uint32_t LO, HI;
       classes4(g, ka, &LO, &HI);
@@ -287,6 +322,75 @@ __device__ __forceinline__ void fast_chunk(u32x4 v, uint32_t c, uint32_t n_chunk
     flush_stage(stage, cmap, c - (c % kStageChunks), ((c % kStageChunks) + 1u) * 64u, stride);
     if (c + 1 != n_chunks) zero_stage(stage, n_chunks - (c + 1u));
   }
+}
+
+// the highest allele digit (2..9) some entry carries, 1 when there is none (dots alone, 0x1E, do not count: they are in
+// every list anyway).  tor = the entry's four words or-ed
+__device__ __forceinline__ uint32_t highest_allele(const Alleles4 &g, uint32_t tor) {
+  uint32_t kmax = 1;
+  if (__any((tor & 0x000E000Eu) != 0)) {
+    // bytes >= 2 that are not dots
+    const uint32_t hi2 = (((g.A + 0x7E7E7E7Eu) & ~g.dA) | ((g.B + 0x7E7E7E7Eu) & ~g.dB)) & 0x80808080u;
+    if (__any(hi2 != 0)) {
+#pragma nounroll
+      for (uint32_t k = 9; k >= 2; k--) {
+        const uint32_t kk = k * 0x01010101u;
+        if (__any((zero_b(g.A ^ kk) | zero_b(g.B ^ kk)) != 0)) {
+          kmax = k;
+          break;
+        }
+      }
+    }
+  }
+  return kmax;
+}
+// do the carriers (and missing samples) of each of ALT #2..#kmax fit a class list?
+__device__ __forceinline__ bool further_fit(const Alleles4 &g, uint32_t kmax) {
+#pragma nounroll
+  for (uint32_t k = 2; k <= kmax; k++) {
+    uint32_t lo_k, hi_k;
+    classes4(g, k * 0x01010101u, &lo_k, &hi_k);
+    if (__popcll(__ballot(class_byte(lo_k, hi_k) != 0)) > (int)BVCF_CMAP_SPARSE_MAX) return false;
+  }
+  return true;
+}
+// the class lists of ALT #2..#kmax from the entries the lanes hold (idx = the entry's map byte): ALT #k's at
+// lists + 64 * (k - 1)
+__device__ __forceinline__ void write_further_lists(const Alleles4 &g, uint32_t idx, uint32_t kmax, uint8_t *lists) {
+#pragma nounroll
+  for (uint32_t k = 2; k <= kmax; k++) {
+    uint32_t lo_k, hi_k;
+    classes4(g, k * 0x01010101u, &lo_k, &hi_k);
+    const uint32_t byte_k = class_byte(lo_k, hi_k);
+    const unsigned long long nz = __ballot(byte_k != 0);
+    uint32_t *list = reinterpret_cast<uint32_t *>(lists + 64u * (k - 1u));
+    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
+    if (byte_k) __builtin_nontemporal_store((idx << 8) | byte_k, list + 1u + at);
+    if (lane_id() == 0) __builtin_nontemporal_store((uint32_t)__popcll(nz), list);
+  }
+}
+
+// End of a line that went dense with a raw list at hand: the list holds the n (1..kRawMax) lanes that saw anything but
+// 0 and 1 (fast_chunk, list_to_stage), in scan order.  When every further allele's carriers fit a class list, the lists
+// go to the next slot (cmap_extra; may be null: no spare slot) and the return value is finish_list's "dense map of
+// ALT #1, bits 1-3 = kmax" form; 1 << 1 when the entries are dots only; 0 leaves the further alleles to k_gt.
+__device__ __forceinline__ uint32_t finish_dense(const RawList *sp, uint32_t n, uint32_t stride, uint8_t *cmap_extra,
+                                                 bool *used_extra) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  u32x4 e = {0u, 0u, 0u, 0u};
+  uint32_t idx = 0;
+  if ((uint32_t)lane_id() < n) {
+    e = sp->t[lane_id()];
+    idx = sp->idx[lane_id()];
+  }
+  const Alleles4 g = gather4(e.x, e.y, e.z, e.w);
+  const uint32_t kmax = highest_allele(g, e.x | e.y | e.z | e.w);
+  if (kmax == 1u) return 1u << 1;
+  if (kmax > 7u || !cmap_extra || 64u * (kmax - 1u) > stride || !further_fit(g, kmax)) return 0u;
+  write_further_lists(g, idx, kmax, cmap_extra - 64u);  // (ALT #2's list at the start of the extra slot)
+  *used_extra = true;
+  return kmax << 1;
 }
 
 // End of a line that stayed in list mode (n = acc.n_sp <= kRawMax entries): lane i classifies entry i.  Returns what
@@ -323,23 +427,7 @@ __device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc,
   acc.hom = __popc(HI & ~LO);
   acc.miss = __popc(LO & HI);
   const uint32_t byte1 = class_byte(LO, HI);
-  // further alleles: a digit 2..9 in some entry (dots alone, 0x1E, do not count: they are in every list anyway)
-  uint32_t kmax = 1;
-  const uint32_t tor = e.x | e.y | e.z | e.w;
-  if (__any((tor & 0x000E000Eu) != 0)) {
-    // bytes >= 2 that are not dots
-    const uint32_t hi2 = (((g.A + 0x7E7E7E7Eu) & ~g.dA) | ((g.B + 0x7E7E7E7Eu) & ~g.dB)) & 0x80808080u;
-    if (__any(hi2 != 0)) {
-#pragma nounroll
-      for (uint32_t k = 9; k >= 2; k--) {
-        const uint32_t kk = k * 0x01010101u;
-        if (__any((zero_b(g.A ^ kk) | zero_b(g.B ^ kk)) != 0)) {
-          kmax = k;
-          break;
-        }
-      }
-    }
-  }
+  const uint32_t kmax = highest_allele(g, e.x | e.y | e.z | e.w);
   const bool sparse1 = n <= BVCF_CMAP_SPARSE_MAX && kmax <= max_k;
   uint32_t enc;
   uint8_t *lists = cmap;  // where the list of ALT #k goes: lists + 64 * (k - 1)
@@ -355,28 +443,12 @@ __device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc,
     // every further allele's carriers must fit a list (else k_gt scans them).  Tried instead: dense maps of ALT #2..#4
     // grown beside ALT #1's in the stage during the scan -- no rescans at all, but k_stream, which is bound by
     // instruction issue, took 23 % longer on configs[3] (and 1-5 % on biallelic files), more than k_gt's rescans cost
-    if (kmax > 7u || !cmap_extra || 64u * (kmax - 1u) > stride) return 0u;
-#pragma nounroll
-    for (uint32_t k = 2; k <= kmax; k++) {
-      uint32_t lo_k, hi_k;
-      classes4(g, k * 0x01010101u, &lo_k, &hi_k);
-      if (__popcll(__ballot(class_byte(lo_k, hi_k) != 0)) > (int)BVCF_CMAP_SPARSE_MAX) return 0u;
-    }
+    if (kmax > 7u || !cmap_extra || 64u * (kmax - 1u) > stride || !further_fit(g, kmax)) return 0u;
     enc = kmax << 1;
     lists = cmap_extra - 64u;  // (ALT #2's list at the start of the extra slot)
     *used_extra = true;
   }
-#pragma nounroll
-  for (uint32_t k = 2; k <= kmax; k++) {
-    uint32_t lo_k, hi_k;
-    classes4(g, k * 0x01010101u, &lo_k, &hi_k);
-    const uint32_t byte_k = class_byte(lo_k, hi_k);
-    const unsigned long long nz = __ballot(byte_k != 0);
-    uint32_t *list = reinterpret_cast<uint32_t *>(lists + 64u * (k - 1u));
-    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
-    if (byte_k) __builtin_nontemporal_store((idx << 8) | byte_k, list + 1u + at);
-    if (lane == 0) __builtin_nontemporal_store((uint32_t)__popcll(nz), list);
-  }
+  write_further_lists(g, idx, kmax, lists);
   if (sparse1) {
     // the list of ALT #1: count, then the entries (an entry may carry a zero byte: a lane whose fields only hold
     // other alleles)

@@ -64,6 +64,12 @@ constexpr uint32_t kS1Chunks = kS1Win / kChunk;        // chunk loads per tile s
 #ifndef BVCF_S1_WAVES
 #define BVCF_S1_WAVES 4
 #endif
+// k_sites2's waves per SIMD: three, by its 168 registers.  Measured with the general per-line code compiled out (100
+// registers, no spills): four waves per SIMD are no faster (69.3 vs 69.9 us) -- the kernel is bound by what it moves,
+// 153 MB in and 129 MB of records out per 142 MB of text; capped at 128 registers with that code in, it spills (84 us)
+#ifndef BVCF_S2_WAVES_EU
+#define BVCF_S2_WAVES_EU 3
+#endif
 // ONE tile per wave: a tile's count is published when the tile is staged.  (A wave that took two tiles in a row
 // published the second one only after finishing the first -- which waits for every earlier tile, i.e. for the previous
 // workgroup's second tile: a chain through the whole block, 8.5 ms instead of 0.1.)
@@ -88,14 +94,28 @@ __host__ __device__ inline uint32_t s1_state_words(uint32_t nbytes) {
   return s1_l0_off(nw) + (nw + 1u) / 2u + kS1LookWgs / 2u + 8u;  // (the window's loads may start a little before and end a little behind the words in use)
 }
 
+// The terminator bitmap is read once per tile (the
+// lane's four words, step 3), before the rounds start: the rounds' FIFO and the long first line's buffers live in its
+// place.  A line's 64 TAB bits may be fetched from up to two words behind `tabs` -- whatever is there lies past the
+// line's end and is masked off (a line of 64 bytes or more has its first 64 bytes inside the window).
+constexpr uint32_t kS2Plane = 32u * 16u + 64u;  // one 16-byte piece of 32 records, and the skew
+// (plain stores: the L2 gathers the pieces of a cache line; as non-temporal stores the old per-lane pieces took 123 us
+// instead of 69, whole lines 67 instead of 64)
+__device__ __forceinline__ void s2_store(u32x4 v, u32x4 *p) { *p = v; }
 struct S1Lds {
   uint8_t text[kS1Win];                 // byte x of the window
-  uint32_t tabs[kS1Win / 32 + 4];       // bit x: byte x is a TAB (zero words behind the window)
-  uint32_t eols[kS1Win / 32];           // bit x: byte x is the terminator
-  uint32_t fifo[kWave];                 // the round's line ends: window offset | TABs before it << 16
-  uint8_t long_head[kS1LongHead];       // the first bytes of a line that starts before the window
-  uint32_t long_tab[10];                // ... its first 9 TAB offsets (block offsets) and its TAB count
+  uint32_t tabs[kS1Win / 32];           // bit x: byte x is a TAB
+  union {
+    uint32_t eols[kS1Win / 32];         // bit x: byte x is the terminator
+    struct {
+      uint32_t fifo[kWave];             // the round's line ends: window offset | TABs before it << 16
+      uint8_t long_head[kS1LongHead];   // the first bytes of a line that starts before the window
+      uint32_t long_tab[10];            // ... its first 9 TAB offsets (block offsets) and its TAB count
+    };
+  };
+  uint32_t xpose[4 * kS2Plane / 4];     // 32 line records on their way out, piece by piece (see the rounds)
 };
+static_assert(sizeof(S1Lds) == 10240 + 4 * kS2Plane, "three workgroups per CU (the registers allow no more)");
 
 __device__ __forceinline__ uint32_t s1_load(const uint32_t *p) {
 #ifdef BVCF_EXP_S1_RMW
@@ -128,7 +148,6 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
   const int lane = lane_id();
   const uint32_t wiw = bcast0(threadIdx.x >> 6);
   S1Lds &S = s_lds[wiw];
-  if (lane < 4) S.tabs[kS1Win / 32 + lane] = 0u;
   const uint32_t nb = a.nbytes;
   const uint32_t need = min(9u, a.n_header - 1u);  // TABs that bound the fixed columns we read
   const uint32_t cap_off = (a.cap - 16u) & ~3u;
@@ -460,24 +479,53 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
       S1STAMP(4)
       const uint32_t line = base + n_done + (uint32_t)lane;
 
-      if (simple && line < a.max_lines) {
+      // ---- the records of the common lines, written as whole cache lines.  A lane storing its own 64-byte records
+      // touches 64 cache lines per store instruction, a quarter of each: with eight such stores per round the kernel
+      // took 69 us per 142 MB, 43 without them.  The round's records are consecutive in memory (line = base + lane), so
+      // they go out transposed -- lane L stores bytes [16 L, 16 L + 16) of a KiB, piece L & 3 of record L >> 2 --: the
+      // line records through an LDS scratch, 32 at a time (planes of one 16-byte piece each, skewed by 64 bytes so that
+      // the four pieces of a record sit in different banks); the allele records, constants but for three bytes, from a
+      // ds_bpermute of those.
+      const unsigned long long smask = __ballot(simple && line < a.max_lines);
+      if (smask) {
+        const uint32_t line0 = base + n_done;  // (wave-uniform)
         const bool ok = status == BVCF_LINE_OK;
-        u32x4 *dl = reinterpret_cast<u32x4 *>(&a.lines[line]);
-        dl[0] = u32x4{ls, len, fe[0], fe[1]};
-        dl[1] = u32x4{fe[2], fe[3], fe[4], fe[5]};
-        dl[2] = u32x4{fe[6], fe[7], fe[8], 0u};                                            // rec_first
-        dl[3] = u32x4{ok ? 1u : 0u, n_tabs + 1u, line, status};                            // n_rec, n_fields, gt_task, status | site_type << 8
-        if (line < a.max_alleles) {
-          if (ok) {
-            u32x4 *da = reinterpret_cast<u32x4 *>(&a.alleles[line]);
-            da[0] = u32x4{0u, 0u, line, 0u};                                               // pos, line, alt_idx
-            da[1] = u32x4{0u, 1u, 0u, 0u};                                                 // alt_off, alt_len, ac, an
-            da[2] = u32x4{0u, 0u, 0u, BVCF_NO_CMAP};                                       // n_het, n_hom, n_miss, cmap_off
-            da[3] = u32x4{ref_b | (alt_b << 8), (uint32_t)trtv_of((uint8_t)ref_b, (uint8_t)alt_b) | ((uint32_t)BVCF_ALLELE_POS_TEXT << 8),
-                          kNoTask, 0u};                                                    // ref alt_base kind site_type | trtv flags pad | gt_task | pad2
-          } else {
-            a.alleles[line].gt_task = kNoTask;
+        const u32x4 pc[4] = {u32x4{ls, len, fe[0], fe[1]}, u32x4{fe[2], fe[3], fe[4], fe[5]}, u32x4{fe[6], fe[7], fe[8], 0u},  // .. rec_first
+                             u32x4{ok ? 1u : 0u, n_tabs + 1u, line, status}};  // n_rec, n_fields, gt_task, status | site_type << 8
+        uint8_t *const xp = reinterpret_cast<uint8_t *>(S.xpose);
+        const uint32_t piece = (uint32_t)lane & 3u, sub = (uint32_t)lane >> 2;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+          if (((uint32_t)(smask >> (32u * h))) == 0u) continue;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (((uint32_t)lane >> 5) == h) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) *reinterpret_cast<u32x4 *>(xp + kS2Plane * q + 16u * ((uint32_t)lane & 31u)) = pc[q];
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t src = 32u * h + 16u * k + sub;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(xp + kS2Plane * piece + 16u * (16u * k + sub));
+            if ((smask >> src) & 1ull) s2_store(v, reinterpret_cast<u32x4 *>(&a.lines[line0 + 32u * h + 16u * k]) + lane);
+          }
+        }
+        // alleles: {pos = 0 (text), line, alt_idx 0} {alt_off 0, alt_len 1, ac 0, an 0} {n_het, n_hom, n_miss 0, no class map}
+        // {ref alt_base kind 0 site_type 0 | trtv flags | no task | 0}; a line that failed the gate gets the same record (all
+        // that counts there is "no task")
+        const uint32_t packed = ref_b | (alt_b << 8) | ((uint32_t)trtv_of((uint8_t)ref_b, (uint8_t)alt_b) << 16);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          const uint32_t src = 16u * k + sub;
+          const uint32_t info = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src * 4u), (int)packed);
+          const uint32_t rec = line0 + src;
+          u32x4 v = u32x4{0u, 0u, rec, 0u};
+          if (piece == 1u) v = u32x4{0u, 1u, 0u, 0u};
+          if (piece == 2u) v = u32x4{0u, 0u, 0u, BVCF_NO_CMAP};
+          if (piece == 3u) v = u32x4{info & 0xFFFFu, (info >> 16) | ((uint32_t)BVCF_ALLELE_POS_TEXT << 8), kNoTask, 0u};
+          if (((smask >> src) & 1ull) && rec < a.max_alleles) s2_store(v, reinterpret_cast<u32x4 *>(&a.alleles[line0 + 16u * k]) + lane);
         }
       }
 
@@ -750,7 +798,7 @@ __global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(3, 3
   s1_body<false>(a, n_tiles, 0u);
 }
 
-__global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sites2(KernelArgs a, uint32_t n_tiles, uint32_t n_chunks) {
+__global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(BVCF_S2_WAVES_EU, BVCF_S2_WAVES_EU))) void k_sites2(KernelArgs a, uint32_t n_tiles, uint32_t n_chunks) {
   s1_body<true>(a, n_tiles, n_chunks);
 }
 

@@ -353,20 +353,28 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           }
           STAMP(3);
           // a line that ends in list mode: its entries classified now, for ALT #1 and every further ALT index; a line that
-          // went dense on the way: all that is known is whether anything but 0 and 1 was seen at all.  A second slot (for
-          // the lists of the further alleles of a line whose ALT #1 became a map) only while the wave's range still covers
-          // one slot for every line that may follow in its run (a regular line is at least 4 ns + 8 bytes long).
+          // went dense on the way kept listing the lanes that saw anything but 0 and 1: the further ALT indices' class
+          // lists come from those (finish_dense).  A second slot (for the lists of the further alleles of a line whose
+          // ALT #1 became a map) only while the wave's range still covers one slot for every line that may follow in its
+          // run (a regular line is at least 4 ns + 8 bytes long).
           uint32_t enc = 0, n_slots = 1;
+          auto spare_slot = [&]() -> bool {
+            return cm_next + 2u <= cm_end && cm_end - (cm_next + 2u) >= (r1 - min(r1, peA)) / (4u * ns + 8u) + 2u &&
+                   cmap_of(a, cm_next + 1u, true) != BVCF_NO_CMAP;
+          };
           if (sparse_ok && acc.n_sp < kDenseMode) {
-            const bool spare = acc.n_sp > BVCF_CMAP_SPARSE_MAX && cm_next + 2u <= cm_end &&
-                               cm_end - (cm_next + 2u) >= (r1 - min(r1, peA)) / (4u * ns + 8u) + 2u &&
-                               cmap_of(a, cm_next + 1u, true) != BVCF_NO_CMAP;
+            const bool spare = acc.n_sp > BVCF_CMAP_SPARSE_MAX && spare_slot();
             bool two = false;
             enc = finish_list(sparse, acc, cm, min(kListAlleles, a.cmap_stride / (4u * kSparseWords)), stage, nc, a.cmap_stride,
                               spare ? cm + a.cmap_stride : nullptr, &two);
             if (two) n_slots = 2;
-          } else if (sparse_ok && !__any((acc.hi & 0x000E000Eu) != 0)) {
+          } else if (sparse_ok && acc.n_oth == 0u) {
             enc = 1u << 1;
+          } else if (sparse_ok && acc.n_oth < kDenseMode) {
+            // the lanes that saw a digit >= 2 or a dot were listed on the way: the further alleles' class lists from them
+            bool two = false;
+            enc = finish_dense(sparse, acc.n_oth, a.cmap_stride, spare_slot() ? cm + a.cmap_stride : nullptr, &two);
+            if (two) n_slots = 2;
           }
           if (__any(acc.bad != 0)) {
             // A is not regular after all: B was predicted from a wrong line end.  Leave the

@@ -132,3 +132,91 @@ def test_dosage_rows_of_multiallelic_lines(bv):
     assert len(got) == len(want) > 100
     for i, (dg, dw) in enumerate(zip(got, want)):
         assert dg == dw, i
+
+
+def _dense_first_rows(seed, ns, n_lines, sep="|"):
+    """ALT #1 common (hundreds of carriers: its class map goes dense, more than 63 non-reference groups), ALT #2..#k
+    carried by a few samples each -- before, inside and after the stretch of the line where the raw list overflows --,
+    sometimes missing genotypes, sometimes one further allele that is common too (no list: k_gt)"""
+    rng = random.Random(seed)
+    bases = "ACGT"
+    rows = []
+    pos = 1000
+    for li in range(n_lines):
+        pos += rng.randint(1, 50)
+        n_alt = rng.choice([2, 2, 3, 4, 5, 7, 8])
+        ref = rng.choice(bases)
+        alts = [rng.choice([b for b in bases if b != ref]) + ("" if k < 3 else "C" * (k - 2)) for k in range(n_alt)]
+        gts = [["0", "0"] for _ in range(ns)]
+        lo = rng.choice([0, 0, ns // 3, ns // 2])       # where ALT #1's carriers start: the list overflows there
+        for s in rng.sample(range(lo, ns), rng.randint(min(300, (ns - lo) // 2), (ns - lo) * 2 // 3)):
+            gts[s] = rng.choice([["0", "1"], ["1", "0"], ["1", "1"]])
+        mode = li % 6
+        for k in range(2, n_alt + 1):
+            if mode == 5 and k == n_alt:
+                continue                                 # the last allele has no carriers: its row is dropped
+            n_car = rng.randint(1, 14) if not (mode == 4 and k == 2) else rng.randint(40, 90)
+            for s in rng.sample(range(ns), n_car):
+                o = rng.choice(["0", "1", str(k), str(rng.randint(1, n_alt))])
+                gts[s] = [str(k), o] if rng.random() < 0.5 else [o, str(k)]
+        if mode in (1, 3):
+            for s in rng.sample(range(ns), rng.randint(1, 6 if mode == 1 else 70)):
+                gts[s] = rng.choice([[".", "."], [".", "1"], ["2", "."]])
+        row = ["7", str(pos), "rs%d" % li, ref, ",".join(alts), ".", "PASS", "NA=%d" % n_alt, "GT"]
+        row += [sep.join(g) for g in gts]
+        rows.append("\t".join(row))
+    return rows
+
+
+@pytest.mark.parametrize("seed,ns", [(31, 2504), (32, 2504), (33, 1030), (34, 513), (35, 2560), (36, 300)])
+def test_further_alleles_of_dense_lines(bv, seed, ns):
+    """a line whose ALT #1 outgrows the raw list keeps listing the lanes that hold anything but 0 and 1; the further
+    alleles' class lists come from those (finish_dense) instead of a rescan per allele (main.go:549-556)"""
+    vcf = (vcfgen.header(ns) + "\n".join(_dense_first_rows(seed, ns, 240, "|" if seed % 2 else "/")) + "\n").encode()
+    out = both(bv, vcf, {"allow": "", "keepInfo": True})
+    assert out.count(b"MULTIALLELIC") > 400
+    both(bv, vcf, {"allow": "", "keepId": True}, max_batch_bytes=1 << 20)
+
+
+def test_dense_lines_use_lists_for_further_alleles(bv, bvcf_path):
+    """streaming path, 2 504 samples: ALT #2.. of a line whose ALT #1 is a dense map come back as class lists (flag
+    BVCF_ALLELE_CMAP_SPARSE) with the census path's counts and classes"""
+    if bvcf_path != "streaming":
+        pytest.skip("streaming path only")
+    ns = 2504
+    # few carriers of the further alleles, nobody missing, at most four ALTs (their carriers' lanes fit the raw list);
+    # three biallelic lines between any two of them, as in a real file: a wave has a quarter more class-map slots than
+    # lines, and every such line takes a second one
+    dense = [r for i, r in enumerate(_dense_first_rows(41, ns, 240)) if i % 6 in (0, 2) and int(r.split("NA=")[1].split("\t")[0]) <= 4]
+    plain = [r for r in _rows(42, ns, 1300) if "NA=1\t" in r][:3 * len(dense)]
+    assert len(plain) == 3 * len(dense)
+    rows, is_dense = [], []
+    for i, r in enumerate(dense):
+        rows += plain[3 * i:3 * i + 3] + [r]
+        is_dense += [False, False, False, True]
+    body = ("\n".join(rows) + "\n").encode()
+    res = {}
+    for path in (1, 2):
+        ctx = bv.Ctx(9 + ns, allow="", path=path)
+        res[path] = ctx.process(body)
+        ctx.close()
+    a, b = res[1], res[2]
+    n_lists = n_further = 0
+    for i in range(len(rows)):
+        ra, rb = a.records(i), b.records(i)
+        assert len(ra) == len(rb)
+        if not is_dense[i]:
+            continue
+        assert len(rb) >= 2
+        assert not int(rb[0]["flags"]) & 2           # ALT #1: a dense map
+        for x, y in zip(ra, rb):
+            for f in ("alt_idx", "ac", "an", "n_het", "n_hom", "n_miss"):
+                assert x[f] == y[f], (i, f, int(x[f]), int(y[f]))
+            if x["ac"] > 0:
+                assert (a.classes(x) == b.classes(y)).all(), (i, int(x["alt_idx"]))
+                if int(y["alt_idx"]) > 0:
+                    n_further += 1
+                    n_lists += (int(y["flags"]) & 2) != 0
+    # (an allele whose carriers -- its own and the other alleles' partners -- sit in more than 15 four-sample groups has
+    # no list and is scanned by k_gt, as is a line the wave had no spare slot for)
+    assert n_further > 40 and n_lists >= 0.8 * n_further, (n_lists, n_further)
