@@ -110,6 +110,7 @@ struct bvcf_ctx {
   bool sites = false; // no sample columns: k_sites after the census instead of k_scatter_eol + k_head + k_finish
   bool sites1 = false;  // ... or k_sites1 on its own, no census, the line numbers by look-back (BVCF_SITES=3)
   bool sites2 = false;  // ... or k_sites2 behind the census: tiles, the common lines on fast lanes (the default for such input)
+  bool sites2_tile_census = true;  // ... its census per tile (k_count_tiles + one scan) instead of per chunk (BVCF_S2_CENSUS=chunk)
   int sites_grid = 0, sites1_grid = 0;
   uint32_t win_bytes = 64u << 10;  // wide: bytes of a line's sample region per wave of the split general scan
   uint32_t tile_bytes = 0, tile_quota = 0;
@@ -472,6 +473,17 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
   const uint32_t n_groups = (n_chunks + kScanGroup - 1) / kScanGroup;
   const uint32_t stream_grid = (uint32_t)std::min<uint64_t>((n_chunks + kWavesPerWg - 1) / kWavesPerWg,
                                                             (uint64_t)c->n_cu * 8);
+  if (c->sites2 && c->sites2_tile_census) {
+    // the census per tile, one scan level
+    const uint32_t n_tiles = s2_n_tiles(a.nbytes);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_tiles + kWavesPerWg - 1) / kWavesPerWg, (uint64_t)c->n_cu * 8);
+    hipLaunchKernelGGL(k_count_tiles, dim3(grid ? grid : 1), dim3(kWgThreads), 0, st, a, n_tiles);
+    hipLaunchKernelGGL(k_scan_flat, dim3(1), dim3(1024), 0, st, a, n_tiles);
+    if (ev_gt0) hipEventRecord(ev_gt0, st);
+    hipLaunchKernelGGL(k_sites2, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, n_tiles, 0u);
+    if (ev_gt1) hipEventRecord(ev_gt1, st);
+    return;
+  }
   hipLaunchKernelGGL(k_count_eol, dim3(stream_grid ? stream_grid : 1), dim3(kWgThreads), 0, st, a, n_chunks);
   hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, n_chunks);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
@@ -878,6 +890,7 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
     c->sites2 = c->sites && m == 2;
     c->sites1 = c->sites && m == 3;
   }
+  if (const char *e = getenv("BVCF_S2_CENSUS")) c->sites2_tile_census = strcmp(e, "chunk") != 0;  // (A/B and parity tests)
   per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sites, kSitesThreads, 0) != hipSuccess || per_cu < 1)
     per_cu = 3;

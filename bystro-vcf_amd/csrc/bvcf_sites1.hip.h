@@ -202,7 +202,9 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
       // terminators before the tile = the census prefix of its first chunk (k_count_eol / k_scan_*): asked for now, used
       // when the records are written
       const uint32_t c_first = tile_start / kChunk;
-      if (c_first < n_chunks) {
+      if (n_chunks == 0u) {  // the census was taken per tile (k_count_tiles) and scanned in one go
+        if (has_tile) rank_c = a.census[t];
+      } else if (c_first < n_chunks) {
         rank_c = a.census[c_first];
         rank_g = a.group_base[c_first / kScanGroup];
       }
@@ -796,6 +798,90 @@ __global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(3, 3
     while (wall_clock64() < until) __builtin_amdgcn_s_sleep(4);
   }
   s1_body<false>(a, n_tiles, 0u);
+}
+
+// k_sites2's own census: terminators per TILE, one wave per tile and seven chunk loads in flight; census[t] then goes
+// through k_scan_top alone (20 k values per 142 MB: one workgroup's work), where the per-chunk census needs two scan levels
+__global__ __launch_bounds__(kWgThreads) void k_count_tiles(KernelArgs a, uint32_t n_tiles) {
+  const int lane = lane_id();
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  const uint32_t last_off = a.cap - 16u;
+  constexpr uint32_t kN = kS2Tile / kChunk;
+  for (uint32_t t = wave_in_grid(); t < n_tiles; t += stride) {
+    const uint32_t base = t * kS2Tile;  // (n_tiles * kS2Tile < 2^32 + kS2Tile: blocks stay below 4 GiB)
+    const uint32_t tile_end = (uint32_t)min((unsigned long long)base + kS2Tile, (unsigned long long)a.nbytes);
+    u32x4 v[kN];
+#pragma unroll
+    for (uint32_t c = 0; c < kN; c++) v[c] = ld_stream(a.buf + min(base + c * kChunk + 16u * lane, last_off));
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < kN; c++) cnt += __popc(eq_mask16(v[c], a.eol_byte) & bits_until(tile_end, base + c * kChunk + 16u * lane));
+    cnt = wave_sum(cnt);
+    if (lane == 0) a.census[t] = cnt;
+  }
+}
+
+// ... and its scan: census[0, n) -> exclusive prefixes in place, one workgroup, 32 values per thread and step from eight
+// independent 16-byte loads (k_scan_top's thread walks its share value by value -- fine for a few hundred group totals,
+// 26 us for the 20 k tiles of 142 MB).  Sets the batch counters as k_scan_top does on the paths without k_stream.
+__global__ __launch_bounds__(1024) void k_scan_flat(KernelArgs a, uint32_t n) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  const int lane = lane_id();
+  const uint32_t w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_carry = 0u;
+  __syncthreads();
+  constexpr uint32_t kPer = 32, kStep = 1024u * kPer;
+  u32x4 *const p4 = reinterpret_cast<u32x4 *>(a.census);  // (hipMalloc'ed: 16-byte aligned; its capacity covers the step's tail)
+  for (uint32_t base = 0; base < n; base += kStep) {
+    const uint32_t lo = base + threadIdx.x * kPer;
+    u32x4 v[kPer / 4];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer / 4; i++) v[i] = lo + 4u * i < n ? p4[(lo >> 2) + i] : u32x4{0u, 0u, 0u, 0u};
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kPer / 4; i++) {
+      const uint32_t at = lo + 4u * i;  // values past n (the buffer's stale tail) do not count
+      if (at + 1u >= n + 1u) v[i].x = 0u;
+      if (at + 1u >= n) v[i].y = 0u;
+      if (at + 2u >= n) v[i].z = 0u;
+      if (at + 3u >= n) v[i].w = 0u;
+      sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    uint32_t wtot;
+    const uint32_t pre = wave_excl_scan(sum, &wtot);
+    if (lane == 0) s_wave[w] = wtot;
+    __syncthreads();
+    uint32_t run = s_carry + pre, total = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+      const uint32_t x = s_wave[j];
+      run += j < w ? x : 0u;
+      total += x;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kPer / 4; i++) {
+      const u32x4 e = v[i];
+      const u32x4 o = u32x4{run, run + e.x, run + e.x + e.y, run + e.x + e.y + e.z};
+      run += e.x + e.y + e.z + e.w;
+      if (lo + 4u * i < n) p4[(lo >> 2) + i] = o;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t all = s_carry;
+    a.counters->n_lines = all;
+    a.counters->n_alleles = 0;
+    a.counters->n_errs = 0;
+    a.counters->n_tasks = 0;
+    a.counters->lines_seen = all;
+    a.counters->cmap_maps = 0;
+    a.counters->pad[0] = a.counters->pad[1] = 0;
+    a.counters->n_finish = 0;
+    a.line_off[0] = 0u;
+  }
 }
 
 __global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(BVCF_S2_WAVES_EU, BVCF_S2_WAVES_EU))) void k_sites2(KernelArgs a, uint32_t n_tiles, uint32_t n_chunks) {

@@ -22,9 +22,11 @@ def bv():
     return b
 
 
-@pytest.fixture(autouse=True, params=["k_sites2", "k_sites1", "k_sites"])
+@pytest.fixture(autouse=True, params=["k_sites2", "k_sites2-chunk-census", "k_sites1", "k_sites"])
 def kernel(request, monkeypatch):
-    monkeypatch.setenv("BVCF_SITES", {"k_sites2": "2", "k_sites1": "3", "k_sites": "1"}[request.param])
+    """k_sites2 behind its census per tile (k_count_tiles, the default) and behind the per-chunk census of the other chains"""
+    monkeypatch.setenv("BVCF_SITES", {"k_sites2": "2", "k_sites2-chunk-census": "2", "k_sites1": "3", "k_sites": "1"}[request.param])
+    monkeypatch.setenv("BVCF_S2_CENSUS", "chunk" if request.param == "k_sites2-chunk-census" else "tile")
     return request.param
 
 
