@@ -902,6 +902,10 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
     const int w = atoi(e);
     if (w >= 1 && w <= 8) per_cu = std::min(per_cu, w);
   }
+  if (const char *e = getenv("BVCF_S2_WGS")) {  // experiment: workgroups per CU
+    const int w = atoi(e);
+    if (w >= 1 && w <= 4) per_cu = std::min(per_cu, w);
+  }
   c->sites1_grid = c->n_cu * per_cu;
   // the streaming kernel gives every wave its own range of class-map slots (two of them slack): room for that
   if (!p->cmap_bytes) {
