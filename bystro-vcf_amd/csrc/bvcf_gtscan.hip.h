@@ -344,15 +344,24 @@ __device__ __forceinline__ uint32_t highest_allele(const Alleles4 &g, uint32_t t
   }
   return kmax;
 }
-// do the carriers (and missing samples) of each of ALT #2..#kmax fit a class list?
-__device__ __forceinline__ bool further_fit(const Alleles4 &g, uint32_t kmax) {
-#pragma nounroll
-  for (uint32_t k = 2; k <= kmax; k++) {
-    uint32_t lo_k, hi_k;
-    classes4(g, k * 0x01010101u, &lo_k, &hi_k);
-    if (__popcll(__ballot(class_byte(lo_k, hi_k) != 0)) > (int)BVCF_CMAP_SPARSE_MAX) return false;
+// A line whose ALT #1 became a dense map hands its further alleles on as a RAW LIST: the (up to kRawMax) entries that
+// can tell who carries them -- all non-reference lanes of a line of 16..63 of them, the lanes with a digit >= 2 or a dot
+// of a line that went dense during the scan -- saved in the class-map slots behind the line's own.  k_head gives every
+// further ALT index of such a line a k_gt task that points here, and k_gt classifies the entries (1.3 KB) instead of
+// reading the line (10 KB) again (main.go:549-556 rescans per allele).  k_stream itself only stores the entries: anything
+// more at the end of a line costs the scan of every line registers (class lists and maps built here: +1.4 % on biallelic
+// files).
+//   area: +0 n, +16 the entries' map byte indices (4 B each), +272 their four field words (16 B each)
+constexpr uint32_t kRawEnc = 7u << 1;  // low bits of the line's class-map offset: "raw list in the next slots"
+constexpr uint32_t kRawAreaBytes = 16u + 4u * (kRawMax + 1u) + 16u * kRawMax;
+constexpr uint32_t kRawTask = 1u;      // GtTask.pad[0]: s_begin is the raw area's offset in the class-map arena
+__device__ __forceinline__ void raw_save(uint8_t *area, uint32_t n, const u32x4 &e, uint32_t idx) {
+  const uint32_t lane = (uint32_t)lane_id();
+  if (lane == 0) __builtin_nontemporal_store(n, reinterpret_cast<uint32_t *>(area));
+  if (lane < n) {
+    __builtin_nontemporal_store(idx, reinterpret_cast<uint32_t *>(area + 16u) + lane);
+    __builtin_nontemporal_store(e, reinterpret_cast<u32x4 *>(area + 16u + 4u * (kRawMax + 1u)) + lane);
   }
-  return true;
 }
 // the class lists of ALT #2..#kmax from the entries the lanes hold (idx = the entry's map byte): ALT #k's at
 // lists + 64 * (k - 1)
@@ -371,11 +380,10 @@ __device__ __forceinline__ void write_further_lists(const Alleles4 &g, uint32_t 
 }
 
 // End of a line that went dense with a raw list at hand: the list holds the n (1..kRawMax) lanes that saw anything but
-// 0 and 1 (fast_chunk, list_to_stage), in scan order.  When every further allele's carriers fit a class list, the lists
-// go to the next slot (cmap_extra; may be null: no spare slot) and the return value is finish_list's "dense map of
-// ALT #1, bits 1-3 = kmax" form; 1 << 1 when the entries are dots only; 0 leaves the further alleles to k_gt.
-__device__ __forceinline__ uint32_t finish_dense(const RawList *sp, uint32_t n, uint32_t stride, uint8_t *cmap_extra,
-                                                 bool *used_extra) {
+// 0 and 1 (fast_chunk, list_to_stage), in scan order.  Returns 1 << 1 when the entries are dots only (nobody carries a
+// further allele), kRawEnc when they were saved for k_gt (raw_area: the slots behind the line's own, null when the
+// wave has none to spare), 0 otherwise (k_gt reads the line).
+__device__ __forceinline__ uint32_t finish_dense(const RawList *sp, uint32_t n, uint8_t *raw_area) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   u32x4 e = {0u, 0u, 0u, 0u};
@@ -385,12 +393,10 @@ __device__ __forceinline__ uint32_t finish_dense(const RawList *sp, uint32_t n, 
     idx = sp->idx[lane_id()];
   }
   const Alleles4 g = gather4(e.x, e.y, e.z, e.w);
-  const uint32_t kmax = highest_allele(g, e.x | e.y | e.z | e.w);
-  if (kmax == 1u) return 1u << 1;
-  if (kmax > 7u || !cmap_extra || 64u * (kmax - 1u) > stride || !further_fit(g, kmax)) return 0u;
-  write_further_lists(g, idx, kmax, cmap_extra - 64u);  // (ALT #2's list at the start of the extra slot)
-  *used_extra = true;
-  return kmax << 1;
+  if (highest_allele(g, e.x | e.y | e.z | e.w) == 1u) return 1u << 1;
+  if (!raw_area) return 0u;
+  raw_save(raw_area, n, e, idx);
+  return kRawEnc;
 }
 
 // End of a line that stayed in list mode (n = acc.n_sp <= kRawMax entries): lane i classifies entry i.  Returns what
@@ -398,17 +404,15 @@ __device__ __forceinline__ uint32_t finish_dense(const RawList *sp, uint32_t n, 
 //   bit 0 = 1, bits 1-3 = kmax - 1   at most BVCF_CMAP_SPARSE_MAX entries: the class list of ALT #1 is at cmap and --
 //                                    when the entries carry allele digits 2..kmax -- the lists of ALT #2..#kmax at
 //                                    cmap + 64 * (k - 1); no sample carries a higher allele
-//   bit 0 = 0, bits 1-3 = kmax       more entries than a list holds: cmap is the dense map of ALT #1.  kmax (1..7) is the
-//                                    highest allele digit a sample carries; for kmax >= 2 the class lists of ALT
-//                                    #2..#kmax (each within BVCF_CMAP_SPARSE_MAX entries) are in the NEXT slot, at
-//                                    cmap_extra + 64 * (k - 2), and *used_extra is set
-//   0                                a dense map of ALT #1 and nothing known about further alleles (k_gt scans them):
-//                                    a digit above max_k / 7, a further allele with too many carriers, no spare slot
+//   1 << 1                           more entries than a list holds: cmap is the dense map of ALT #1, and no sample carries
+//                                    a further allele
+//   kRawEnc                          ... some do: the entries were saved behind the line's slot (raw_save) for k_gt
+//   0                                a dense map of ALT #1 and nothing known about further alleles (k_gt reads the line):
+//                                    no spare slots
 // Either way a multiallelic line whose non-reference samples fit the raw list is read once (the reference rescans the
 // line once per allele, main.go:549-556).
 __device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc, uint8_t *cmap, uint32_t max_k,
-                                                uint8_t *stage, uint32_t n_chunks, uint32_t stride, uint8_t *cmap_extra,
-                                                bool *used_extra) {
+                                                uint8_t *stage, uint32_t n_chunks, uint32_t stride, uint8_t *raw_area) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int lane = lane_id();
@@ -429,33 +433,26 @@ __device__ __forceinline__ uint32_t finish_list(const RawList *sp, FastAcc &acc,
   const uint32_t byte1 = class_byte(LO, HI);
   const uint32_t kmax = highest_allele(g, e.x | e.y | e.z | e.w);
   const bool sparse1 = n <= BVCF_CMAP_SPARSE_MAX && kmax <= max_k;
-  uint32_t enc;
-  uint8_t *lists = cmap;  // where the list of ALT #k goes: lists + 64 * (k - 1)
-  if (sparse1) {
-    enc = 1u | ((kmax - 1u) << 1);
-  } else {
+  if (!sparse1) {
     // a dense map of ALT #1 after all
     zero_stage(stage, n_chunks);
     if ((uint32_t)lane < n) stage[idx % kStageBytes] = (uint8_t)byte1;
     flush_stage(stage, cmap, 0u, n_chunks * 64u, stride);
     acc.n_sp = bcast0(kDenseMode);
     if (kmax == 1u) return 1u << 1;  // nobody carries a further allele
-    // every further allele's carriers must fit a list (else k_gt scans them).  Tried instead: dense maps of ALT #2..#4
-    // grown beside ALT #1's in the stage during the scan -- no rescans at all, but k_stream, which is bound by
-    // instruction issue, took 23 % longer on configs[3] (and 1-5 % on biallelic files), more than k_gt's rescans cost
-    if (kmax > 7u || !cmap_extra || 64u * (kmax - 1u) > stride || !further_fit(g, kmax)) return 0u;
-    enc = kmax << 1;
-    lists = cmap_extra - 64u;  // (ALT #2's list at the start of the extra slot)
-    *used_extra = true;
+    // (Tried: dense maps of ALT #2..#4 grown beside ALT #1's in the stage during the scan -- no rescans at all, but
+    // k_stream, which is bound by instruction issue, took 23 % longer on configs[3] and 1-5 % on biallelic files, more
+    // than k_gt's rescans cost; class lists and maps of the further alleles built here from the entries: +1.4 %.)
+    if (!raw_area) return 0u;
+    raw_save(raw_area, n, e, idx);
+    return kRawEnc;
   }
-  write_further_lists(g, idx, kmax, lists);
-  if (sparse1) {
-    // the list of ALT #1: count, then the entries (an entry may carry a zero byte: a lane whose fields only hold
-    // other alleles)
-    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((idx << 8) | byte1), 0x138, 0xF, 0xF, false);  // wave_shr:1
-    if ((uint32_t)lane <= n) __builtin_nontemporal_store(lane == 0 ? n : prev, reinterpret_cast<uint32_t *>(cmap) + lane);
-  }
-  return enc;
+  write_further_lists(g, idx, kmax, cmap);  // (the list of ALT #k at cmap + 64 * (k - 1))
+  // the list of ALT #1: count, then the entries (an entry may carry a zero byte: a lane whose fields only hold other
+  // alleles)
+  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((idx << 8) | byte1), 0x138, 0xF, 0xF, false);  // wave_shr:1
+  if ((uint32_t)lane <= n) __builtin_nontemporal_store(lane == 0 ? n : prev, reinterpret_cast<uint32_t *>(cmap) + lane);
+  return 1u | ((kmax - 1u) << 1);
 }
 
 // check_term: also require the byte after the last sample to be the line terminator (the caller
@@ -689,7 +686,35 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
     uint32_t n_fields;
     // regular region: 4 bytes per sample, every dword of a lane is one "x|y<TAB>" field
     bool regular = false;
-    if (a.wide && t.cend + 1u - t.s_begin == 4u * ns && a.results[ti].pad == 0) {
+    if (t.pad[0] == kRawTask) {
+      // a further allele of a line k_stream scanned: its carriers are among the entries saved with the line (raw_save)
+      const uint8_t *area = a.cmap + t.s_begin;
+      const uint32_t n = min(*reinterpret_cast<const uint32_t *>(area), kRawMax);
+      u32x4 e = {0u, 0u, 0u, 0u};
+      uint32_t idx = 0;
+      if ((uint32_t)lane < n) {
+        idx = reinterpret_cast<const uint32_t *>(area + 16u)[lane];
+        e = reinterpret_cast<const u32x4 *>(area + 16u + 4u * (kRawMax + 1u))[lane];
+      }
+      const Alleles4 g = gather4(e.x, e.y, e.z, e.w);
+      uint32_t LO, HI;
+      classes4(g, t.allele <= 9u ? t.allele * 0x01010101u : 0x7F7F7F7Fu, &LO, &HI);  // (the fast scan's fields hold one digit)
+      wave_sum3(__popc(LO & ~HI), __popc(HI & ~LO), __popc(LO & HI), ns, &st.n_het, &st.n_hom, &st.n_miss);
+      st.ac = st.n_het + 2u * st.n_hom;
+      st.an = 2u * (ns - st.n_miss);
+      if (cm) {
+        const uint32_t n_chunks = (ns * 4u + kChunk - 1u) / kChunk;
+        const uint32_t byte_k = class_byte(LO, HI);
+        for (uint32_t c0 = 0; c0 < n_chunks; c0 += kStageChunks) {  // (a window of the stage at a time: 16 384 samples)
+          const uint32_t nc = min(n_chunks - c0, kStageChunks);
+          zero_stage(stage, nc);
+          if (byte_k && idx / kStageBytes == c0 / kStageChunks) stage[idx % kStageBytes] = (uint8_t)byte_k;
+          flush_stage(stage, cm, c0, nc * 64u, a.cmap_stride);
+        }
+      }
+      n_fields = ns;
+      regular = true;
+    } else if (a.wide && t.cend + 1u - t.s_begin == 4u * ns && a.results[ti].pad == 0) {
       // k_gt_wide scanned the region window by window and every window was regular: add up
       const GtResult part = a.results[ti];
       st.n_het = part.n_het;

@@ -92,7 +92,7 @@ constexpr uint32_t kNoTask = 0xFFFFFFFFu;
 // Write genotype-scan task `ti` (allele == 0 marks a slot without a scan).  Task i < n_lines is
 // "line i, ALT #1"; tasks past n_lines are the further ALT indices of multiallelic lines.
 __device__ inline void put_task(const KernelArgs &a, uint32_t ti, uint32_t line, uint32_t allele, uint32_t s_begin,
-                                uint32_t cend, uint32_t cmap_off) {
+                                uint32_t cend, uint32_t cmap_off, uint32_t kind = 0u) {
   if (ti < a.max_tasks) {
     GtTask t;
     t.line = line;
@@ -100,7 +100,8 @@ __device__ inline void put_task(const KernelArgs &a, uint32_t ti, uint32_t line,
     t.s_begin = s_begin;
     t.cend = cend;
     t.cmap_off = cmap_off;
-    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    t.pad[0] = kind;  // (kRawTask: s_begin is the offset of the line's raw list in the class-map arena)
+    t.pad[1] = t.pad[2] = 0;
     a.tasks[ti] = t;
     // (wide lines: the longest sample region bounds the windows per task of the split scans)
     if (a.wide && allele != 0 && cend >= s_begin) atomicMax(&a.counters->pad[1], cend - s_begin);
@@ -482,12 +483,13 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
             // the class list of every further ALT index they carry (finish_list), so the line is not read again
             // (the reference rescans it once per allele, main.go:549-556).  The counts come from the list.
             bool resolved = false;
-            if (a.fused && !deferred && cm0 != BVCF_NO_CMAP && (cm0 & 15u) && task < a.max_tasks) {
+            const bool raw = a.fused && !deferred && cm0 != BVCF_NO_CMAP && (cm0 & 15u) == kRawEnc;
+            if (a.fused && !deferred && cm0 != BVCF_NO_CMAP && (cm0 & 15u) && !raw && task < a.max_tasks) {
               // bit 0: ALT #1 is a class list and the lists of ALT #2..#kmax follow it in the slot (kmax - 1 in bits 1-3).
-              // Otherwise ALT #1 is a dense map and bits 1-3 = kmax, the highest allele a sample carries (finish_list,
-              // k_stream): the class lists of ALT #2..#kmax are in the next slot
+              // Otherwise ALT #1 is a dense map and bits 1-3 = 1: no sample carries a further allele (finish_list,
+              // finish_dense; kRawEnc: some do, and k_gt settles them from the entries saved behind the slot)
               const bool in_slot = (cm0 & 1u) != 0;
-              const uint32_t kmax = ((cm0 >> 1) & 7u) + (in_slot ? 1u : 0u);
+              const uint32_t kmax = in_slot ? ((cm0 >> 1) & 7u) + 1u : 1u;
               const GtResult first = g0;
               r.ac = 0;
               r.an = first.an;
@@ -497,7 +499,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
               r.regular = 1;
               r.pad = 0;
               if (k + 1u <= kmax) {
-                cm_off = ((cm0 & ~15u) + (in_slot ? 64u * k : a.cmap_stride + 64u * (k - 1u))) | 1u;
+                cm_off = ((cm0 & ~15u) + 64u * k) | 1u;
                 const uint32_t *list = reinterpret_cast<const uint32_t *>(a.cmap + (cm_off & ~15u));
                 const uint32_t n = min(list[0], (uint32_t)BVCF_CMAP_SPARSE_MAX);
 #pragma nounroll
@@ -517,6 +519,12 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
                 put_task(a, task, line, 0, cend, cend, BVCF_NO_CMAP);  // nothing to scan
                 gr = &r;
               }
+            }
+            if (raw) {
+              // k_gt classifies the line's saved entries for this allele instead of reading the line again
+              resolved = true;
+              cm_off = cmap_of(a, map_base + tasks_used, maps);
+              put_task(a, task, line, k + 1, (cm0 & ~15u) + a.cmap_stride, cend, cm_off, kRawTask);
             }
             if (!resolved) {
               cm_off = cmap_of(a, map_base + tasks_used, maps);

@@ -352,30 +352,29 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
             va[g] = chunk_at(s_next, g);
           }
           STAMP(3);
-          // a line that ends in list mode: its entries classified now, for ALT #1 and every further ALT index; a line that
-          // went dense on the way kept listing the lanes that saw anything but 0 and 1: the further ALT indices' class
-          // lists come from those (finish_dense).  A second slot (for the lists of the further alleles of a line whose
-          // ALT #1 became a map) only while the wave's range still covers one slot for every line that may follow in its
-          // run (a regular line is at least 4 ns + 8 bytes long).
+          // a line that ends in list mode: its entries classified now, for ALT #1 and -- while ALT #1's list fits -- every
+          // further ALT index; a line whose ALT #1 became a map (at its end, or on the way: it kept listing the lanes that
+          // saw anything but 0 and 1) leaves its entries behind its slot for k_gt (a regular line is at least 4 ns + 8
+          // bytes long: that bounds the lines that may follow in the run).
           uint32_t enc = 0, n_slots = 1;
-          auto spare_slot = [&]() -> bool {
-            return cm_next + 2u <= cm_end && cm_end - (cm_next + 2u) >= (r1 - min(r1, peA)) / (4u * ns + 8u) + 2u &&
-                   cmap_of(a, cm_next + 1u, true) != BVCF_NO_CMAP;
+          // the slots behind the line's own for its raw list (raw_save), while the range still covers one slot for every
+          // line that may follow in the run and the arena covers them
+          const uint32_t raw_slots = (kRawAreaBytes + a.cmap_stride - 1u) / a.cmap_stride;
+          auto raw_area = [&]() -> uint8_t * {
+            const uint32_t reserve = (r1 - min(r1, peA)) / (4u * ns + 8u) + 2u;
+            if (cm_next + 1u + raw_slots + reserve > cm_end || cmap_of(a, cm_next + raw_slots, true) == BVCF_NO_CMAP) return nullptr;
+            return cm + a.cmap_stride;
           };
           if (sparse_ok && acc.n_sp < kDenseMode) {
-            const bool spare = acc.n_sp > BVCF_CMAP_SPARSE_MAX && spare_slot();
-            bool two = false;
             enc = finish_list(sparse, acc, cm, min(kListAlleles, a.cmap_stride / (4u * kSparseWords)), stage, nc, a.cmap_stride,
-                              spare ? cm + a.cmap_stride : nullptr, &two);
-            if (two) n_slots = 2;
+                              acc.n_sp > BVCF_CMAP_SPARSE_MAX ? raw_area() : nullptr);
           } else if (sparse_ok && acc.n_oth == 0u) {
             enc = 1u << 1;
           } else if (sparse_ok && acc.n_oth < kDenseMode) {
-            // the lanes that saw a digit >= 2 or a dot were listed on the way: the further alleles' class lists from them
-            bool two = false;
-            enc = finish_dense(sparse, acc.n_oth, a.cmap_stride, spare_slot() ? cm + a.cmap_stride : nullptr, &two);
-            if (two) n_slots = 2;
+            // the lanes that saw a digit >= 2 or a dot were listed on the way: k_gt settles the further alleles from them
+            enc = finish_dense(sparse, acc.n_oth, raw_area());
           }
+          if (enc == kRawEnc) n_slots += raw_slots;
           if (__any(acc.bad != 0)) {
             // A is not regular after all: B was predicted from a wrong line end.  Leave the
             // pipeline (the loads in flight are simply dropped) and take A the slow way.

@@ -171,16 +171,16 @@ def _dense_first_rows(seed, ns, n_lines, sep="|"):
 @pytest.mark.parametrize("seed,ns", [(31, 2504), (32, 2504), (33, 1030), (34, 513), (35, 2560), (36, 300)])
 def test_further_alleles_of_dense_lines(bv, seed, ns):
     """a line whose ALT #1 outgrows the raw list keeps listing the lanes that hold anything but 0 and 1; the further
-    alleles' class lists come from those (finish_dense) instead of a rescan per allele (main.go:549-556)"""
+    alleles are settled by k_gt from those (finish_dense, raw_save) instead of a rescan per allele (main.go:549-556)"""
     vcf = (vcfgen.header(ns) + "\n".join(_dense_first_rows(seed, ns, 240, "|" if seed % 2 else "/")) + "\n").encode()
     out = both(bv, vcf, {"allow": "", "keepInfo": True})
     assert out.count(b"MULTIALLELIC") > 400
     both(bv, vcf, {"allow": "", "keepId": True}, max_batch_bytes=1 << 20)
 
 
-def test_dense_lines_use_lists_for_further_alleles(bv, bvcf_path):
-    """streaming path, 2 504 samples: ALT #2.. of a line whose ALT #1 is a dense map come back as class lists (flag
-    BVCF_ALLELE_CMAP_SPARSE) with the census path's counts and classes"""
+def test_dense_lines_hand_their_entries_to_k_gt(bv, bvcf_path):
+    """streaming path, 2 504 samples: ALT #2.. of a line whose ALT #1 is a dense map are settled by k_gt from the entries
+    k_stream saved with the line (raw_save) -- the census path's counts and classes"""
     if bvcf_path != "streaming":
         pytest.skip("streaming path only")
     ns = 2504
@@ -217,6 +217,37 @@ def test_dense_lines_use_lists_for_further_alleles(bv, bvcf_path):
                 if int(y["alt_idx"]) > 0:
                     n_further += 1
                     n_lists += (int(y["flags"]) & 2) != 0
-    # (an allele whose carriers -- its own and the other alleles' partners -- sit in more than 15 four-sample groups has
-    # no list and is scanned by k_gt, as is a line the wave had no spare slot for)
-    assert n_further > 40 and n_lists >= 0.8 * n_further, (n_lists, n_further)
+    assert n_further > 40 and n_lists == 0, (n_lists, n_further)   # (maps, not lists: k_gt writes them)
+
+
+def test_dense_lines_agree_between_paths(bv, bvcf_path):
+    """every shape of _dense_first_rows (further alleles with a few carriers, with more than a class list holds, with
+    more lanes than the raw list holds, with missing genotypes), record by record against the census path, where k_gt
+    scans every allele from the text"""
+    if bvcf_path != "streaming":
+        pytest.skip("compares the two paths itself")
+    ns = 2504
+    dense = _dense_first_rows(43, ns, 96)
+    plain = [r for r in _rows(44, ns, 700) if "NA=1\t" in r][:2 * len(dense)]
+    rows = []
+    for i, r in enumerate(dense):
+        rows += plain[2 * i:2 * i + 2] + [r]
+    body = ("\n".join(rows) + "\n").encode()
+    res = {}
+    for path in (1, 2):
+        ctx = bv.Ctx(9 + ns, allow="", path=path)
+        res[path] = ctx.process(body)
+        ctx.close()
+    a, b = res[1], res[2]
+    n_cmp = n_dense_further = 0
+    for i in range(len(rows)):
+        ra, rb = a.records(i), b.records(i)
+        assert len(ra) == len(rb)
+        for x, y in zip(ra, rb):
+            for f in ("alt_idx", "ac", "an", "n_het", "n_hom", "n_miss"):
+                assert x[f] == y[f], (i, f, int(x[f]), int(y[f]))
+            if x["ac"] > 0:
+                assert (a.classes(x) == b.classes(y)).all(), (i, int(x["alt_idx"]))
+                n_cmp += 1
+                n_dense_further += int(y["alt_idx"]) > 0 and not int(y["flags"]) & 2
+    assert n_cmp > 250 and n_dense_further > 10
