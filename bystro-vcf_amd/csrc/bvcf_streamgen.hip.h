@@ -398,8 +398,8 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
     // ---- fields whose separator / end byte differ from R's, or whose allele bytes are not '0' ^ [0, 31]
     // (a chrX-like file: its haploid reference calls are settled here, four at a time)
     if (hapref) {
-      const bool h0 = S0 && ((u0 ^ kHapRef) & 0xFFFFu) == 0u, h1 = S1 && ((u1 ^ kHapRef) & 0xFFFFu) == 0u;
-      const bool h2 = S2 && ((u2 ^ kHapRef) & 0xFFFFu) == 0u, h3 = S3 && ((u3 ^ kHapRef) & 0xFFFFu) == 0u;
+      const uint32_t hx = (kHapRef ^ R) & 0xFFFFu;  // (x = 0, no start in the dword, cannot match: see the packed-flag tier)
+      const bool h0 = (x0 & 0xFFFFu) == hx, h1 = (x1 & 0xFFFFu) == hx, h2 = (x2 & 0xFFFFu) == hx, h3 = (x3 & 0xFFFFu) == hx;
       hap += (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
       x0 = h0 ? 0u : x0;
       x1 = h1 ? 0u : x1;
@@ -557,10 +557,13 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
       const uint32_t two_starts = (S0 & (S0 - 1u)) | (S1 & (S1 - 1u)) | (S2 & (S2 - 1u)) | (S3 & (S3 - 1u));
       uint32_t hq = 0;
       if (hapref && hap_ok) {
-        // haploid reference calls count as reference here (a dword with two field starts is not looked at twice: exact handler)
-        const bool h0 = S0 && ((u0 ^ kHapRef) & 0xFFFFu) == 0u, h1 = S1 && ((u1 ^ kHapRef) & 0xFFFFu) == 0u;
-        const bool h2 = S2 && ((u2 ^ kHapRef) & 0xFFFFu) == 0u, h3 = S3 && ((u3 ^ kHapRef) & 0xFFFFu) == 0u;
-        mis = ((S0 && !h0) ? u0 ^ R : 0u) | ((S1 && !h1) ? u1 ^ R : 0u) | ((S2 && !h2) ? u2 ^ R : 0u) | ((S3 && !h3) ? u3 ^ R : 0u) | two_starts;
+        // haploid reference calls count as reference here (a dword with two field starts is not looked at twice: exact
+        // handler).  "0:" against R = "0<sep>0:" differs in one known pattern of the low half (byte 0 equal, byte 1 =
+        // ':' ^ sep, never zero): one xor serves both tests, and a dword without a start (x = 0) cannot match
+        const uint32_t hx = (kHapRef ^ R) & 0xFFFFu;
+        const uint32_t y0 = S0 ? u0 ^ R : 0u, y1 = S1 ? u1 ^ R : 0u, y2 = S2 ? u2 ^ R : 0u, y3 = S3 ? u3 ^ R : 0u;
+        const bool h0 = (y0 & 0xFFFFu) == hx, h1 = (y1 & 0xFFFFu) == hx, h2 = (y2 & 0xFFFFu) == hx, h3 = (y3 & 0xFFFFu) == hx;
+        mis = (h0 ? 0u : y0) | (h1 ? 0u : y1) | (h2 ? 0u : y2) | (h3 ? 0u : y3) | two_starts;
         hq = (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
       }
       if (!__any((mis | hard) != 0)) {
