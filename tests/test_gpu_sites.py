@@ -164,3 +164,33 @@ def test_sites_bench_shape_runs_of_many_windows(bv):
         assert (new.lines[f] == old.lines[f]).all(), f
     for f in ("pos", "line", "alt_idx", "alt_len", "ref", "alt_base", "kind", "site_type", "trtv", "flags"):
         assert (new.alleles[:300_000][f] == old.alleles[:300_000][f]).all(), f
+
+
+def test_sites_block_of_many_scan_steps(bv, kernel):
+    """a sites-only block of 1.9 M rows = 270 MB: 37 k tiles, i.e. more than k_scan_flat's one step of 32 768 values (the
+    carry between steps), line numbers past 2^20 -- against the census chain with k_head on the same block"""
+    if kernel not in ("k_sites2", "k_sites2-chunk-census"):
+        pytest.skip("k_sites2 behind its two censuses")
+    import os
+    import benchgen as bg
+    cfg = bg.make_cfg("c2")
+    n = 1_900_000
+    body = bg.rows_host(cfg, 5_000_000, n)
+    assert len(body) > 32_768 * 7168
+    n_hdr = bg.n_header_fields(cfg)
+    ctx = bv.Ctx(n_hdr, max_batch_bytes=len(body), max_lines=n + 16)
+    new = ctx.process(body)
+    ctx.close()
+    mine = os.environ["BVCF_SITES"]
+    os.environ["BVCF_SITES"] = "0"
+    try:
+        ctx = bv.Ctx(n_hdr, max_batch_bytes=len(body), max_lines=n + 16)
+        old = ctx.process(body)
+        ctx.close()
+    finally:
+        os.environ["BVCF_SITES"] = mine
+    assert len(new.lines) == len(old.lines) == n
+    for f in ("off", "len", "fend", "n_rec", "n_fields", "status", "site_type"):
+        assert (new.lines[f] == old.lines[f]).all(), f
+    for f in ("pos", "line", "alt_idx", "alt_len", "ref", "alt_base", "kind", "site_type", "trtv", "flags"):
+        assert (new.alleles[:n][f] == old.alleles[:n][f]).all(), f
