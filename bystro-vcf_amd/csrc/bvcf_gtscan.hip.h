@@ -674,13 +674,39 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
   const uint32_t ns = a.n_samples;
   // streaming path: ALT #1 of every regular line is already scanned; only the slots past n_lines
   // (further ALT indices, and lines k_stream merely delimited) hold tasks
-  uint32_t ti = (a.fused ? n_lines : 0u) + wave_in_grid();
-  GtTask nxt = GtTask{};
-  if (ti < n_tasks) nxt = a.tasks[ti];
-  for (; ti < n_tasks; ti += stride) {
-    const GtTask t = nxt;
-    if (ti + stride < n_tasks) nxt = a.tasks[ti + stride];  // in flight while this task is scanned
-    if (t.allele == 0) continue;  // line rejected before getAlleles: nothing to scan
+  // The wave's tasks are first + k * stride.  It fetches 64 of them at a time, one per lane (k = k0 + lane), and walks
+  // only those with something to scan: on the streaming path most slots are placeholders -- further alleles k_head
+  // settled from class lists, allele 0 -- and taking them one load at a time, each a memory latency for nothing, was
+  // most of this kernel's time on configs[3].  The next 64 are in flight meanwhile.
+  const uint32_t first = (a.fused ? n_lines : 0u) + wave_in_grid();
+  static_assert(sizeof(GtTask) == 32, "fetched as two 16-byte words: line, allele, s_begin, cend | cmap_off, pad[3]");
+  auto fetch = [&](uint32_t k0, u32x4 &lo, u32x4 &hi) {
+    const unsigned long long tl = (unsigned long long)first + (unsigned long long)(k0 + (uint32_t)lane) * stride;
+    lo = hi = u32x4{0u, 0u, 0u, 0u};
+    if (tl < n_tasks) {
+      const u32x4 *p = reinterpret_cast<const u32x4 *>(&a.tasks[tl]);
+      lo = p[0];
+      hi = p[1];
+    }
+  };
+  u32x4 nlo, nhi;
+  fetch(0u, nlo, nhi);
+  for (uint32_t k0 = 0; (unsigned long long)first + (unsigned long long)k0 * stride < n_tasks; k0 += kWave) {
+   const u32x4 lo = nlo, hi = nhi;
+   fetch(k0 + kWave, nlo, nhi);
+   unsigned long long todo = __ballot(lo.y != 0u);  // (allele 0: rejected before getAlleles, or settled: nothing to scan)
+   while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    GtTask t;
+    t.line = lane_value(lo.x, src);
+    t.allele = lane_value(lo.y, src);
+    t.s_begin = lane_value(lo.z, src);
+    t.cend = lane_value(lo.w, src);
+    t.cmap_off = lane_value(hi.x, src);
+    t.pad[0] = lane_value(hi.y, src);
+    t.pad[1] = t.pad[2] = 0;
+    const uint32_t ti = first + (k0 + (uint32_t)src) * stride;
     uint8_t *cm = t.cmap_off != BVCF_NO_CMAP ? a.cmap + t.cmap_off : nullptr;
     GtStats st = {0, 0, 0, 0, 0};
     uint32_t n_fields;
@@ -754,6 +780,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
       r.pad = 0;
       a.results[ti] = r;
     }
+   }
   }
 }
 // ------------------------------------------------------------------ k_gt_wide: one wave per (task, window)
