@@ -715,12 +715,18 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
     if (t.pad[0] == kRawTask) {
       // a further allele of a line k_stream scanned: its carriers are among the entries saved with the line (raw_save)
       const uint8_t *area = a.cmap + t.s_begin;
-      const uint32_t n = min(*reinterpret_cast<const uint32_t *>(area), kRawMax);
+      // (all three loads at once -- the area is there for kRawMax entries whatever the count says -- and the count applied
+      // afterwards: one memory latency per task instead of two)
       u32x4 e = {0u, 0u, 0u, 0u};
       uint32_t idx = 0;
-      if ((uint32_t)lane < n) {
+      if ((uint32_t)lane < kRawMax) {
         idx = reinterpret_cast<const uint32_t *>(area + 16u)[lane];
         e = reinterpret_cast<const u32x4 *>(area + 16u + 4u * (kRawMax + 1u))[lane];
+      }
+      const uint32_t n = min(*reinterpret_cast<const uint32_t *>(area), kRawMax);
+      if ((uint32_t)lane >= n) {
+        e = u32x4{0u, 0u, 0u, 0u};
+        idx = 0;
       }
       const Alleles4 g = gather4(e.x, e.y, e.z, e.w);
       uint32_t LO, HI;
