@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""What is k_gt's time on configs[3] made of?  One block of the c4 row model with some of its knobs changed, through
+the chain one block at a time, under rocprofv3 (the kernel stats are the answer):
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -- python3 tools/kgt_probe.py p_multi=0 p_indel=1500"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import benchgen as bg  # noqa: E402
+import bystro_vcf_amd as bv  # noqa: E402
+
+over = dict(kv.split("=") for kv in sys.argv[1:])
+over = {k: int(v) for k, v in over.items()}
+rows = 262_144
+cfg = bg.make_cfg("c4", **over)
+t, nbytes = bg.rows_device(cfg, 0, rows, pad=bv.DEVICE_PAD)
+ns = cfg.n_samples
+stride = ((ns + 3) // 4 + 15) & ~15
+n_alt = rows * 4 + 1024
+ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=1, max_lines=rows + 16, max_alleles=n_alt,
+             cmap_bytes=min((n_alt + nbytes // (4 * ns + 8) + 16 * 8192) * stride + 4096, 0xFFFFFF00))
+chain, scan, counts = ctx.bench_device([t.data_ptr()], [nbytes], 12, slots=1)
+print(over, "chain ms", sum(chain) / len(chain), "counts", list(counts)[:8])
+ctx.close()
