@@ -21,7 +21,9 @@ for i in range(n_cases):
     rng = random.Random(seed0 + i)
     ns = rng.choice([0, 1, 3, 17, 63, 64, 65, 255, 256, 257, 300, 511, 512, 700, 1023, 1024, 1500, 2047, 2048, 2504,
                      2559, 2560, 2561, 3000, rng.randint(1, 3500)])
-    n_lines = rng.randint(20, 160 if ns > 1000 else 400)
+    if os.environ.get("SOAK_NS"):  # e.g. SOAK_NS=0: sites-only files only (k_sites2 and its census), many more lines
+        ns = int(os.environ["SOAK_NS"])
+    n_lines = rng.randint(20, 160 if ns > 1000 else 400) if ns else rng.randint(20, 6000)
     weird = rng.choice([0.0, 0.0, 0.001, 0.01, 0.05, 0.3])
     fmt_extra = rng.random() < 0.4
     eol = "\r\n" if rng.random() < float(os.environ.get("SOAK_CRLF", "0.1")) else "\n"
