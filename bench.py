@@ -24,9 +24,19 @@ Prints ONE JSON line (rank 0):
                 the timed region, where it shares the CUs with the previous block's tail kernels (longer than the
                 time per block: two launches overlap; informational).
   e2e           (rank 0, N == 1) the CLI end to end: `bystro-vcf --in <file in /dev/shm> > /dev/null` over
-                >= 1 M rows of the same stream (the first blocks of the resident set, copied back to the host), wall
-                and steady-state variants/s, the BVCF_TIMING stage split, and the md5 of its output against the
-                oracle CLI's on a prefix of the file.  PCIe-inclusive: never `value`.
+                configs[2]'s own 6.2 M rows (the rank's stream, written to /dev/shm once), every run kept with its
+                wall clock and its BVCF_TIMING stage split (`runs`; `cold` = the first exec of the CLI on the box,
+                `warm` = the best later run), the md5 of its output against the oracle CLI's on a prefix of the file,
+                and `full_output_check`: sha256 of the WHOLE output of one more CLI run against the sha256 of what
+                the oracle run of the cpu_baseline leg printed for the same file.  PCIe-inclusive: never `value`.
+  e2e_bgzf      the reference's published shape (README.md:10,49: `pigz -d -c in.vcf.gz | bystro-vcf`) without the
+                host decompressor: the same number of rows as a BGZF file (one block of the stream compressed at
+                bgzip's level 6 and its member stream repeated -- BGZF blocks are independent) -> `--in x.vcf.gz`,
+                inflated on the device; prefix md5 against the oracle; whole-output sha256 against the oracle's
+                rows for that block, repeated.
+  e2e_stdin     `cat file | bystro-vcf` through a real pipe, text and BGZF: the drop-in stdin surface.
+  e2e_c4        configs[3]'s rows (20 % multiallelic + 15 % indels) with --keepId --keepInfo through the CLI, the
+                whole output hashed against the oracle CLI's with the same flags.
   cpu_baseline  (rank 0, N == 1) the CPU oracle -- the C restatement of the reference algorithm, kind "port" -- over
                 the same file with all host cores and with 4 threads (the README's box has 4 cores).
 """
@@ -38,6 +48,7 @@ import os
 import re
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -75,14 +86,153 @@ def reduce_over_ranks(elapsed, n_variants, device, world):
     return float(t_el.item()), float(n_var.item())
 
 
+def _hash_stdout(cmd, stdin_path=None, algo="md5", env=None, timeout_s=900):
+    """(return code, hex digest of stdout, bytes of stdout, stderr text, wall seconds)"""
+    h = hashlib.new(algo)
+    n = 0
+    t0 = time.perf_counter()
+    with open(stdin_path or os.devnull, "rb") as f, tempfile.TemporaryFile() as errf:
+        p = subprocess.Popen(cmd, stdin=f, stdout=subprocess.PIPE, stderr=errf, env=env)
+        try:
+            for chunk in iter(lambda: p.stdout.read(1 << 24), b""):
+                h.update(chunk)
+                n += len(chunk)
+                if time.perf_counter() - t0 > timeout_s:
+                    p.kill()
+                    break
+            p.wait()
+        finally:
+            if p.poll() is None:
+                p.kill()
+        errf.seek(0, 2)
+        errf.seek(max(0, errf.tell() - 4096))
+        err = errf.read().decode(errors="replace")
+    return p.returncode, h.hexdigest(), n, err, time.perf_counter() - t0
+
+
 def _md5_stdout(cmd, stdin_path=None):
-    h = hashlib.md5()
-    with open(stdin_path or os.devnull, "rb") as f:
-        p = subprocess.Popen(cmd, stdin=f, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-        for chunk in iter(lambda: p.stdout.read(1 << 24), b""):
-            h.update(chunk)
-        p.wait()
-    return p.returncode, h.hexdigest()
+    rc, hx, _, _, _ = _hash_stdout(cmd, stdin_path)
+    return rc, hx
+
+
+def _stages_of(stderr_text):
+    for ln in reversed(stderr_text.splitlines()):
+        if ln.startswith("[bvcf timing-json] "):
+            return json.loads(ln[len("[bvcf timing-json] "):])
+    return None
+
+
+def _run_cli(args, cat_path=None, timeout_s=300):
+    """one timed run of the CLI with stdout -> /dev/null.  cat_path: `cat <path> | bystro-vcf` through a real pipe
+    (stdin is then the pipe's read end, as in the reference's `pigz -d -c in.vcf.gz | bystro-vcf`, README.md:10).
+    -> {"wall_s", "stages"} or {"error"}"""
+    env = dict(os.environ, BVCF_TIMING="json")
+    t0 = time.perf_counter()
+    cat = None
+    try:
+        with open(os.devnull, "wb") as out, tempfile.TemporaryFile() as errf:
+            if cat_path:
+                cat = subprocess.Popen(["cat", cat_path], stdout=subprocess.PIPE)
+                p = subprocess.Popen([CLI] + args, stdin=cat.stdout, stdout=out, stderr=errf, env=env)
+                cat.stdout.close()  # the CLI holds the read end now
+            else:
+                p = subprocess.Popen([CLI] + args, stdin=subprocess.DEVNULL, stdout=out, stderr=errf, env=env)
+            try:
+                p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+                return {"error": "the CLI did not finish within %d s" % timeout_s}
+            wall = time.perf_counter() - t0
+            errf.seek(0, 2)
+            errf.seek(max(0, errf.tell() - 16384))
+            err = errf.read().decode(errors="replace")
+    finally:
+        if cat is not None:
+            if cat.poll() is None:
+                cat.kill()
+            cat.wait()
+    if p.returncode != 0:
+        return {"error": "CLI rc %d: %s" % (p.returncode, err[-300:])}
+    return {"wall_s": wall, "stages": _stages_of(err)}
+
+
+def e2e_leg(what, args, rows, text_bytes, runs=2, cat_path=None, timeout_s=300, file_bytes=None):
+    """`runs` runs of the CLI, every one kept (wall clock around the process, BVCF_TIMING=json stage split).  A run that
+    does not come back within timeout_s is reported, not waited for: the bench line must not depend on this leg."""
+    out = {"input": what, "argv": " ".join((["cat", "FILE", "|"] if cat_path else []) + ["bystro-vcf"] + args),
+           "rows": rows, "text_bytes": text_bytes, "runs": []}
+    if file_bytes is not None:
+        out["file_bytes"] = file_bytes
+    for _ in range(runs):
+        r = _run_cli(args, cat_path, timeout_s)
+        if "error" in r:
+            out["error"] = r["error"]
+            break
+        st = r["stages"] or {}
+        r["variants_per_s"] = rows / r["wall_s"]
+        if st.get("steady_s"):
+            r["steady_variants_per_s"] = rows / st["steady_s"]
+        if st and st.get("lines_in") != rows:
+            out["error"] = "the CLI saw %s lines, the input has %d" % (st.get("lines_in"), rows)
+        out["runs"].append(r)
+    if not out["runs"]:
+        return out
+    best = min(out["runs"], key=lambda r: r["wall_s"])
+    out.update({"wall_s": best["wall_s"], "variants_per_s": rows / best["wall_s"], "variants_per_min": rows / best["wall_s"] * 60,
+                "text_GBps": text_bytes / best["wall_s"] / 1e9, "stages": best["stages"],
+                "meets_50M_variants_per_min": rows / best["wall_s"] * 60 >= 50e6})
+    st = best["stages"] or {}
+    if st.get("steady_s"):
+        # from the first block's submit to the last byte written: the run without process / HIP start-up and teardown
+        out["steady_variants_per_s"] = rows / st["steady_s"]
+        out["steady_variants_per_min"] = rows / st["steady_s"] * 60
+        out["steady_text_GBps"] = text_bytes / st["steady_s"] / 1e9
+    return out
+
+
+def cold_warm(leg):
+    """the first exec of the CLI on the box against the best later one, with where the difference went (every stage
+    whose time differs by more than 50 ms between the two runs)"""
+    rs = leg.get("runs") or []
+    if len(rs) < 2:
+        return None
+    cold, warm = rs[0], min(rs[1:], key=lambda r: r["wall_s"])
+    out = {"cold_wall_s": cold["wall_s"], "warm_wall_s": warm["wall_s"], "ratio": cold["wall_s"] / warm["wall_s"]}
+    cs, ws = cold.get("stages") or {}, warm.get("stages") or {}
+    diff = {}
+    for k, v in cs.items():
+        if isinstance(v, (int, float)) and isinstance(ws.get(k), (int, float)) and k.endswith("_s") or k in (
+                "major_faults", "minor_faults", "in_blocks", "vol_ctx_switches", "invol_ctx_switches"):
+            if isinstance(v, (int, float)) and isinstance(ws.get(k), (int, float)):
+                d = v - ws[k]
+                if (k.endswith("_s") and abs(d) > 0.05) or (not k.endswith("_s") and d):
+                    diff[k] = {"cold": v, "warm": ws[k]}
+    out["stages_that_differ"] = diff
+    out["outside_the_run_s"] = {"cold": cold["wall_s"] - cs.get("total_s", 0.0), "warm": warm["wall_s"] - ws.get("total_s", 0.0),
+                                "what": "wall clock around the process minus bvcf_run_fd's own total: exec, dynamic loading of "
+                                        "the HIP runtime's libraries, exit"}
+    return out
+
+
+def prefix_check(hip_args, hip_in, oracle_in, oracle_args, rows):
+    """parity on a prefix of the same stream: md5 of the CLI's stdout == md5 of the oracle CLI's"""
+    rc_g, m_g = _md5_stdout([CLI, "--in", hip_in] + hip_args)
+    rc_o, m_o = _md5_stdout([ORACLE, "--in", oracle_in, "--threads", str(min(usable_cpus(), 64))] + oracle_args)
+    return {"rows": rows, "hip": m_g, "oracle": m_o, "equal": rc_g == 0 and rc_o == 0 and m_g == m_o}
+
+
+def bgzf_of(data_mv, level=6, threads=16, block=0xFF00):
+    """BGZF member stream of a buffer (no EOF marker), bgzip's framing and level; zlib releases the GIL, so threads do"""
+    import bgzf
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(data_mv)
+    span = block * 64
+    def part(off):
+        return b"".join(bgzf.bgzf_block(bytes(data_mv[o:min(o + block, off + span, n)]), level)
+                        for o in range(off, min(off + span, n), block))
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        return b"".join(ex.map(part, range(0, n, span)))
 
 
 def write_e2e_file(header, blocks, sizes, want_rows, rows_per_block, make_block):
@@ -239,34 +389,194 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(path, rows, profile):
+def cpu_baseline(path, rows, profile, oracle_args=(), four=True):
     """oracle/bvcf_oracle (the CLI of the C restatement: N workers over 64-line batches, split-then-scan, per-allele
-    rescan) over the e2e file, output to /dev/null as in README.md:49: all the cores this process may use, and 4 threads"""
+    rescan) over the e2e file (mapped, not copied), as in README.md:49: all the cores this process may use -- that run's
+    output goes through sha256 for the whole-output check of the e2e legs; it is printed after the timed readVcf, so the
+    rate does not see the pipe -- and 4 threads with the output to /dev/null"""
     cores = usable_cpus()
 
-    def run(threads):
-        t0 = time.perf_counter()
-        with open(os.devnull, "wb") as out:
-            p = subprocess.run([ORACLE, "--in", path, "--threads", str(threads), "--timing"], stdout=out, stderr=subprocess.PIPE,
-                               timeout=900)
-        wall = time.perf_counter() - t0
-        m = re.search(r"\[oracle timing\] rows (\d+) threads (\d+) read ([\d.]+) process ([\d.]+) write ([\d.]+)", p.stderr.decode(errors="replace"))
-        assert p.returncode == 0 and m and int(m.group(1)) == rows, p.stderr[-300:]
+    def run(threads, hashed):
+        cmd = [ORACLE, "--in", path, "--threads", str(threads), "--timing"] + list(oracle_args)
+        if hashed:
+            rc, hx, n_out, err, wall = _hash_stdout(cmd, algo="sha256")
+        else:
+            t0 = time.perf_counter()
+            with open(os.devnull, "wb") as out:
+                p = subprocess.run(cmd, stdout=out, stderr=subprocess.PIPE, timeout=900)
+            wall, rc, err, hx, n_out = time.perf_counter() - t0, p.returncode, p.stderr.decode(errors="replace"), None, None
+        m = re.search(r"\[oracle timing\] rows (\d+) threads (\d+) read ([\d.]+) process ([\d.]+) write ([\d.]+)", err)
+        assert rc == 0 and m and int(m.group(1)) == rows, err[-300:]
         return {"threads": threads, "process_s": float(m.group(4)), "read_s": float(m.group(3)), "write_s": float(m.group(5)),
-                "wall_s": wall, "variants_per_s": rows / float(m.group(4))}
+                "wall_s": wall, "variants_per_s": rows / float(m.group(4)), "output_sha256": hx, "output_bytes": n_out}
 
-    full, four = run(cores), run(4)
-    return {
+    full = run(cores, True)
+    out = {
         "value": full["variants_per_s"], "unit": "variants/s", "cores": cores, "kind": "port",
-        "sample": "%d rows of the same synthetic %s stream (the e2e file), oracle/bvcf_oracle with %d worker threads over 64-line "
-                  "batches (the host shows %d hardware threads, the CPU quota of this process is %d cores), output to /dev/null; rate = "
-                  "rows / readVcf time (%.2f s), input already in memory (reading it took %.2f s)"
-                  % (rows, profile, cores, os.cpu_count() or 1, cores, full["process_s"], full["read_s"]),
-        "threads_4": {"value": four["variants_per_s"], "unit": "variants/s", "cores": 4, "process_s": four["process_s"],
-                      "wall_s": four["wall_s"]},
+        "sample": "%d rows of the same synthetic %s stream (the e2e file), oracle/bvcf_oracle%s with %d worker threads over 64-line "
+                  "batches (the host shows %d hardware threads, the CPU quota of this process is %d cores); rate = "
+                  "rows / readVcf time (%.2f s), input mapped into memory beforehand (%.2f s), output hashed afterwards"
+                  % (rows, profile, (" " + " ".join(oracle_args)) if oracle_args else "", cores, os.cpu_count() or 1, cores,
+                     full["process_s"], full["read_s"]),
         "all_cores": full,
         "published_reference": "README.md:44-52: 6.2 M variants in 2 m 45 s on a 4-core i3.2xlarge = 37.6 k variants/s (Go, pigz-bound)",
     }
+    if four:
+        f4 = run(4, False)
+        out["threads_4"] = {"value": f4["variants_per_s"], "unit": "variants/s", "cores": 4, "process_s": f4["process_s"],
+                            "wall_s": f4["wall_s"]}
+    return out
+
+
+def full_output_check(hip_args, oracle_run, what):
+    """one more (untimed) CLI run whose WHOLE output is hashed, against the hash of what the oracle printed for the same
+    file in the cpu_baseline leg"""
+    rc, hx, n_out, err, wall = _hash_stdout([CLI] + hip_args, algo="sha256")
+    return {"what": what, "hip_sha256": hx, "oracle_sha256": oracle_run["output_sha256"], "output_bytes": n_out,
+            "oracle_output_bytes": oracle_run["output_bytes"], "hip_rc": rc,
+            "equal": rc == 0 and hx == oracle_run["output_sha256"] and n_out == oracle_run["output_bytes"]}
+
+
+def host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, release_device):
+    """everything that runs the CLI (rank 0, N == 1).  The files live in /dev/shm and are removed in any case."""
+    import torch
+    ns = cfg.n_samples
+    dev = str(local_rank)
+    files = []
+
+    def tmp(name):
+        q = "%s.%s" % (files[0], name)
+        files.append(q)
+        return q
+
+    try:
+        hdr = bg.header(cfg)
+        first0 = rank_blocks(rank, args.blocks, args.rows)[0]
+        path, f_rows, f_bytes, where = write_e2e_file(
+            hdr, blocks, sizes, args.e2e_rows, args.rows,
+            lambda b: bg.rows_device(cfg, first0 + b * args.rows, args.rows, pad=bv.DEVICE_PAD))
+        files.append(path)
+        n_blk = f_rows // args.rows
+        if not args.no_e2e:
+            # prefix of the same stream for the md5 checks (rows [first, first + n) of block 0), as text and as BGZF; and
+            # block 0 alone as BGZF members, which the compressed file repeats
+            p_rows = min(args.rows, 65_536 if ns else 1_000_000)
+            pt, pn = bg.rows_device(cfg, first0, p_rows, pad=bv.DEVICE_PAD)
+            prefix, prefix_gz, block0, gz = tmp("prefix"), tmp("prefix.gz"), tmp("block0"), tmp("gz")
+            p_host = pt[:pn].cpu().numpy()
+            with open(prefix, "wb") as f:
+                f.write(hdr)
+                f.write(memoryview(p_host))
+            import bgzf as _bg
+            eof = _bg.bgzf_block(b"")
+            hdr_gz = bgzf_of(memoryview(hdr))
+            with open(prefix_gz, "wb") as f:
+                f.write(hdr_gz + bgzf_of(memoryview(p_host), threads=usable_cpus()) + eof)
+            del pt, p_host
+            t0 = time.perf_counter()
+            b0 = blocks[0][:sizes[0]].cpu().numpy()
+            with open(block0, "wb") as f:
+                f.write(hdr)
+                f.write(memoryview(b0))
+            members = bgzf_of(memoryview(b0), threads=usable_cpus())
+            del b0
+            with open(gz, "wb") as f:
+                f.write(hdr_gz)
+                for _ in range(n_blk):
+                    f.write(members)
+                f.write(eof)
+            gz_bytes, gz_text = os.path.getsize(gz), len(hdr) + n_blk * sizes[0]
+            t_gz = time.perf_counter() - t0
+            del members
+        # the device is the CLI's from here on: the resident blocks and the bench ctx go
+        release_device()
+        blocks.clear()
+        torch.cuda.empty_cache()
+
+        base = None
+        if not args.no_cpu_baseline:
+            base = line["cpu_baseline"] = cpu_baseline(path, f_rows, args.profile)
+        if not args.no_e2e:
+            src = "%d rows, %.2f GB of the same synthetic stream in %s" % (f_rows, f_bytes / 1e9, where)
+            e = e2e_leg(src + " -> bystro-vcf --in (HIP) -> /dev/null", ["--in", path, "--devices", dev], f_rows, f_bytes, runs=3)
+            e["devices"] = dev
+            e["cold_vs_warm"] = cold_warm(e)
+            e["md5_check"] = prefix_check(["--devices", dev], prefix, prefix, [], p_rows)
+            if base:
+                e["full_output_check"] = full_output_check(["--in", path, "--devices", dev], base["all_cores"],
+                                                           "sha256 of all %d rows' output, CLI vs the oracle run of cpu_baseline" % f_rows)
+            line["e2e"] = e
+
+            g = e2e_leg("%d rows as BGZF (level 6, %.3f GB for %.2f GB of text, made in %.1f s: block 0 of the stream compressed once, "
+                        "its member stream %d times) in %s -> bystro-vcf --in x.vcf.gz, inflated on the device -> /dev/null"
+                        % (f_rows, gz_bytes / 1e9, gz_text / 1e9, t_gz, n_blk, where),
+                        ["--in", gz, "--devices", dev], f_rows, gz_text, runs=3, file_bytes=gz_bytes)
+            g["md5_check"] = prefix_check(["--devices", dev], prefix_gz, prefix, [], p_rows)
+            # the whole output: the oracle's rows for header + block 0, n_blk times behind one header line
+            po = subprocess.run([ORACLE, "--in", block0, "--threads", str(usable_cpus())], stdout=subprocess.PIPE,
+                                stderr=subprocess.DEVNULL)
+            rc_o, ob = po.returncode, po.stdout
+            cut = ob.index(b"\n") + 1
+            h = hashlib.sha256(ob[:cut])
+            for _ in range(n_blk):
+                h.update(memoryview(ob)[cut:])
+            want_n = cut + n_blk * (len(ob) - cut)
+            rc, hx, n_out, _, _ = _hash_stdout([CLI, "--in", gz, "--devices", dev], algo="sha256")
+            g["full_output_check"] = {"what": "sha256 of all %d rows' output vs the oracle's rows for block 0, %d times" % (f_rows, n_blk),
+                                      "hip_sha256": hx, "oracle_sha256": h.hexdigest(), "output_bytes": n_out,
+                                      "equal": rc == 0 and rc_o == 0 and hx == h.hexdigest() and n_out == want_n}
+            del ob
+            line["e2e_bgzf"] = g
+
+            line["e2e_stdin"] = {
+                "text": e2e_leg("cat <the e2e file: " + src + "> | bystro-vcf (stdin is a pipe) -> /dev/null", ["--devices", dev],
+                                f_rows, f_bytes, runs=1, cat_path=path, timeout_s=240),
+                "bgzf": e2e_leg("cat <the BGZF file of e2e_bgzf> | bystro-vcf (stdin is a pipe) -> /dev/null", ["--devices", dev],
+                                f_rows, gz_text, runs=2, cat_path=gz, file_bytes=gz_bytes),
+                "note": "README.md:10,49 runs the reference as `pigz -d -c in.vcf.gz | bystro-vcf`; the BGZF pipe is that run "
+                        "without pigz (the device inflates), the text pipe is what a decompressor in front would have to deliver",
+            }
+            n_vis = torch.cuda.device_count()
+            if n_vis > 1:
+                # (not part of `value`, which is this rank's GPU alone) the same files dealt range by range to every visible
+                # device by the one CLI process
+                all_dev = ",".join(str(d) for d in range(n_vis))
+                line["e2e_all_devices"] = {
+                    "text": e2e_leg(src + " -> bystro-vcf --in --devices " + all_dev, ["--in", path, "--devices", all_dev],
+                                    f_rows, f_bytes, runs=2, timeout_s=180),
+                    "bgzf": e2e_leg("the BGZF file of e2e_bgzf -> bystro-vcf --in --devices " + all_dev, ["--in", gz, "--devices", all_dev],
+                                    f_rows, gz_text, runs=2, timeout_s=180, file_bytes=gz_bytes)}
+        for q in files:
+            if os.path.exists(q):
+                os.unlink(q)
+        del files[:]
+
+        # ---- configs[3] end to end: --keepId --keepInfo, whole output against the oracle
+        if not args.no_e2e and not args.no_cpu_baseline and args.profile == "c3" and args.e2e_c4_rows > 0:
+            cfg4 = bg.make_cfg("c4")
+            r4 = SHAPES["c4"][0]
+            n4 = max(1, -(-args.e2e_c4_rows // r4))
+            path4, rows4, bytes4, where4 = write_e2e_file(
+                bg.header(cfg4), [], [r4 * (4 * cfg4.n_samples + 400)], n4 * r4, r4,
+                lambda b: bg.rows_device(cfg4, b * r4, r4, pad=bv.DEVICE_PAD))
+            files.append(path4)
+            torch.cuda.empty_cache()
+            flags = ["--keepId", "--keepInfo"]
+            base4 = cpu_baseline(path4, rows4, "c4", oracle_args=flags, four=False)
+            c4 = e2e_leg("%d rows, %.2f GB of BASELINE configs[3]'s synthetic stream (20%% multiallelic + 15%% indels) in %s -> bystro-vcf "
+                         "--in --keepId --keepInfo -> /dev/null" % (rows4, bytes4 / 1e9, where4),
+                         ["--in", path4, "--devices", dev] + flags, rows4, bytes4, runs=2)
+            c4["full_output_check"] = full_output_check(["--in", path4, "--devices", dev] + flags, base4["all_cores"],
+                                                        "sha256 of all %d rows' output with --keepId --keepInfo, CLI vs oracle CLI" % rows4)
+            c4["cpu_baseline"] = {k: base4[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            line["e2e_c4"] = c4
+    except Exception as exc:  # the host legs inform; the measured line above stands without them
+        import traceback
+        line.setdefault("host_legs_error", (repr(exc) + " @ " + traceback.format_exc().splitlines()[-3].strip())[:500])
+    finally:
+        for q in files:
+            if q and os.path.exists(q):
+                os.unlink(q)
 
 
 def main():
@@ -284,6 +594,8 @@ def main():
     ap.add_argument("--e2e-rows", type=int, default=6_200_000,
                     help="rows of the end-to-end / cpu_baseline file (rounded up to whole blocks; BASELINE configs[2] is 6.2 M rows = "
                          "63 GB, written to /dev/shm -- fewer when it does not hold them)")
+    ap.add_argument("--e2e-c4-rows", type=int, default=1_048_576,
+                    help="rows of the configs[3] end-to-end leg (--keepId --keepInfo, whole output hashed against the oracle); 0 = skip")
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
     ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
     ap.add_argument("--path", type=int, default=0, help="0 choose, 1 census path, 2 streaming path")
@@ -451,37 +763,7 @@ def main():
                 line["real_data"] = {"error": repr(exc)[:300]}
         want_host_legs = world == 1 and not args.golden and not (args.no_e2e and args.no_cpu_baseline)
         if want_host_legs:
-            path = prefix = None
-            try:
-                hdr = bg.header(cfg)
-                first0 = rank_blocks(rank, args.blocks, args.rows)[0]
-                path, f_rows, f_bytes, where = write_e2e_file(
-                    hdr, blocks, sizes, args.e2e_rows, args.rows,
-                    lambda b: bg.rows_device(cfg, first0 + b * args.rows, args.rows, pad=bv.DEVICE_PAD))
-                if not args.no_e2e:
-                    # prefix of the same stream for the md5 check: rows [first, first + n) of block 0
-                    p_rows = min(args.rows, 65_536 if ns else 1_000_000)
-                    pt, pn = bg.rows_device(cfg, rank_blocks(rank, args.blocks, args.rows)[0], p_rows, pad=bv.DEVICE_PAD)
-                    prefix = path + ".prefix"
-                    with open(prefix, "wb") as f:
-                        f.write(hdr)
-                        f.write(memoryview(pt[:pn].cpu().numpy()))
-                    del pt
-                    line["e2e"] = e2e_leg(path, f_rows, f_bytes, where, prefix, p_rows, str(local_rank))
-                    n_vis = torch.cuda.device_count()
-                    if n_vis > 1:
-                        # (not part of `value`, which is this rank's GPU alone) the same file dealt block by block to every
-                        # visible device by the one CLI process
-                        line["e2e_all_devices"] = e2e_leg(path, f_rows, f_bytes, where, None, 0,
-                                                          ",".join(str(d) for d in range(n_vis)), runs=2, timeout_s=180)
-                if not args.no_cpu_baseline:
-                    line["cpu_baseline"] = cpu_baseline(path, f_rows, args.profile)
-            except Exception as exc:  # the host legs inform; the measured line above stands without them
-                line.setdefault("host_legs_error", repr(exc)[:400])
-            finally:
-                for q in (path, prefix):
-                    if q and os.path.exists(q):
-                        os.unlink(q)
+            host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, ctx.close)
         print(json.dumps(line))
     ctx.close()
     if world > 1:

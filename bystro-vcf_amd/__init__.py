@@ -40,6 +40,10 @@ CLS_NONE, CLS_HET, CLS_HOM, CLS_MISSING = 0, 1, 2, 3
 # the measurement hooks of include/bvcf_bench.h (not part of the drop-in ABI)
 BENCH_EXPORTS = ["bvcf_bench_device", "bvcf_bench_device_slots", "bvcf_bench_stream_kernel"]
 
+# the partition logic of bvcf_run_fd, exported for host-only tests (include/bvcf_plan.h; not part of the drop-in ABI)
+PLAN_EXPORTS = ["bvcf_plan_text_ranges", "bvcf_plan_bgzf_ranges", "bvcf_cut_text_range", "bvcf_find_bgzf_chain",
+                "bvcf_plan_threads", "bvcf_plan_fd"]
+
 # every symbol include/bvcf.h declares
 EXPORTS = [
     "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_set_sample_names", "bvcf_alloc_pinned", "bvcf_alloc_pinned_near", "bvcf_warmup",
@@ -135,6 +139,49 @@ lib.bvcf_run_fd.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.POIN
 lib.bvcf_decompress_fd.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_char_p]
 lib.bvcf_free.argtypes = [C.c_void_p]
 lib.bvcf_free.restype = None
+
+
+class RangePlan(C.Structure):
+    _fields_ = [("data_off", C.c_uint64), ("range_bytes", C.c_uint64), ("spare_bytes", C.c_uint64), ("n_ranges", C.c_uint64)]
+
+
+class TextCut(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_uint32), ("start", C.c_uint64), ("end", C.c_uint64), ("long_start", C.c_uint64)]
+
+
+class ThreadBudget(C.Structure):
+    _fields_ = [("readers", C.c_uint32), ("copy_threads", C.c_uint32), ("format_threads", C.c_uint32), ("busy_total", C.c_uint32)]
+
+
+class PlanBlock(C.Structure):
+    _fields_ = [("worker", C.c_uint32), ("piece", C.c_uint32), ("range", C.c_uint64), ("file_off", C.c_uint64),
+                ("nbytes", C.c_uint64), ("own", C.c_uint64), ("first_off", C.c_uint32), ("bgzf", C.c_uint8),
+                ("bgzf_flags", C.c_uint8), ("last_piece", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+CUT_LINES, CUT_NONE, CUT_LONG = 0, 1, 2
+MODE_STREAM, MODE_TEXT_RANGES, MODE_BGZF_RANGES = 0, 1, 2
+BGZF_SKIP_FIRST_LINE, BGZF_END_OF_STREAM = 1, 2
+lib.bvcf_plan_text_ranges.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(RangePlan)]
+lib.bvcf_plan_bgzf_ranges.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(RangePlan)]
+lib.bvcf_cut_text_range.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint8, C.POINTER(TextCut)]
+lib.bvcf_find_bgzf_chain.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t]
+lib.bvcf_find_bgzf_chain.restype = C.c_long
+lib.bvcf_plan_threads.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(ThreadBudget)]
+lib.bvcf_plan_fd.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(PlanBlock), C.c_size_t,
+                             C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(RangePlan)]
+
+
+def plan_fd(fd_in, n_workers, max_batch_bytes=0, device_inflate=1, fd_err=2, cap=1 << 16):
+    """the blocks bvcf_run_fd's readers would hand to n_workers device workers (no device involved)
+    -> (rc, mode, RangePlan, [PlanBlock])"""
+    out = (PlanBlock * cap)()
+    n = C.c_size_t(0)
+    mode = C.c_int(-1)
+    plan = RangePlan()
+    rc = lib.bvcf_plan_fd(fd_in, fd_err, n_workers, max_batch_bytes, device_inflate, out, cap, C.byref(n), C.byref(mode), C.byref(plan))
+    assert n.value <= cap, "more blocks than room"
+    return rc, mode.value, plan, [out[i] for i in range(n.value)]
 
 
 class BvcfError(RuntimeError):

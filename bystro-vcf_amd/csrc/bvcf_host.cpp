@@ -4,6 +4,8 @@
 // Nothing here computes what the kernels compute: rows are assembled from bvcf_result only.
 #include "bvcf_host_internal.h"
 
+using namespace bvcf_host;
+
 
 
 extern "C" {

@@ -27,6 +27,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef ORC_MAIN
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#endif
 
 /* ------------------------------------------------------------------ buffers */
 
@@ -1085,7 +1090,21 @@ int main(int argc, char **argv) {
   clock_gettime(CLOCK_MONOTONIC, &ts0);
   orc_buf in;
   orc_buf_init(&in);
-  for (;;) {
+  /* a regular file is mapped, not copied (bench.py's file is 63 GB in /dev/shm: a second copy of it is 15 s and as much
+   * memory again); MAP_POPULATE so that the page-table work stays in the "read" figure, not in "process" */
+  char *mapped = NULL;
+  size_t mapped_len = 0;
+  {
+    struct stat st;
+    if (in_path && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fileno(f), 0);
+      if (m != MAP_FAILED) {
+        mapped = (char *)m;
+        mapped_len = (size_t)st.st_size;
+      }
+    }
+  }
+  while (!mapped) {
     buf_reserve(&in, 1 << 24);
     size_t r = fread(in.data + in.len, 1, 1 << 24, f);
     if (!r) break;
@@ -1098,7 +1117,8 @@ int main(int argc, char **argv) {
   buf_putc(&out, '\n');
   uint64_t n_rows = 0;
   clock_gettime(CLOCK_MONOTONIC, &ts1);
-  int rv = orc_read_vcf(&cfg, in.data ? in.data : "", in.len, &out, &err, &n_rows);
+  int rv = mapped ? orc_read_vcf(&cfg, mapped, mapped_len, &out, &err, &n_rows)
+                  : orc_read_vcf(&cfg, in.data ? in.data : "", in.len, &out, &err, &n_rows);
   clock_gettime(CLOCK_MONOTONIC, &ts2);
   fwrite(out.data, 1, out.len, stdout);
   if (err.len) fwrite(err.data, 1, err.len, stderr);
@@ -1111,6 +1131,7 @@ int main(int argc, char **argv) {
             (double)(ts2.tv_sec - ts1.tv_sec) + 1e-9 * (double)(ts2.tv_nsec - ts1.tv_nsec),
             (double)(ts3.tv_sec - ts2.tv_sec) + 1e-9 * (double)(ts3.tv_nsec - ts2.tv_nsec));
   }
+  if (mapped) munmap(mapped, mapped_len);
   orc_buf_free(&in);
   orc_buf_free(&out);
   orc_buf_free(&err);
