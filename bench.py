@@ -267,55 +267,6 @@ def write_e2e_file(header, blocks, sizes, want_rows, rows_per_block, make_block)
     return path, n_blk * rows_per_block, total, base
 
 
-def e2e_leg(path, rows, nbytes, where, prefix_path, prefix_rows, devices, runs=2, timeout_s=300):
-    """the CLI over the file, wall clock around the process; BVCF_TIMING=json gives the stage split.  A run that does
-    not come back within timeout_s is reported, not waited for: the bench line must not depend on this leg."""
-    env = dict(os.environ, BVCF_TIMING="json")
-    best = None
-    walls = []
-    for _ in range(runs):
-        t0 = time.perf_counter()
-        try:
-            with open(os.devnull, "wb") as out:
-                p = subprocess.run([CLI, "--in", path, "--devices", devices], stdout=out, stderr=subprocess.PIPE, env=env,
-                                   timeout=timeout_s)
-        except subprocess.TimeoutExpired:
-            return {"error": "CLI --devices %s did not finish within %d s" % (devices, timeout_s)}
-        wall = time.perf_counter() - t0
-        if p.returncode != 0:
-            return {"error": "CLI rc %d: %s" % (p.returncode, p.stderr[-300:].decode(errors="replace"))}
-        stages = None
-        for ln in p.stderr.decode(errors="replace").splitlines():
-            if ln.startswith("[bvcf timing-json] "):
-                stages = json.loads(ln[len("[bvcf timing-json] "):])
-        walls.append(wall)
-        if best is None or wall < best[0]:
-            best = (wall, stages)
-    wall, stages = best
-    out = {
-        "input": "%d rows, %.2f GB of the same synthetic stream in %s -> bystro-vcf --in --devices %s (HIP) -> /dev/null" % (
-            rows, nbytes / 1e9, where, devices),
-        "devices": devices,
-        "rows": rows, "bytes": nbytes, "runs_wall_s": walls, "wall_s": wall,
-        "variants_per_s": rows / wall, "variants_per_min": rows / wall * 60, "text_GBps": nbytes / wall / 1e9,
-        "stages": stages,
-    }
-    if stages and stages.get("steady_s"):
-        # from the first block's submit to the last byte written: the run without process / HIP start-up and teardown
-        out["steady_variants_per_s"] = rows / stages["steady_s"]
-        out["steady_variants_per_min"] = rows / stages["steady_s"] * 60
-        out["steady_text_GBps"] = nbytes / stages["steady_s"] / 1e9
-        if stages["lines_in"] != rows:
-            out["error"] = "the CLI saw %d lines, the file has %d" % (stages["lines_in"], rows)
-    if not prefix_path:
-        return out
-    # parity on a prefix of the same stream: md5 of the CLI's stdout == md5 of the oracle CLI's
-    rc_g, m_g = _md5_stdout([CLI, "--in", prefix_path, "--devices", devices])
-    rc_o, m_o = _md5_stdout([ORACLE, "--in", prefix_path, "--threads", str(min(usable_cpus(), 64))])
-    out["md5_check"] = {"rows": prefix_rows, "hip": m_g, "oracle": m_o, "equal": rc_g == 0 and rc_o == 0 and m_g == m_o}
-    return out
-
-
 def real_data_leg(bv, bg, cfg, device, args, kernel, synthetic_GBps):
     """the same kernel over REAL 1000-Genomes lines (the reference's regression input, tests/golden/: 19 747 rows x 2 504
     samples, replicated to one block), one block at a time: the synthetic row model lets the scan skip 53 % of its
