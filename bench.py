@@ -549,6 +549,9 @@ def main():
                     help="rows of the configs[3] end-to-end leg (--keepId --keepInfo, whole output hashed against the oracle); 0 = skip")
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
     ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
+    ap.add_argument("--no-packed-sites", action="store_true",
+                    help="sites-only input (profile c2): the full form of the results (128 bytes per line) instead of the packed one "
+                         "(ABI 6, 32 bytes per line, what the CLI asks for)")
     ap.add_argument("--path", type=int, default=0, help="0 choose, 1 census path, 2 streaming path")
     ap.add_argument("--slots", type=int, default=2,
                     help="blocks in flight per GPU: block i runs on slot i %% slots, each slot on its own HIP stream, as "
@@ -614,7 +617,7 @@ def main():
                  # plus two of slack)
                  cmap_bytes=min((n_alt_cap + (max_bytes // (4 * ns + 8) if ns else 0) + 16 * 8192) * stride + 4096, 0xFFFFFF00),
                  path=args.path,
-                 want_class_maps=not args.no_class_maps)
+                 want_class_maps=not args.no_class_maps, packed_sites=ns == 0 and not args.no_packed_sites)
     ptrs = [t.data_ptr() for t in blocks]
 
     def barrier():
@@ -654,7 +657,8 @@ def main():
         # every row (4 bytes per sample).  Streaming path, k_stream, and sites-only input, k_sites: every byte of
         # every row (it is also the pass that finds the lines).
         streaming = ctx.path() == 2
-        sites_kernel = {"0": "k_head", "1": "k_sites", "3": "k_sites1"}.get(os.environ.get("BVCF_SITES", ""), "k_sites2")
+        sites_kernel = {"0": "k_head", "1": "k_sites", "3": "k_sites1"}.get(os.environ.get("BVCF_SITES", ""),
+                                                                              "k_sites2" if args.no_packed_sites else "k_sites2p")
         kernel = ctx.stream_kernel() if streaming else ("k_gt" if ns else sites_kernel)
         alg_bytes = int(mean_bytes) if (streaming or not ns) else args.rows * 4 * ns
         achieved = alg_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms else None

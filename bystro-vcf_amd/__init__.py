@@ -27,7 +27,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 DEVICE_PAD = 64
 NO_CMAP = 0xFFFFFFFF
 
@@ -60,6 +60,7 @@ class Params(C.Structure):
         ("want_dosage", C.c_uint8), ("want_name_lists", C.c_uint8), ("allow_filter", C.c_char_p), ("exclude_filter", C.c_char_p),
         ("max_batch_bytes", C.c_uint64), ("max_lines", C.c_uint32), ("max_alleles", C.c_uint32),
         ("cmap_bytes", C.c_uint64), ("n_slots", C.c_uint32), ("path", C.c_uint32),
+        ("packed_sites", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -85,6 +86,7 @@ class Result(C.Structure):
         ("n_lines_seen", C.c_uint64), ("dosage", C.c_void_p), ("dosage_stride", C.c_uint32), ("reserved2", C.c_uint32),
         ("name_lists", C.c_void_p), ("names", C.c_void_p), ("n_name_bytes", C.c_uint64),
         ("text", C.c_void_p), ("n_text_bytes", C.c_uint64), ("head_off", C.c_void_p),
+        ("sites", C.c_void_p), ("n_full_lines", C.c_uint32), ("reserved3", C.c_uint32),
     ]
 
 
@@ -97,8 +99,11 @@ ALLELE_DTYPE = np.dtype([
     ("alt_base", "u1"), ("kind", "u1"), ("site_type", "u1"), ("trtv", "u1"), ("flags", "u1"), ("pad", "u1", (2,)),
     ("gt_task", "<u4"), ("pad2", "<u4")])
 ERR_DTYPE = np.dtype([("line", "<u4"), ("alt_no", "<u4"), ("code", "<u4"), ("pad", "<u4")])
+SITE_DTYPE = np.dtype([("off", "<u4"), ("len", "<u4"), ("fend", "u1", (8,)), ("ref", "u1"), ("alt_base", "u1"), ("trtv", "u1"),
+                       ("status", "u1"), ("full_idx", "<u4"), ("n_fields", "<u4"), ("reserved", "<u4")])
+SITE_FULL = 0x80
 NAMES_DTYPE = np.dtype([("off", "<u4", (3,)), ("len", "<u4", (3,))])
-assert LINE_DTYPE.itemsize == 64 and ALLELE_DTYPE.itemsize == 64 and ERR_DTYPE.itemsize == 16
+assert LINE_DTYPE.itemsize == 64 and ALLELE_DTYPE.itemsize == 64 and ERR_DTYPE.itemsize == 16 and SITE_DTYPE.itemsize == 32
 
 lib.bvcf_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Params)]
 lib.bvcf_create.restype = C.c_int
@@ -303,8 +308,17 @@ class Batch:
                 return np.zeros(0, dtype=dt)
             return np.frombuffer(C.string_at(ptr, n * dt.itemsize), dtype=dt).copy()
 
-        self.lines = arr(r.lines, r.n_lines, LINE_DTYPE)
-        self.alleles = arr(r.alleles, r.n_alleles, ALLELE_DTYPE)
+        self.sites = None
+        if r.sites:
+            # the packed form of a file without samples (bvcf_params.packed_sites): expanded here into the arrays of the full
+            # form, so that line i is lines[i] and its first record alleles[i] whichever way the batch came back
+            self.sites = arr(r.sites, r.n_lines, SITE_DTYPE)
+            self.full_lines = arr(r.lines, r.n_full_lines, LINE_DTYPE)
+            raw = arr(r.alleles, r.n_alleles, ALLELE_DTYPE)
+            self.lines, self.alleles = self._expand(self.sites, self.full_lines, raw, r.n_lines)
+        else:
+            self.lines = arr(r.lines, r.n_lines, LINE_DTYPE)
+            self.alleles = arr(r.alleles, r.n_alleles, ALLELE_DTYPE)
         self.errs = arr(r.errs, r.n_errs, ERR_DTYPE)
         self.cmap = arr(r.cmap, r.n_cmap_bytes, np.dtype("u1"))
         # want_dosage: one int8 row per alleles[] slot (rows of slots without a record hold garbage)
@@ -318,6 +332,43 @@ class Batch:
         self.dosage = None
         if r.dosage and r.n_alleles:
             self.dosage = arr(r.dosage, r.n_alleles * r.dosage_stride, np.dtype("i1")).reshape(r.n_alleles, r.dosage_stride)
+
+    @staticmethod
+    def _expand(sites, full_lines, raw_alleles, n):
+        lines = np.zeros(n, dtype=LINE_DTYPE)
+        alleles = raw_alleles.copy()
+        if len(alleles) < n:
+            alleles = np.concatenate([alleles, np.zeros(n - len(alleles), dtype=ALLELE_DTYPE)])
+        full = (sites["status"] & SITE_FULL) != 0
+        fi = sites["full_idx"][full]
+        assert len(set(fi.tolist())) == len(fi) and (fi < len(full_lines)).all(), "full_idx: distinct slots below n_full_lines"
+        lines[full] = full_lines[fi]
+        assert (full_lines[fi]["gt_task"] == np.nonzero(full)[0]).all(), "a full record names its line"
+        firsts = raw_alleles[fi].copy()
+        # packed lines: a SNP with its position taken verbatim (or a line that failed the gate: no record)
+        pk = ~full
+        lines["off"][pk] = sites["off"][pk]
+        lines["len"][pk] = sites["len"][pk]
+        fe = sites["fend"].astype(np.uint32)
+        fe9 = np.concatenate([fe, np.full((n, 1), 0xFF, dtype=np.uint32)], axis=1)
+        fe9 = np.where(fe9 == 0xFF, sites["len"][:, None], fe9)
+        lines["fend"][pk] = fe9[pk]
+        lines["n_rec"][pk] = (sites["status"][pk] == LINE_OK).astype(np.uint32)
+        lines["n_fields"][pk] = sites["n_fields"][pk]
+        lines["gt_task"][pk] = np.nonzero(pk)[0]
+        lines["status"][pk] = sites["status"][pk]
+        alleles[:n] = np.zeros(n, dtype=ALLELE_DTYPE)
+        idx = np.nonzero(pk)[0]
+        alleles["line"][idx] = idx
+        alleles["alt_len"][idx] = 1
+        alleles["cmap_off"][idx] = NO_CMAP
+        alleles["ref"][idx] = sites["ref"][pk]
+        alleles["alt_base"][idx] = sites["alt_base"][pk]
+        alleles["trtv"][idx] = sites["trtv"][pk]
+        alleles["flags"][idx] = 1
+        alleles["gt_task"][idx] = 0xFFFFFFFF
+        alleles[np.nonzero(full)[0]] = firsts
+        return lines, alleles
 
     def records(self, i):
         """the output alleles of line i, in order"""
@@ -367,7 +418,7 @@ class Ctx:
 
     def __init__(self, n_header_fields, allow="PASS,.", exclude="", device=0, eol_chars=1, eol_byte=b"\n",
                  max_batch_bytes=0, max_lines=0, max_alleles=0, cmap_bytes=0, n_slots=0, want_class_maps=True,
-                 path=0, want_dosage=False, sample_names=None, delimiter=";"):
+                 path=0, want_dosage=False, sample_names=None, delimiter=";", packed_sites=False):
         p = Params()
         p.abi_version = ABI_VERSION
         p.device = device
@@ -384,6 +435,7 @@ class Ctx:
         p.cmap_bytes = cmap_bytes
         p.n_slots = n_slots
         p.path = path
+        p.packed_sites = int(packed_sites)
         p.want_name_lists = int(sample_names is not None)
         self.h = C.c_void_p()
         rc = lib.bvcf_create(C.byref(self.h), C.byref(p))

@@ -38,6 +38,7 @@ struct BatchCounters {
   uint32_t cmap_maps;    // streaming path: class maps handed out
   uint32_t pad[2];       // [0]: internal error flag; [1]: wide ctxs, the longest sample region
   uint32_t n_finish;     // streaming path: entries of finish_items (what k_finish still has to settle)
+  uint32_t n_full;       // sites-only input, packed form (KernelArgs.sites): lines whose full records were written (lines[0 .. n_full))
   uint32_t n_other_shape;  // streaming path: listed lines that were not of the shape the kernel is made for -- k_stream: not the
                            // 4-byte grid (left to k_gt); k_stream_gen: of the 4-byte grid.  The host picks the next batch's kernel by it.
 };
@@ -88,6 +89,8 @@ struct KernelArgs {
   uint32_t *line_off;    // [max_lines + 1]
   bvcf_line *lines;
   bvcf_allele *alleles;
+  bvcf_site *sites;      // sites-only input, bvcf_params.packed_sites: one 32-byte record per line; lines[] / alleles[] then
+                         // only for the lines that need them, in slots handed out by counters->n_full.  Null: the full form
   bvcf_err *errs;
   uint8_t *cmap;
   GtTask *tasks;

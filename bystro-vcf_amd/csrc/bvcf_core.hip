@@ -32,6 +32,7 @@ struct Slot {
   uint32_t *d_census = nullptr, *d_group = nullptr, *d_line_off = nullptr;
   bvcf_line *d_lines = nullptr;
   bvcf_allele *d_alleles = nullptr;
+  bvcf_site *d_sites = nullptr, *h_sites = nullptr;  // packed ctxs only
   bvcf_err *d_errs = nullptr;
   uint8_t *d_cmap = nullptr;
   int8_t *d_dosage = nullptr;
@@ -110,6 +111,7 @@ struct bvcf_ctx {
   bool sites = false; // no sample columns: k_sites after the census instead of k_scatter_eol + k_head + k_finish
   bool sites1 = false;  // ... or k_sites1 on its own, no census, the line numbers by look-back (BVCF_SITES=3)
   bool sites2 = false;  // ... or k_sites2 behind the census: tiles, the common lines on fast lanes (the default for such input)
+  bool packed = false;  // ... and the batch comes back in the packed form (bvcf_params.packed_sites; k_sites2 only)
   bool sites2_tile_census = true;  // ... its census per tile (k_count_tiles + one scan) instead of per chunk (BVCF_S2_CENSUS=chunk)
   int sites_grid = 0, sites1_grid = 0;
   uint32_t win_bytes = 64u << 10;  // wide: bytes of a line's sample region per wave of the split general scan
@@ -180,6 +182,8 @@ void free_slot(Slot &s) {
   hipFree(s.d_line_off);
   hipFree(s.d_lines);
   hipFree(s.d_alleles);
+  hipFree(s.d_sites);
+  hipHostFree(s.h_sites);
   hipFree(s.d_errs);
   hipFree(s.d_cmap);
   hipFree(s.d_dosage);
@@ -275,6 +279,10 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   hipFree(s.d_line_off);
   hipFree(s.d_lines);
   hipFree(s.d_alleles);
+  hipFree(s.d_sites);
+  hipHostFree(s.h_sites);
+  s.d_sites = nullptr;
+  s.h_sites = nullptr;
   hipFree(s.d_errs);
   hipFree(s.d_cmap);
   hipFree(s.d_dosage);
@@ -312,6 +320,10 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   HIP_TRY(c, hipMalloc(&s.d_line_off, (c->max_lines + 1) * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&s.d_lines, c->max_lines * sizeof(bvcf_line)));
   HIP_TRY(c, hipMalloc(&s.d_alleles, c->max_alleles * sizeof(bvcf_allele)));
+  if (c->packed) {
+    HIP_TRY(c, hipMalloc(&s.d_sites, (c->max_lines + 64) * sizeof(bvcf_site)));
+    HIP_TRY(c, hipHostMalloc(&s.h_sites, (c->max_lines + 64) * sizeof(bvcf_site), hipHostMallocDefault));
+  }
   HIP_TRY(c, hipMalloc(&s.d_errs, c->max_alleles * sizeof(bvcf_err)));
   HIP_TRY(c, hipMalloc(&s.d_cmap, c->max_cmap + 64));
   HIP_TRY(c, hipMalloc(&s.d_tasks, c->max_alleles * sizeof(GtTask)));
@@ -386,6 +398,7 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.line_off = s.d_line_off;
   a.lines = s.d_lines;
   a.alleles = s.d_alleles;
+  a.sites = c->packed ? s.d_sites : nullptr;
   a.errs = s.d_errs;
   a.cmap = s.d_cmap;
   a.dosage = s.d_dosage;
@@ -453,6 +466,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     if (a.dosage) hipLaunchKernelGGL(k_dosage, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     return;
   }
+#ifdef BVCF_EXPERIMENTS
   if (c->sites1) {
     // sites-only input, one pass: the counters and the tiles' look-back state start from zero
     const uint32_t n_words = s1_state_words(a.nbytes);
@@ -469,6 +483,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     if (ev_gt1) hipEventRecord(ev_gt1, st);
     return;
   }
+#endif
   const uint32_t n_chunks = (a.nbytes + kChunk - 1) / kChunk;
   const uint32_t n_groups = (n_chunks + kScanGroup - 1) / kScanGroup;
   const uint32_t stream_grid = (uint32_t)std::min<uint64_t>((n_chunks + kWavesPerWg - 1) / kWavesPerWg,
@@ -480,7 +495,10 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     hipLaunchKernelGGL(k_count_tiles, dim3(grid ? grid : 1), dim3(kWgThreads), 0, st, a, n_tiles);
     hipLaunchKernelGGL(k_scan_flat, dim3(1), dim3(1024), 0, st, a, n_tiles);
     if (ev_gt0) hipEventRecord(ev_gt0, st);
-    hipLaunchKernelGGL(k_sites2, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, n_tiles, 0u);
+    if (a.sites)
+      hipLaunchKernelGGL(k_sites2p, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, n_tiles, 0u);
+    else
+      hipLaunchKernelGGL(k_sites2, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, n_tiles, 0u);
     if (ev_gt1) hipEventRecord(ev_gt1, st);
     return;
   }
@@ -489,10 +507,14 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
   if (c->sites2) {
     if (ev_gt0) hipEventRecord(ev_gt0, st);
-    hipLaunchKernelGGL(k_sites2, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, s2_n_tiles(a.nbytes), n_chunks);
+    if (a.sites)
+      hipLaunchKernelGGL(k_sites2p, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, s2_n_tiles(a.nbytes), n_chunks);
+    else
+      hipLaunchKernelGGL(k_sites2, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, s2_n_tiles(a.nbytes), n_chunks);
     if (ev_gt1) hipEventRecord(ev_gt1, st);
     return;
   }
+#ifdef BVCF_EXPERIMENTS
   if (c->sites) {
     // sites-only input: line records and allele records straight from one pass over the text
     if (ev_gt0) hipEventRecord(ev_gt0, st);
@@ -500,6 +522,7 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
     if (ev_gt1) hipEventRecord(ev_gt1, st);
     return;
   }
+#endif
   hipLaunchKernelGGL(k_scatter_eol, dim3(stream_grid ? stream_grid : 1), dim3(kWgThreads), 0, st, a, n_chunks);
   // (k_head_lean when batches overlap: at 132 registers three of its workgroups fit on a CU beside the kernels of
   // the neighbouring batch; sites-only benchmark with two slots 4.4 -> 4.9 G variants/s, with one slot 3.5 -> 3.4)
@@ -583,9 +606,11 @@ static const CrcTabs *crc_tabs_on_device() {
 // inflate + CRC of BGZF blocks whose compressed bytes are at d_comp (device): text to d_text.  desc/crc/status are
 // device arrays of n_blocks entries.
 // w16: the 16 KiB-window kernel (two batches of blocks resident at once), for text whose lines are well under 16 KB
-static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_desc, uint32_t n_blocks, uint8_t *d_text,
+// false: the CRC tables could not be put on the device -- nothing was launched (a batch must not go unchecked)
+static bool launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_desc, uint32_t n_blocks, uint8_t *d_text,
                            uint32_t *d_status, uint32_t *d_crc, hipStream_t st, bool w16) {
   const CrcTabs *crc_tabs = crc_tabs_on_device();
+  if (!crc_tabs) return false;
   static const int per_cu32 = [] {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_inflate, kInfThreads, 0) != hipSuccess || n < 1) n = 4;
@@ -620,10 +645,9 @@ static void launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_de
     hipLaunchKernelGGL(k_inflate_w16, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
   else
     hipLaunchKernelGGL(k_inflate, dim3(grid ? grid : 1), dim3(kInfThreads), 0, st, d_comp, d_desc, n_blocks, d_text, d_status);
-  // (no tables: the launch is left out, the status words stay as they were, k_cuts reports the mismatch)
-  if (crc_tabs)
-    hipLaunchKernelGGL(k_crc32, dim3(std::min<uint32_t>(n_blocks ? n_blocks : 1, (uint32_t)n_cu * 16u)), dim3(kWave), 0, st,
-                       (const uint8_t *)d_text, d_desc, n_blocks, crc_tabs, d_crc);
+  hipLaunchKernelGGL(k_crc32, dim3(std::min<uint32_t>(n_blocks ? n_blocks : 1, (uint32_t)n_cu * 16u)), dim3(kWave), 0, st,
+                     (const uint8_t *)d_text, d_desc, n_blocks, crc_tabs, d_crc);
+  return true;
 }
 
 // the kernel chain of the batch in slot s over the resident text src[0 .. nbytes), the counter read-back and the event
@@ -721,7 +745,11 @@ int launch_after_cuts(bvcf_ctx *c, Slot &s, bool wait) {
 
 extern "C" {
 
+#ifdef BVCF_EXPERIMENTS
+const char *bvcf_version(void) { return "bvcf-mi355x 0.1 (gfx950) +experiments"; }
+#else
 const char *bvcf_version(void) { return "bvcf-mi355x 0.1 (gfx950)"; }
+#endif
 
 const char *bvcf_last_error(const bvcf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -734,9 +762,14 @@ void *bvcf_alloc_pinned(size_t nbytes) {
 
 void *bvcf_alloc_pinned_near(int device, size_t nbytes) {
   // (the runtime places pinned memory on the NUMA node closest to the calling thread's current device)
-  int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev || hipSetDevice(device) != hipSuccess) return nullptr;
-  return bvcf_alloc_pinned(nbytes);
+  // The calling thread's current device is put back afterwards.
+  int n_dev = 0, was = -1;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return nullptr;
+  if (hipGetDevice(&was) != hipSuccess) was = -1;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  void *p = bvcf_alloc_pinned(nbytes);
+  if (was >= 0 && was != device) hipSetDevice(was);
+  return p;
 }
 
 int bvcf_device_pci_bus_id(int device, char *out, int cap) {
@@ -865,39 +898,51 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   // flight the third wave's registers are better spent on the previous batch's k_head_lean / k_gt / k_finish, which
   // then run beside this kernel instead of waiting for its workgroups to finish (+7 % on the two-slot benchmark).
   if (c->p.n_slots > 1 && per_cu > 2) per_cu = 2;
+#ifdef BVCF_EXPERIMENTS
   if (const char *e = getenv("BVCF_STREAM_WGS")) {  // experiment: workgroups per CU, up to the occupancy limit
     const int w = atoi(e);
     if (w >= 1 && w <= 4) per_cu = w;
   }
+#endif
   c->stream_grid = c->n_cu * per_cu;
   per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream_gen, kWgThreads, gen_lds_bytes(c->n_samples)) != hipSuccess || per_cu < 1)
     per_cu = 2;
   per_cu = std::min(per_cu, 6);  // (7 fit a cohort of a few thousand samples; 6 measured best)
+#ifdef BVCF_EXPERIMENTS
   if (const char *e = getenv("BVCF_GEN_WGS")) {  // experiment: workgroups per CU
     const int w = atoi(e);
     if (w >= 1 && w <= 8) per_cu = std::min(per_cu, w);
   }
+#endif
   c->gen_grid = c->n_cu * per_cu;
-  // sites-only input takes the fused kernel (BVCF_SITES=0: the census chain with k_head, for A/B and parity tests)
-  // (BVCF_SITES=0: the census chain with k_head; 1: k_sites behind the census, round 2's chain; 2: k_sites2 behind the
-  // census, the default; 3: k_sites1, no census, line numbers by look-back)
+  // sites-only input takes k_sites2 behind its census (BVCF_SITES=0: the census chain with k_head, for A/B and parity
+  // tests; builds with -DBVCF_EXPERIMENTS also know 1: k_sites, round 2's kernel, and 3: k_sites1, no census, the line
+  // numbers by look-back -- both slower, kept out of the product library)
   c->sites = c->n_samples == 0;
   c->sites2 = c->sites;
   if (const char *e = getenv("BVCF_SITES")) {
     const int m = atoi(e);
+#ifdef BVCF_EXPERIMENTS
     c->sites = c->sites && m != 0;
     c->sites2 = c->sites && m == 2;
     c->sites1 = c->sites && m == 3;
+#else
+    c->sites = c->sites2 = c->sites && m != 0;
+#endif
   }
   if (const char *e = getenv("BVCF_S2_CENSUS")) c->sites2_tile_census = strcmp(e, "chunk") != 0;  // (A/B and parity tests)
+  c->packed = c->sites2 && p->packed_sites != 0;
   per_cu = 0;
+#ifdef BVCF_EXPERIMENTS
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sites, kSitesThreads, 0) != hipSuccess || per_cu < 1)
     per_cu = 3;
   c->sites_grid = c->n_cu * per_cu;
   per_cu = 0;
+#endif
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sites2, kS1Threads, 0) != hipSuccess || per_cu < 1)
     per_cu = 2;
+#ifdef BVCF_EXPERIMENTS
   if (const char *e = getenv("BVCF_SITES1_WGS")) {  // experiment: workgroups per CU
     const int w = atoi(e);
     if (w >= 1 && w <= 8) per_cu = std::min(per_cu, w);
@@ -906,6 +951,7 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
     const int w = atoi(e);
     if (w >= 1 && w <= 4) per_cu = std::min(per_cu, w);
   }
+#endif
   c->sites1_grid = c->n_cu * per_cu;
   // the streaming kernel gives every wave its own range of class-map slots (two of them slack): room for that
   if (!p->cmap_bytes) {
@@ -1190,7 +1236,10 @@ int bvcf_submit_bgzf(bvcf_ctx *c, const uint8_t *comp, size_t n_comp, size_t n_o
   HIP_TRY(c, hipMemcpyAsync(s.d_comp, comp, n_comp, hipMemcpyHostToDevice, s.stream));
   HIP_TRY(c, hipMemcpyAsync(s.d_bgzf, s.h_bgzf, 5 * nb * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
   // lines well under 16 KB (the batches so far say): the small-window kernel, so that two batches inflate side by side
-  launch_inflate(c->n_cu, s.d_comp, d_desc, (uint32_t)nb, s.d_in, d_status, d_crc, s.stream, c->avg_line_bytes && c->avg_line_bytes <= 12000);
+  if (!launch_inflate(c->n_cu, s.d_comp, d_desc, (uint32_t)nb, s.d_in, d_status, d_crc, s.stream, c->avg_line_bytes && c->avg_line_bytes <= 12000)) {
+    c->err = "bvcf_submit_bgzf: the CRC tables could not be placed on the device";
+    return BVCF_E_NOMEM;
+  }
   // the pad behind the text is read (and masked) by the scans: keep it defined
   HIP_TRY(c, hipMemsetAsync(s.d_in + total, '\n', BVCF_DEVICE_PAD, s.stream));
   CutArgs ca;
@@ -1268,7 +1317,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   adapt_stream_kernel(c, s.used_gen, ctr);
   // slot i of alleles[] / tasks / class maps belongs to line i; the counters count the extras, which follow the lines'
   // slots (k_sites1 does not know the number of lines while it runs: there they follow slot max_lines)
-  const uint64_t extras_at = c->sites1 ? (uint64_t)s.cap_lines : (uint64_t)ctr.n_lines;
+  const uint64_t extras_at = (c->sites1 || c->packed) ? (uint64_t)s.cap_lines : (uint64_t)ctr.n_lines;
   const uint64_t n_alleles = extras_at + ctr.n_alleles;
   const uint64_t n_tasks = (uint64_t)ctr.n_lines + ctr.n_tasks;
   const uint64_t need_alleles = std::max<uint64_t>(std::max<uint64_t>(n_alleles, ctr.n_errs), n_tasks);
@@ -1288,11 +1337,16 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     release();
     return BVCF_E_CAPACITY;
   }
-  if (ctr.n_lines)
-    HIP_TRY(c, hipMemcpyAsync(s.h_lines, s.d_lines, ctr.n_lines * sizeof(bvcf_line), hipMemcpyDeviceToHost, s.stream));
-  if (c->sites1) {
-    if (ctr.n_lines)
-      HIP_TRY(c, hipMemcpyAsync(s.h_alleles, s.d_alleles, (size_t)ctr.n_lines * sizeof(bvcf_allele), hipMemcpyDeviceToHost, s.stream));
+  // the packed form: a site record per line, full records (lines[], their first alleles) only for the n_full lines that
+  // asked for them
+  const uint32_t n_first = c->packed ? std::min<uint32_t>(ctr.n_full, ctr.n_lines) : ctr.n_lines;
+  if (c->packed && ctr.n_lines)
+    HIP_TRY(c, hipMemcpyAsync(s.h_sites, s.d_sites, ctr.n_lines * sizeof(bvcf_site), hipMemcpyDeviceToHost, s.stream));
+  if (n_first)
+    HIP_TRY(c, hipMemcpyAsync(s.h_lines, s.d_lines, (size_t)n_first * sizeof(bvcf_line), hipMemcpyDeviceToHost, s.stream));
+  if (c->sites1 || c->packed) {
+    if (n_first)
+      HIP_TRY(c, hipMemcpyAsync(s.h_alleles, s.d_alleles, (size_t)n_first * sizeof(bvcf_allele), hipMemcpyDeviceToHost, s.stream));
     if (ctr.n_alleles)
       HIP_TRY(c, hipMemcpyAsync(s.h_alleles + extras_at, s.d_alleles + extras_at, (size_t)ctr.n_alleles * sizeof(bvcf_allele),
                                 hipMemcpyDeviceToHost, s.stream));
@@ -1363,10 +1417,17 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   }
   // getAlleles' messages were recorded before the field-count verdict was known: a line that
   // fails linePasses (main.go:537-539) never reaches getAlleles, so its messages are dropped here
+  // (packed form: the verdict of line i is in its site record, or in the full record that one points at)
+  auto verdict_of = [&](uint32_t i) -> uint32_t {
+    if (!c->packed) return s.h_lines[i].status;
+    const bvcf_site &st = s.h_sites[i];
+    if (!(st.status & BVCF_SITE_FULL)) return st.status;
+    return st.full_idx < n_first ? s.h_lines[st.full_idx].status : (uint32_t)BVCF_LINE_FIELDS;
+  };
   uint32_t n_errs = 0;
   for (uint32_t i = 0; i < ctr.n_errs; i++) {
     const bvcf_err &er = s.h_errs[i];
-    if (er.line < ctr.n_lines && s.h_lines[er.line].status != BVCF_LINE_FIELDS) s.h_errs[n_errs++] = er;
+    if (er.line < ctr.n_lines && verdict_of(er.line) != BVCF_LINE_FIELDS) s.h_errs[n_errs++] = er;
   }
   r->status = BVCF_OK;
   r->n_lines = ctr.n_lines;
@@ -1383,12 +1444,22 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   r->text = was_bgzf ? s.h_text : nullptr;
   r->n_text_bytes = was_bgzf ? text_bytes : 0;
   r->head_off = (was_bgzf && s.heads) ? s.h_head_off : nullptr;
+  r->sites = c->packed ? s.h_sites : nullptr;
+  r->n_full_lines = c->packed ? n_first : 0u;
   r->name_lists = names ? s.h_name_lists : nullptr;
   r->names = names ? s.h_names : nullptr;
   r->n_name_bytes = name_bytes;
 
   uint64_t ok = 0, ac0 = 0, recs = 0;
-  for (uint32_t i = 0; i < ctr.n_lines; i++) {
+  if (c->packed)
+    for (uint32_t i = 0; i < ctr.n_lines; i++) {
+      const bvcf_site &st = s.h_sites[i];
+      if (!(st.status & BVCF_SITE_FULL)) {
+        ok += st.status == BVCF_LINE_OK;
+        recs += st.status == BVCF_LINE_OK;
+      }
+    }
+  for (uint32_t i = 0; i < n_first; i++) {
     const bvcf_line &L = s.h_lines[i];
     if (L.status != BVCF_LINE_OK) continue;
     ok++;
@@ -1466,11 +1537,11 @@ int bvcf_bgzf_inflate_device(int device, const uint8_t *comp, size_t n_comp, uin
              hipMemcpy(d_desc, desc.data(), nb * sizeof(BgzfDesc), hipMemcpyHostToDevice) != hipSuccess) {
     rc = BVCF_E_HIP;
   } else {
-    launch_inflate(prop.multiProcessorCount, d_comp, d_desc, (uint32_t)nb, d_text, d_status, d_crc, nullptr, false);
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+    if (!launch_inflate(prop.multiProcessorCount, d_comp, d_desc, (uint32_t)nb, d_text, d_status, d_crc, nullptr, false)) rc = BVCF_E_NOMEM;
+    if (rc || hipDeviceSynchronize() != hipSuccess || hipMemcpy(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(crc.data(), d_crc, nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         (total && hipMemcpy(out, d_text, total, hipMemcpyDeviceToHost) != hipSuccess))
-      rc = BVCF_E_HIP;
+      rc = rc ? rc : BVCF_E_HIP;
   }
   hipFree(d_comp);
   hipFree(d_text);

@@ -113,8 +113,49 @@ const char *err_text(uint32_t code) {
 // one log line in the reference's formats (main.go:730-986)
 // where line li's bytes are: in the block the batch was submitted as, or -- bvcf_submit_bgzf with head_off -- in the
 // compact copy of the line heads that came back
-const char *row_of(const bvcf_result *r, const uint8_t *block, uint32_t li) {
-  return (const char *)block + (r->head_off ? r->head_off[li] : r->lines[li].off);
+const char *row_of(const bvcf_result *r, const uint8_t *block, uint32_t li, const bvcf_line &L) {
+  return (const char *)block + (r->head_off ? r->head_off[li] : L.off);
+}
+
+// Line li of a batch as full records: the batch's own -- the unpacked form, or a BVCF_SITE_FULL line of the packed form
+// (bvcf_params.packed_sites) -- or expanded from the line's 32-byte site record into *tl / *ta: a line that passed is a
+// biallelic SNP with its position taken verbatim (main.go:735-745).
+LineView line_view(const bvcf_result *r, uint32_t li, bvcf_line *tl, bvcf_allele *ta) {
+  LineView v;
+  if (!r->sites) {
+    v.L = &r->lines[li];
+    v.A0 = &r->alleles[li];
+    return v;
+  }
+  const bvcf_site &s = r->sites[li];
+  if (s.status & BVCF_SITE_FULL) {
+    v.L = &r->lines[s.full_idx];
+    v.A0 = &r->alleles[s.full_idx];
+    return v;
+  }
+  memset(tl, 0, sizeof *tl);
+  tl->off = s.off;
+  tl->len = s.len;
+  for (int k = 0; k < 9; k++) tl->fend[k] = (k < 8 && s.fend[k] != 0xFFu) ? s.fend[k] : s.len;
+  tl->n_rec = s.status == BVCF_LINE_OK ? 1u : 0u;
+  tl->n_fields = s.n_fields;
+  tl->gt_task = li;
+  tl->status = s.status;
+  tl->site_type = BVCF_SITE_SNP;
+  memset(ta, 0, sizeof *ta);
+  ta->line = li;
+  ta->alt_len = 1;
+  ta->cmap_off = BVCF_NO_CMAP;
+  ta->ref = s.ref;
+  ta->alt_base = s.alt_base;
+  ta->kind = BVCF_ALT_BASE;
+  ta->site_type = BVCF_SITE_SNP;
+  ta->trtv = s.trtv;
+  ta->flags = BVCF_ALLELE_POS_TEXT;
+  ta->gt_task = 0xFFFFFFFFu;
+  v.L = tl;
+  v.A0 = ta;
+  return v;
 }
 
 void append_err(std::string &log, const bvcf_err &e, const bvcf_line &L, const char *row) {
@@ -144,14 +185,17 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
   const char *empty = or_default(c->empty_field, "!");
   const uint32_t ns = r->n_samples;
   const double num_samples = (double)ns;
+  bvcf_line tmp_line;
+  bvcf_allele tmp_allele;
   for (uint32_t li = lo; li < hi; li++) {
-    const bvcf_line &L = r->lines[li];
+    const LineView view = line_view(r, li, &tmp_line, &tmp_allele);
+    const bvcf_line &L = *view.L;
     if (L.status != BVCF_LINE_OK) continue;
-    const char *row = row_of(r, block, li);
+    const char *row = row_of(r, block, li, L);
     auto fstart = [&](int i) -> uint32_t { return i ? L.fend[i - 1] + 1 : 0; };
     for (uint32_t k = 0; k < L.n_rec; k++) {
-      const uint32_t slot = k ? L.rec_first + k - 1 : li;
-      const bvcf_allele &A = r->alleles[slot];
+      const uint32_t slot = k ? L.rec_first + k - 1 : li;  // (k == 0, packed form: the record is *view.A0, wherever it lies)
+      const bvcf_allele &A = k ? r->alleles[slot] : *view.A0;
       // main.go:555-560: with samples, an allele nobody carries is skipped
       if (ns > 0 && A.ac == 0) continue;
       const bvcf_names *NL = r->name_lists ? &r->name_lists[slot] : nullptr;
@@ -301,7 +345,13 @@ void format_log(const bvcf_result *r, const uint8_t *block, std::string &log) {
   std::vector<uint32_t> idx(r->n_errs);
   for (uint32_t i = 0; i < r->n_errs; i++) idx[i] = i;
   std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return r->errs[x].line < r->errs[y].line; });
-  for (uint32_t i : idx) append_err(log, r->errs[i], r->lines[r->errs[i].line], row_of(r, block, r->errs[i].line));
+  bvcf_line tl;
+  bvcf_allele ta;
+  for (uint32_t i : idx) {
+    const uint32_t li = r->errs[i].line;
+    const bvcf_line &L = *line_view(r, li, &tl, &ta).L;
+    append_err(log, r->errs[i], L, row_of(r, block, li, L));
+  }
 }
 
 // rows of one batch as consecutive pieces (parts[0] + parts[1] + ... is the batch's TSV): runs of lines are claimed
@@ -496,6 +546,12 @@ int prepare_run(Run &R, std::string *msg, const uint8_t *data, size_t n_data, bo
                         strlen(or_default(R.cfg->field_delimiter, ";")) <= 16;
   }
   p.want_dosage = R.cfg->dosage_path && *R.cfg->dosage_path && R.pre.header.size() > 9;
+  {
+    // a file without samples comes back in the packed form: 32 bytes per line instead of 128 (BVCF_PACKED_SITES=0: the
+    // full form, for A/B and parity tests)
+    const char *e = getenv("BVCF_PACKED_SITES");
+    p.packed_sites = R.pre.header.size() <= 9 && !(e && *e == '0');
+  }
   p.allow_filter = R.cfg->allow_filter;
   p.exclude_filter = R.cfg->exclude_filter;
   p.max_batch_bytes = R.max_batch;
@@ -578,10 +634,10 @@ int open_ctx(Run &R, std::string *msg, const uint8_t *data, size_t n_data) {
 int append_dosage(Run &R, const bvcf_result *r, const uint8_t *block) {
   if (!R.arrow || !r->dosage) return BVCF_OK;
   std::string locus;
-  for (uint32_t li = 0; li < r->n_lines; li++) {
+  for (uint32_t li = 0; li < r->n_lines; li++) {  // (a dosage matrix needs samples: never the packed form)
     const bvcf_line &L = r->lines[li];
     if (L.status != BVCF_LINE_OK) continue;
-    const char *row = row_of(r, block, li);
+    const char *row = row_of(r, block, li, L);
     for (uint32_t k = 0; k < L.n_rec; k++) {
       const uint32_t slot = k ? L.rec_first + k - 1 : li;
       const bvcf_allele &A = r->alleles[slot];

@@ -101,7 +101,13 @@ void join_class(std::string &o, const uint8_t *cmap, bool sparse, uint32_t ns, u
 const char *err_text(uint32_t code);
 // where line li's bytes are: in the block the batch was submitted as, or -- bvcf_submit_bgzf with head_off -- in the
 // compact copy of the line heads that came back
-const char *row_of(const bvcf_result *r, const uint8_t *block, uint32_t li);
+const char *row_of(const bvcf_result *r, const uint8_t *block, uint32_t li, const bvcf_line &L);
+// line li of a batch as full records, whichever form the batch came back in (see the definition)
+struct LineView {
+  const bvcf_line *L;
+  const bvcf_allele *A0;  // its first output allele
+};
+LineView line_view(const bvcf_result *r, uint32_t li, bvcf_line *tmp_line, bvcf_allele *tmp_allele);
 void append_err(std::string &log, const bvcf_err &e, const bvcf_line &L, const char *row);
 // rows of lines [lo, hi), main.go:566-695
 void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm, const Ratios *rt,

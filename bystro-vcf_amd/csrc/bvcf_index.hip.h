@@ -98,6 +98,7 @@ __global__ __launch_bounds__(1024) void k_scan_top(KernelArgs a, uint32_t n_grou
       a.counters->cmap_maps = 0;
       a.counters->pad[0] = a.counters->pad[1] = 0;
       a.counters->n_finish = 0;
+      a.counters->n_full = 0;
       a.line_off[0] = 0u;
     }
   }

@@ -456,6 +456,8 @@ void Driver::push_end(bool read_error, bool too_long) {
 // first data line on is handed over compressed, each batch with the following blocks as look-ahead.
 void Driver::stream_bgzf(bvcf_input::ByteSource &src) {
   input_is_bgzf_device_.store(true);
+  // (batches of 256 MiB of text, as for a BGZF file: a batch takes as long as its slowest block however few it has)
+  if (!c_->max_batch_bytes) R_.max_batch = cap_ = 256ull << 20;
   std::vector<uint8_t> pend;  // compressed bytes read from the input; pend[pp..] not yet handed over
   size_t pp = 0;
   bool raw_eof = false;

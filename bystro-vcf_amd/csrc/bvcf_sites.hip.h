@@ -65,6 +65,7 @@ __device__ inline uint32_t find_eol_before(const KernelArgs &a, uint32_t limit) 
   return kNone;
 }
 
+#ifdef BVCF_EXPERIMENTS  // round 2's kernel, slower than k_sites2: kept for A/B builds (make EXTRA=-DBVCF_EXPERIMENTS)
 __global__ __launch_bounds__(kSitesThreads) void k_sites(KernelArgs a, uint32_t n_chunks) {
   __shared__ __attribute__((aligned(16))) SitesLds s_lds[kSitesWaves];
   __shared__ FilterTable s_ft;
@@ -447,5 +448,7 @@ __global__ __launch_bounds__(kSitesThreads) void k_sites(KernelArgs a, uint32_t 
     }
   }
 }
+
+#endif  // BVCF_EXPERIMENTS
 
 }  // namespace bvcf_dev

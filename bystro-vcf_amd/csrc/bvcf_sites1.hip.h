@@ -131,15 +131,19 @@ __device__ __forceinline__ void s1_store(uint32_t *p, uint32_t v) {
 // bits [0, n) for n in 0..32
 __device__ __forceinline__ uint32_t low_bits(uint32_t n) { return n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u; }
 
+#ifdef BVCF_EXPERIMENTS
 // the state words of the next k_sites1 launch and the batch counters, zeroed by one small launch
 __global__ __launch_bounds__(256) void k_s1_zero(KernelArgs a, uint32_t n_words) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) a.census[i] = 0u;
   if (blockIdx.x == 0 && threadIdx.x < sizeof(BatchCounters) / 4u) reinterpret_cast<uint32_t *>(a.counters)[threadIdx.x] = 0u;
 }
 
+#endif  // BVCF_EXPERIMENTS
+
 // kCensus = false: k_sites1, the line numbers by look-back (one tile per wave, workgroup b takes tiles kS1Waves*b ..);
 // kCensus = true:  k_sites2, the line numbers from the newline census in front of it (a persistent grid, tiles strided)
-template <bool kCensus>
+// kPacked (k_sites2p): the packed form of the results, a 32-byte bvcf_site per line
+template <bool kCensus, bool kPacked = false>
 __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_tiles, const uint32_t n_chunks) {
   constexpr uint32_t kLead = kCensus ? kS2Lead : kS1Lead;
   constexpr uint32_t kTile = kS1Win - kLead;
@@ -153,8 +157,13 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
   const uint32_t cap_off = (a.cap - 16u) & ~3u;
   uint32_t *const st_l1 = a.census + s1_l1_off();
   uint16_t *const st_l0 = reinterpret_cast<uint16_t *>(a.census + s1_l0_off(gridDim.x));
-  // records past a line's first: behind the lines' slots -- whose number only the census knows in advance
-  const uint32_t extras_at = kCensus ? min(a.counters->n_lines, a.max_lines) : a.max_lines;
+  // the packed form (bvcf_params.packed_sites, k_sites2 only): a 32-byte bvcf_site per line, full records only for the
+  // lines that leave the fast lanes, in slots handed out per round
+  constexpr bool packed = kPacked;
+  static_assert(kCensus || !kPacked, "the packed form is k_sites2's");
+  // records past a line's first: behind the lines' slots -- whose number only the census knows in advance (packed: how
+  // many lines get full records is not known either, so there too they follow slot max_lines)
+  const uint32_t extras_at = (kCensus && !packed) ? min(a.counters->n_lines, a.max_lines) : a.max_lines;
 
   // ---- the FILTER gate of the common lines (linePasses, main.go:447-454): up to four allowed values of up to four
   // bytes as dwords, nothing excluded -- prepared on the host (KernelArgs.s1_*).  mode 0: no such table (every line that
@@ -488,8 +497,44 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
       // line records through an LDS scratch, 32 at a time (planes of one 16-byte piece each, skewed by 64 bytes so that
       // the four pieces of a record sit in different banks); the allele records, constants but for three bytes, from a
       // ds_bpermute of those.
-      const unsigned long long smask = __ballot(simple && line < a.max_lines);
-      if (smask) {
+      // ---- the packed form: the round's 64 site records are 2 KiB of consecutive memory.  Every lane puts its record
+      // into the LDS scratch in memory order, the wave copies the scratch out as whole cache lines (lane L stores bytes
+      // [16 L, 16 L + 16) of each KiB).  A line that needs full records gets their slot first (one atomic per round that
+      // has such lines), so that its site record -- "see lines[full_idx]" -- goes out with the others.
+      uint32_t lslot = line;  // slot of the line's full records in lines[] / alleles[]
+      if constexpr (packed) {
+        const unsigned long long gm = __ballot(general && line < a.max_lines);
+        if (gm) {
+          uint32_t got = 0;
+          if (lane == 0) got = atomicAdd(&a.counters->n_full, (uint32_t)__popcll(gm));
+          lslot = bcast0(got) + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull));
+        }
+        uint32_t fb[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (simple) {
+          fb[0] = fb[1] = 0u;
+#pragma unroll
+          for (uint32_t k = 0; k < 8; k++) fb[k >> 2] |= (k < want_k ? fe[k] : 0xFFu) << (8u * (k & 3u));
+        }
+        const uint32_t info = simple ? (ref_b | (alt_b << 8) | ((uint32_t)trtv_of((uint8_t)ref_b, (uint8_t)alt_b) << 16) | (status << 24))
+                                     : ((uint32_t)BVCF_SITE_FULL << 24);
+        uint8_t *const xp = reinterpret_cast<uint8_t *>(S.xpose);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<u32x4 *>(xp + 32u * (uint32_t)lane) = u32x4{ls, len, fb[0], fb[1]};
+        *reinterpret_cast<u32x4 *>(xp + 32u * (uint32_t)lane + 16u) = u32x4{info, simple ? 0u : lslot, n_tabs + 1u, 0u};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t line0 = base + n_done;  // (wave-uniform)
+        const uint32_t room = line0 < a.max_lines ? a.max_lines - line0 : 0u;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+          const uint32_t rec = 32u * h + ((uint32_t)lane >> 1);
+          const u32x4 v = *reinterpret_cast<const u32x4 *>(xp + 1024u * h + 16u * (uint32_t)lane);
+          if (rec < n && rec < room) s2_store(v, reinterpret_cast<u32x4 *>(&a.sites[line0]) + 64u * h + lane);
+        }
+      }
+      const unsigned long long smask = packed ? 0ull : __ballot(simple && line < a.max_lines);
+      if (!packed && smask) {
         const uint32_t line0 = base + n_done;  // (wave-uniform)
         const bool ok = status == BVCF_LINE_OK;
         const u32x4 pc[4] = {u32x4{ls, len, fe[0], fe[1]}, u32x4{fe[2], fe[3], fe[4], fe[5]}, u32x4{fe[6], fe[7], fe[8], 0u},  // .. rec_first
@@ -662,7 +707,7 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
             if (mode == 0) log_err(a, line, 0, BVCF_ERR_SAME);
             if (mode == 3) log_err(a, line, 0, BVCF_ERR_EMPTY_REF);
             const bool fits = (unsigned long long)extra_base + want_rec <= a.max_alleles;
-            auto slot = [&](uint32_t j) -> uint32_t { return j == 0 ? line : extra_base + j - 1; };
+            auto slot = [&](uint32_t j) -> uint32_t { return j == 0 ? lslot : extra_base + j - 1; };
             uint32_t cur = 0, emitted = 0;
             if (mode == 1 || mode == 2) {
 #pragma nounroll
@@ -732,8 +777,8 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
             L.status = (uint8_t)status;
             L.site_type = (uint8_t)site_type;
             L.pad[0] = L.pad[1] = 0;
-            a.lines[line] = L;
-            if (!primary_written && line < a.max_alleles) a.alleles[line].gt_task = kNoTask;
+            a.lines[lslot] = L;
+            if (!primary_written && lslot < a.max_alleles) a.alleles[lslot].gt_task = kNoTask;
           }
         };  // serial
         {
@@ -789,6 +834,7 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
   }
 }
 
+#ifdef BVCF_EXPERIMENTS  // the single-pass attempt, slower than k_sites2 behind its census: kept for A/B builds
 __global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sites1(KernelArgs a, uint32_t n_tiles, uint32_t first_wgs, uint32_t stagger_ticks) {
   // (experiment: the workgroups that fill the GPU when the kernel starts do not start together -- all at once they ask
   // for 25 MB of text in one burst and every one of them then waits for the slowest load of the burst, whose count is
@@ -797,8 +843,9 @@ __global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(3, 3
     const unsigned long long until = wall_clock64() + (unsigned long long)blockIdx.x * stagger_ticks / first_wgs;
     while (wall_clock64() < until) __builtin_amdgcn_s_sleep(4);
   }
-  s1_body<false>(a, n_tiles, 0u);
+  s1_body<false, false>(a, n_tiles, 0u);
 }
+#endif  // BVCF_EXPERIMENTS
 
 // k_sites2's own census: terminators per TILE, one wave per tile and seven chunk loads in flight; census[t] then goes
 // through k_scan_top alone (20 k values per 142 MB: one workgroup's work), where the per-chunk census needs two scan levels
@@ -880,12 +927,18 @@ __global__ __launch_bounds__(1024) void k_scan_flat(KernelArgs a, uint32_t n) {
     a.counters->cmap_maps = 0;
     a.counters->pad[0] = a.counters->pad[1] = 0;
     a.counters->n_finish = 0;
+    a.counters->n_full = 0;
     a.line_off[0] = 0u;
   }
 }
 
 __global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(BVCF_S2_WAVES_EU, BVCF_S2_WAVES_EU))) void k_sites2(KernelArgs a, uint32_t n_tiles, uint32_t n_chunks) {
-  s1_body<true>(a, n_tiles, n_chunks);
+  s1_body<true, false>(a, n_tiles, n_chunks);
+}
+
+// ... with the packed form of the results (bvcf_params.packed_sites): 32 bytes per line instead of 128
+__global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(BVCF_S2_WAVES_EU, BVCF_S2_WAVES_EU))) void k_sites2p(KernelArgs a, uint32_t n_tiles, uint32_t n_chunks) {
+  s1_body<true, true>(a, n_tiles, n_chunks);
 }
 
 }  // namespace bvcf_dev

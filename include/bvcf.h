@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BVCF_ABI_VERSION 5
+#define BVCF_ABI_VERSION 6
 
 typedef enum {
   BVCF_OK = 0,
@@ -124,6 +124,12 @@ typedef struct {
                                  "GT:DP:..."): the first batch already takes the kernel for such lines.  bvcf_submit
                                  finds that out from a host block by itself; a device-resident or BGZF first batch
                                  cannot be looked at before it is launched */
+  uint32_t packed_sites;      /* files WITHOUT sample columns (n_header_fields <= 9): 1 = return the packed form of the
+                                 batch -- one 32-byte bvcf_site per line (bvcf_result.sites) and full bvcf_line /
+                                 bvcf_allele records only for the lines that need them (anything but a plain SNP).  A
+                                 sites-only line is ~140 bytes of text; its full records are 128.  Ignored (sites == NULL)
+                                 when the file has samples */
+  uint32_t reserved;
 } bvcf_params;
 
 /* one input line; 64 bytes */
@@ -165,6 +171,25 @@ typedef struct {
   uint32_t gt_task;    /* internal: genotype-scan task that produced ac..n_miss */
   uint32_t pad2;
 } bvcf_allele;
+
+/* packed form of one line of a file without samples (bvcf_params.packed_sites); 32 bytes.  Without BVCF_SITE_FULL the
+ * line is settled here: status is its verdict (BVCF_LINE_OK / FIELDS / FILTER) and, when OK, it is a biallelic SNP whose
+ * single output allele is {pos = the POS field verbatim, ref, alt_base, trtv, alt_idx 0, type SNP} -- main.go:735-745;
+ * every TAB that bounds a fixed column lies in the line's first 64 bytes.  With BVCF_SITE_FULL the line's records are
+ * lines[full_idx] / alleles[full_idx] (+ alleles[lines[full_idx].rec_first ..]) as in the unpacked form. */
+#define BVCF_SITE_FULL 0x80u
+typedef struct {
+  uint32_t off;        /* line start, bytes from block start */
+  uint32_t len;        /* bytes without the terminator */
+  uint8_t fend[8];     /* end (exclusive, relative to off) of fields 0..7; 0xFF = len (the line's last field, or missing) */
+  uint8_t ref;
+  uint8_t alt_base;
+  uint8_t trtv;        /* 0 / 1 / 2 (main.go:602-606) */
+  uint8_t status;      /* BVCF_LINE_OK / BVCF_LINE_FIELDS / BVCF_LINE_FILTER, or BVCF_SITE_FULL */
+  uint32_t full_idx;   /* BVCF_SITE_FULL: index into lines[] (and of the line's first record in alleles[]) */
+  uint32_t n_fields;   /* len(record) */
+  uint32_t reserved;
+} bvcf_site;
 
 /* one message getAlleles would log; 16 bytes */
 typedef struct {
@@ -226,6 +251,13 @@ typedef struct {
   const uint8_t *text;
   uint64_t n_text_bytes;
   const uint32_t *head_off;  /* [n_lines]; entries of lines that did not pass (status FIELDS / FILTER) are undefined */
+  /* bvcf_params.packed_sites on a file without samples: sites[i] describes line i (n_lines of them); lines[] then
+   * holds only the n_full_lines records of the lines marked BVCF_SITE_FULL, in no particular order (lines[j].gt_task is
+   * the line number), alleles[j] is the first output allele of lines[j], and the further alleles of such lines sit past
+   * the slots of the lines as always (lines[j].rec_first).  bvcf_err.line stays the line number.  NULL otherwise. */
+  const bvcf_site *sites;
+  uint32_t n_full_lines;
+  uint32_t reserved3;
 } bvcf_result;
 
 /* ---- lifecycle ---- */

@@ -1,6 +1,7 @@
 """The kernels for sites-only input (no sample columns; BASELINE configs[1]) -- k_sites2, tiles behind the newline
-census with the common lines on fast lanes (the default); k_sites1, the same without the census, the line numbers from
-a look-back over tile counts (BVCF_SITES=3); k_sites, round 2's kernel (BVCF_SITES=1) --:
+census with the common lines on fast lanes, with the packed form of the results (32-byte site records, ABI 6: the
+default of the host driver) and with the full one; in builds with -DBVCF_EXPERIMENTS also k_sites1, the same without the
+census, the line numbers from a look-back over tile counts (BVCF_SITES=3), and k_sites, round 2's kernel (BVCF_SITES=1) --:
 lines of every length around their 8 KiB windows, tiles and runs that start in the middle of a line, rounds of more
 than 64 lines, and agreement with the census chain they replace (BVCF_SITES=0: k_scatter_eol + k_head)."""
 import random
@@ -22,12 +23,17 @@ def bv():
     return b
 
 
-@pytest.fixture(autouse=True, params=["k_sites2", "k_sites2-chunk-census", "k_sites1", "k_sites"])
-def kernel(request, monkeypatch):
-    """k_sites2 behind its census per tile (k_count_tiles, the default) and behind the per-chunk census of the other chains"""
-    monkeypatch.setenv("BVCF_SITES", {"k_sites2": "2", "k_sites2-chunk-census": "2", "k_sites1": "3", "k_sites": "1"}[request.param])
-    monkeypatch.setenv("BVCF_S2_CENSUS", "chunk" if request.param == "k_sites2-chunk-census" else "tile")
-    return request.param
+@pytest.fixture(autouse=True, params=["k_sites2-packed", "k_sites2-packed-chunk-census", "k_sites2", "k_sites2-chunk-census", "k_sites1", "k_sites"])
+def kernel(request, monkeypatch, bv):
+    """k_sites2 behind its census per tile (k_count_tiles, the default) and behind the per-chunk census of the other chains,
+    each with the packed and with the full form of the results"""
+    name = request.param
+    if name in ("k_sites1", "k_sites") and b"experiments" not in bv.lib.bvcf_version():
+        pytest.skip("%s is only in builds with -DBVCF_EXPERIMENTS" % name)
+    monkeypatch.setenv("BVCF_SITES", {"k_sites1": "3", "k_sites": "1"}.get(name, "2"))
+    monkeypatch.setenv("BVCF_S2_CENSUS", "chunk" if name.endswith("chunk-census") else "tile")
+    monkeypatch.setenv("BVCF_PACKED_SITES", "1" if "packed" in name else "0")
+    return name
 
 
 def both(bv, vcf, cfg=None, **kw):
@@ -136,7 +142,7 @@ def test_sites_nine_header_fields(bv):
     assert out.count(b"\n") > 1500
 
 
-def test_sites_bench_shape_runs_of_many_windows(bv):
+def test_sites_bench_shape_runs_of_many_windows(bv, kernel):
     """BASELINE configs[1] rows from the bench generator, 300 000 of them (45 MB: several windows per wave, most runs
     start in the middle of a line), against the oracle; and the census chain it replaces gives the same records"""
     import benchgen as bg
@@ -147,9 +153,12 @@ def test_sites_bench_shape_runs_of_many_windows(bv):
     rc_g, out_g, log_g, n_g = bv.run_buffer(vcf)
     assert rc_g == 0 and n_g == n_o == 300_000 and out_g == out_o and log_g == log_o
     n_hdr = bg.n_header_fields(cfg)
-    ctx = bv.Ctx(n_hdr, max_batch_bytes=len(body))
+    ctx = bv.Ctx(n_hdr, max_batch_bytes=len(body), packed_sites="packed" in kernel)
     new = ctx.process(body)
     ctx.close()
+    assert (new.sites is not None) == ("packed" in kernel)
+    if new.sites is not None:
+        assert len(new.full_lines) == 0, "bench rows are all plain SNPs: no line needs full records"
     import os
     mine = os.environ["BVCF_SITES"]
     os.environ["BVCF_SITES"] = "0"
@@ -169,7 +178,7 @@ def test_sites_bench_shape_runs_of_many_windows(bv):
 def test_sites_block_of_many_scan_steps(bv, kernel):
     """a sites-only block of 1.9 M rows = 270 MB: 37 k tiles, i.e. more than k_scan_flat's one step of 32 768 values (the
     carry between steps), line numbers past 2^20 -- against the census chain with k_head on the same block"""
-    if kernel not in ("k_sites2", "k_sites2-chunk-census"):
+    if not kernel.startswith("k_sites2"):
         pytest.skip("k_sites2 behind its two censuses")
     import os
     import benchgen as bg
@@ -178,7 +187,7 @@ def test_sites_block_of_many_scan_steps(bv, kernel):
     body = bg.rows_host(cfg, 5_000_000, n)
     assert len(body) > 32_768 * 7168
     n_hdr = bg.n_header_fields(cfg)
-    ctx = bv.Ctx(n_hdr, max_batch_bytes=len(body), max_lines=n + 16)
+    ctx = bv.Ctx(n_hdr, max_batch_bytes=len(body), max_lines=n + 16, packed_sites="packed" in kernel)
     new = ctx.process(body)
     ctx.close()
     mine = os.environ["BVCF_SITES"]
@@ -194,3 +203,54 @@ def test_sites_block_of_many_scan_steps(bv, kernel):
         assert (new.lines[f] == old.lines[f]).all(), f
     for f in ("pos", "line", "alt_idx", "alt_len", "ref", "alt_base", "kind", "site_type", "trtv", "flags"):
         assert (new.alleles[:n][f] == old.alleles[:n][f]).all(), f
+
+
+def test_packed_form_record_by_record(bv, kernel):
+    """ABI 6: the packed form (a 32-byte bvcf_site per line, full records only for the lines that need them) describes
+    every line exactly as the full form of the census chain does -- lines of all kinds, in rounds where packed and full
+    lines mix, with messages to log"""
+    if "packed" not in kernel:
+        pytest.skip("the packed form")
+    import os
+    rng = random.Random(23)
+    rows, pos = [], 500
+    for i in range(20000):
+        pos += rng.randint(1, 50)
+        rows.append(_line(rng, pos, kind=None if i % 3 else 0.1))
+    body = ("\n".join(rows) + "\n").encode()
+    ctx = bv.Ctx(8, allow="PASS,.", max_batch_bytes=len(body), packed_sites=True)
+    new = ctx.process(body)
+    ctx.close()
+    mine = os.environ["BVCF_SITES"]
+    os.environ["BVCF_SITES"] = "0"
+    try:
+        ctx = bv.Ctx(8, allow="PASS,.", max_batch_bytes=len(body))
+        old = ctx.process(body)
+        ctx.close()
+    finally:
+        os.environ["BVCF_SITES"] = mine
+    assert new.sites is not None and old.sites is None
+    n = len(old.lines)
+    assert len(new.lines) == n == 20000
+    full = (new.sites["status"] & bv.SITE_FULL) != 0
+    assert 0 < full.sum() < n and len(new.full_lines) == full.sum()
+    # a line stays packed exactly when it is settled without getAlleles' general code: failed the gate, or a plain SNP
+    for i in range(n):
+        L = old.lines[i]
+        if not full[i]:
+            assert L["status"] in (bv.LINE_OK, bv.LINE_FIELDS, bv.LINE_FILTER)
+            if L["status"] == bv.LINE_OK:
+                r = old.records(i)
+                assert len(r) == 1 and r[0]["kind"] == bv.ALT_BASE and r[0]["site_type"] == 0 and r[0]["flags"] & 1
+    for f in ("off", "len", "n_rec", "status"):
+        assert (new.lines[f] == old.lines[f]).all(), f
+    ok = old.lines["status"] == bv.LINE_OK
+    assert (new.lines["fend"][ok] == old.lines["fend"][ok]).all()
+    assert (new.lines["site_type"][ok] == old.lines["site_type"][ok]).all()
+    for i in np.nonzero(ok)[0]:
+        a, b = new.records(i), old.records(i)
+        assert len(a) == len(b)
+        for f in ("pos", "alt_idx", "alt_off", "alt_len", "ref", "alt_base", "kind", "site_type", "trtv", "flags"):
+            assert (a[f] == b[f]).all(), (i, f)
+    key = lambda e: (int(e["line"]), int(e["alt_no"]), int(e["code"]))
+    assert sorted(map(key, new.errs)) == sorted(map(key, old.errs)) and len(old.errs) > 0
