@@ -262,14 +262,16 @@ __device__ inline bool next_token(const AlleleCtxT<B> &c, uint32_t *cursor, Span
   return true;
 }
 
-__device__ inline void log_err(const KernelArgs &a, uint32_t line, uint32_t alt_no, uint32_t code) {
+// ord: the message's place among its line's (the ALT index it is about), for callers whose lanes log a line's messages
+// in no particular order (k_head: one lane per ALT token); 0 where one lane logs them in order
+__device__ inline void log_err(const KernelArgs &a, uint32_t line, uint32_t alt_no, uint32_t code, uint32_t ord = 0u) {
   uint32_t i = atomicAdd(&a.counters->n_errs, 1u);
   if (i < a.max_errs) {
     bvcf_err e;
     e.line = line;
     e.alt_no = alt_no;
     e.code = code;
-    e.pad = 0;
+    e.pad = ord;
     a.errs[i] = e;
   }
 }

@@ -138,6 +138,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   return v;
 }
 
+// running maximum over the 64 lanes (values >= 0; the same DPP steps as the sum)
+__device__ __forceinline__ uint32_t wave_incl_scan_max(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+  return v;
+}
+
 // value of lane `src` (wave-uniform index) in every lane's scalar view: v_readlane, no LDS
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int src) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, src);

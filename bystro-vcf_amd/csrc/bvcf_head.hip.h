@@ -14,7 +14,15 @@ namespace bvcf_dev {
 constexpr int kGroup = 16;                       // lanes per line in k_head
 constexpr int kGroupsPerWg = kWgThreads / kGroup;
 constexpr uint32_t kWindow = kGroup * 16;        // bytes per group step
-constexpr uint32_t kHeadStage = 128;             // line-head bytes kept in LDS for the serial phase
+// Line-head bytes kept in LDS for the serial phase.  CHROM..FILTER of a 1000-Genomes line are ~40 bytes; what lies past
+// the staged bytes (a long indel, INFO) is read from memory.  64 instead of 128 bytes: 36 KB of LDS per workgroup instead
+// of 52, four workgroups per CU instead of three -- k_head_lean alone 109 -> 91 us per 262 144 rows of configs[3], 63 ->
+// 54 us on biallelic rows (round 4, profiles/r04_k_head_*; the kernel is one latency-bound step per workgroup, so what
+// counts is how many of its 1 024 workgroups are resident at once).
+#ifndef BVCF_HEAD_STAGE
+#define BVCF_HEAD_STAGE 64
+#endif
+constexpr uint32_t kHeadStage = BVCF_HEAD_STAGE;
 
 __device__ __forceinline__ int glane() { return threadIdx.x & (kGroup - 1); }
 
@@ -421,24 +429,33 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     const uint32_t map_base = a.fused ? s_base[2] + task_rank : task_base;
 
     HSTAMP(3);
-    // ---- part 2: evaluate the ALT tokens, write records and scan tasks
+    // ---- part 2: the ALT tokens -> records and scan tasks, ONE LANE PER (line, ALT token) PAIR.
+    // The reference walks a line's ALT tokens one after the other (main.go:774-999).  With one lane per line a wave that
+    // holds a single multiallelic line ran the token loop three times with one lane working -- k_head's time followed the
+    // number of waves that hold such a line, not their number (47 -> 69 us per 262 144 rows at 2 % multiallelic lines).
+    // Here the tokens of the wave's 64 lines are numbered (exclusive scan of the token counts) and dealt to the lanes,
+    // 64 pairs per round: a biallelic wave is one round with lane == line, a wave of BASELINE configs[3] (20 % lines
+    // with 2-3 ALTs) two rounds instead of three or four passes.  What the sequential loop carries from token to
+    // token -- records emitted so far, task slots used, "Invalid POS" ending the loop -- becomes prefix sums over the
+    // lanes of a line (segments of consecutive lanes); a line that straddles two rounds carries its sums in its own lane.
+    const bool has_tok = eval && (mode == 1 || mode == 2);
     if (eval) {
       if (mode == 0) log_err(a, line, 0, BVCF_ERR_SAME);
       if (mode == 3) log_err(a, line, 0, BVCF_ERR_EMPTY_REF);
-      const bool fits = (unsigned long long)extra_base + want_rec <= a.max_alleles;
-      // slot of this line's j-th record
-      auto slot = [&](uint32_t j) -> uint32_t { return j == 0 ? line : extra_base + j - 1; };
-
-      // With samples, the scan for ALT #1 always runs: it also settles len(record) == len(header).
-      // On the streaming path k_stream has already done it (results[line], line_cmap[line]).
-      uint32_t cm0 = BVCF_NO_CMAP;
+    }
+    const bool fits = (unsigned long long)extra_base + want_rec <= a.max_alleles;
+    // With samples, the scan for ALT #1 always runs: it also settles len(record) == len(header).
+    // On the streaming path k_stream has already done it (results[line], line_cmap[line]).
+    uint32_t cm0 = BVCF_NO_CMAP;
+    uint32_t task0 = line;  // where ALT #1's counts are (to be) found
+    uint32_t tasks_used = 0, emitted = 0, stype_line = 0;
+    bool dropped = false;  // "Invalid POS" ended the line's token loop (main.go:826-829)
+    if (eval) {
       if (ns > 0 && !a.fused) {
-        cm0 = cmap_of(a, line, maps && (mode == 1 || mode == 2));
+        cm0 = cmap_of(a, line, maps && has_tok);
         put_task(a, line, line, 1, s_begin, cend, cm0);
         task_written = true;
       }
-      uint32_t task0 = line;  // where ALT #1's counts are (to be) found
-      uint32_t tasks_used = 0;
       if (ns > 0 && a.fused) {
         if (deferred) {
           task0 = task_base;
@@ -450,117 +467,209 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         }
       }
       first_task = task0;
-      // Streaming path: the counts of ALT #1 of a line k_stream scanned are final (results[line]), as are those of the
-      // further ALT indices resolved from class lists below: such records are complete here.  A line with records that
-      // still depend on k_gt is on k_finish's work list (above).
-      const bool final0 = a.fused && ns > 0 && !deferred && line < a.max_tasks;
-      GtResult g0 = GtResult{};
-      if (final0) g0 = a.results[line];
-
-      uint32_t cur = 0, emitted = 0;
-      if (mode == 1 || mode == 2) {
+    }
+    // Streaming path: the counts of ALT #1 of a line k_stream scanned are final (results[line]), as are those of the
+    // further ALT indices resolved from class lists below: such records are complete here.  A line with records that
+    // still depend on k_gt is on k_finish's work list (above).
+    const bool final0 = eval && a.fused && ns > 0 && !deferred && line < a.max_tasks;
+    {
+      const uint32_t n_tok = has_tok ? (mode == 1 ? 1u : n_commas + 1u) : 0u;
+      uint32_t n_pairs;
+      const uint32_t pair0 = wave_excl_scan(n_tok, &n_pairs);  // the line's tokens are pairs [pair0, pair0 + n_tok)
+      const uint32_t lflags = mode | (deferred ? 4u : 0u) | (fits ? 8u : 0u) | (final0 ? 16u : 0u);
+      uint32_t *const s_mark = &s_found[(uint32_t)w * kWave];  // (s_found was consumed above: this wave's 64 words)
 #pragma nounroll
-        for (uint32_t k = 0;; k++) {
-          AlleleEval e;
-          Span t;
-          if (mode == 1) {
-            if (k > 0) break;
+      for (uint32_t q0 = 0; q0 < n_pairs; q0 += kWave) {
+        // ---- who owns lane p's pair: the lines with tokens in this round leave their lane number where those start
+        const bool mine = n_tok && pair0 < q0 + kWave && pair0 + n_tok > q0;
+        const uint32_t seg0 = pair0 > q0 ? pair0 - q0 : 0u;  // lane of the first of them
+        s_mark[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (mine) s_mark[seg0] = (uint32_t)lane + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n_here = min(n_pairs - q0, (uint32_t)kWave);
+        const bool pl = (uint32_t)lane < n_here;
+        const uint32_t mk = wave_incl_scan_max(s_mark[lane]);
+        const uint32_t o = (pl && mk) ? mk - 1u : (uint32_t)lane;  // the owner's lane
+        auto from_owner = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(o * 4u), (int)v); };
+        const uint32_t o_pair0 = from_owner(pair0), o_flags = from_owner(lflags), o_commas = from_owner(n_commas);
+        const uint32_t o_extra = from_owner(extra_base), o_task = from_owner(task_base), o_map = from_owner(map_base);
+        const uint32_t o_task0 = from_owner(task0), o_cm0 = from_owner(cm0);
+        const uint32_t o_emitted = from_owner(emitted), o_used = from_owner(tasks_used), o_dropped = from_owner(dropped ? 1u : 0u);
+        const uint32_t k = q0 + (uint32_t)lane - o_pair0;  // ALT index of this lane's token
+        const uint32_t o_mode = o_flags & 3u;
+        const bool o_deferred = (o_flags & 4u) != 0, o_fits = (o_flags & 8u) != 0, o_final0 = (o_flags & 16u) != 0;
+        // the owner's line: its bytes and fixed columns are in the LDS of this workgroup step
+        const uint32_t oll = (uint32_t)w * kWave + o, o_line = line0 + oll;
+        const uint32_t o_ls = s_ls[oll], o_cend = o_ls + (s_len[oll] & ~kHasHeadBits);
+        const uint32_t *otab = &s_tab[oll * kTabRow];
+        AlleleCtx c;
+        c.buf.g = a.buf;
+        c.buf.lds = as_lds(&s_head[oll * kHeadRow]);
+        c.buf.lo = o_ls;
+        c.buf.sub = o_ls;
+        c.buf.n = pl ? s_staged[oll] : 0u;
+        const Bytes &ob = c.buf;
+        c.chrom = Span{o_ls, otab[0] - o_ls};
+        c.pos = Span{otab[0] + 1u, otab[1] - otab[0] - 1u};
+        c.ref = Span{otab[2] + 1u, otab[3] - otab[2] - 1u};
+        c.alt = Span{otab[3] + 1u, (need > 4u ? otab[4] : o_cend) - otab[3] - 1u};
+        c.int_pos = 0;
+        c.pos_bad = false;
+        c.line = o_line;
+        const uint32_t o_sbegin = need == 9 ? otab[8] + 1u : o_cend;
+
+        // ---- this lane's token
+        AlleleEval e = AlleleEval{};
+        Span t = c.alt;
+        if (pl) {
+          if (o_mode == 1) {
             eval_single(c, e);
-            t = c.alt;
           } else {
-            if (!next_token(c, &cur, &t)) break;
+            uint32_t i = 0, seen = 0, start = 0;
+#pragma nounroll
+            for (; i < c.alt.len && seen < k; i++)
+              if (ob[c.alt.off + i] == ',') {
+                seen++;
+                start = i + 1u;
+              }
+            uint32_t end = start;
+#pragma nounroll
+            while (end < c.alt.len && ob[c.alt.off + end] != ',') end++;
+            t.off = c.alt.off + start;
+            t.len = end - start;
             eval_token(c, t, e);
           }
-          if (e.err) log_err(a, line, (e.err == BVCF_ERR_POS) ? 0u : k + 1u, e.err);
-          if (e.stop) break;
-          if (!e.n) continue;
-          uint32_t task = task0, cm_off = cm0;
-          const GtResult *gr = (k == 0 && final0) ? &g0 : nullptr;
-          GtResult r = GtResult{};
-          if (ns > 0 && k > 0) {
-            task = task_base + tasks_used;
-            // Streaming path, a line k_stream kept as a list of its few non-reference samples: the same entries gave
-            // the class list of every further ALT index they carry (finish_list), so the line is not read again
-            // (the reference rescans it once per allele, main.go:549-556).  The counts come from the list.
-            bool resolved = false;
-            const bool raw = a.fused && !deferred && cm0 != BVCF_NO_CMAP && (cm0 & 15u) == kRawEnc;
-            if (a.fused && !deferred && cm0 != BVCF_NO_CMAP && (cm0 & 15u) && !raw && task < a.max_tasks) {
-              // bit 0: ALT #1 is a class list and the lists of ALT #2..#kmax follow it in the slot (kmax - 1 in bits 1-3).
-              // Otherwise ALT #1 is a dense map and bits 1-3 = 1: no sample carries a further allele (finish_list,
-              // finish_dense; kRawEnc: some do, and k_gt settles them from the entries saved behind the slot)
-              const bool in_slot = (cm0 & 1u) != 0;
-              const uint32_t kmax = in_slot ? ((cm0 >> 1) & 7u) + 1u : 1u;
-              const GtResult first = g0;
-              r.ac = 0;
-              r.an = first.an;
-              r.n_het = r.n_hom = 0;
-              r.n_miss = first.n_miss;
-              r.n_fields = first.n_fields;
-              r.regular = 1;
-              r.pad = 0;
-              if (k + 1u <= kmax) {
-                cm_off = ((cm0 & ~15u) + 64u * k) | 1u;
-                const uint32_t *list = reinterpret_cast<const uint32_t *>(a.cmap + (cm_off & ~15u));
-                const uint32_t n = min(list[0], (uint32_t)BVCF_CMAP_SPARSE_MAX);
+        }
+        // ---- what the tokens before it in the line did (exclusive sums over the line's lanes of this round, plus what
+        // the line carries from the round before)
+        const uint32_t seg_lane = o_pair0 > q0 ? o_pair0 - q0 : 0u;
+        auto seg_excl = [&](uint32_t v) -> uint32_t {
+          const uint32_t ex = wave_incl_scan(v) - v;
+          return ex - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(seg_lane * 4u), (int)ex);
+        };
+        const uint32_t stop_me = (pl && e.stop) ? 1u : 0u;
+        const bool dropped_me = o_dropped != 0u || seg_excl(stop_me) != 0u;
+        const bool live = pl && !dropped_me;
+        const uint32_t n_me = live ? e.n : 0u;
+        const uint32_t tk_me = (live && ns > 0 && k > 0 && e.n > 0) ? 1u : 0u;
+        const uint32_t emitted_before = o_emitted + seg_excl(n_me);
+        const uint32_t used_before = o_used + seg_excl(tk_me);
+        uint32_t stype_me = 0;
+
+        if (live) {
+          if (e.err) log_err(a, o_line, (e.err == BVCF_ERR_POS) ? 0u : k + 1u, e.err, k);
+          if (e.n) {
+            uint32_t task = o_task0, cm_off = o_cm0;
+            GtResult g0 = GtResult{};
+            if (o_final0 && ns > 0) g0 = a.results[o_line];
+            const GtResult *gr = (k == 0 && o_final0) ? &g0 : nullptr;
+            GtResult r = GtResult{};
+            if (ns > 0 && k > 0) {
+              task = o_task + used_before;
+              // Streaming path, a line k_stream kept as a list of its few non-reference samples: the same entries gave
+              // the class list of every further ALT index they carry (finish_list), so the line is not read again
+              // (the reference rescans it once per allele, main.go:549-556).  The counts come from the list.
+              bool resolved = false;
+              const bool raw = a.fused && !o_deferred && o_cm0 != BVCF_NO_CMAP && (o_cm0 & 15u) == kRawEnc;
+              if (a.fused && !o_deferred && o_cm0 != BVCF_NO_CMAP && (o_cm0 & 15u) && !raw && task < a.max_tasks) {
+                // bit 0: ALT #1 is a class list and the lists of ALT #2..#kmax follow it in the slot (kmax - 1 in bits 1-3).
+                // Otherwise ALT #1 is a dense map and bits 1-3 = 1: no sample carries a further allele (finish_list,
+                // finish_dense; kRawEnc: some do, and k_gt settles them from the entries saved behind the slot)
+                const bool in_slot = (o_cm0 & 1u) != 0;
+                const uint32_t kmax = in_slot ? ((o_cm0 >> 1) & 7u) + 1u : 1u;
+                r.ac = 0;
+                r.an = g0.an;
+                r.n_het = r.n_hom = 0;
+                r.n_miss = g0.n_miss;
+                r.n_fields = g0.n_fields;
+                r.regular = 1;
+                r.pad = 0;
+                if (k + 1u <= kmax) {
+                  cm_off = ((o_cm0 & ~15u) + 64u * k) | 1u;
+                  const uint32_t *list = reinterpret_cast<const uint32_t *>(a.cmap + (cm_off & ~15u));
+                  const uint32_t n = min(list[0], (uint32_t)BVCF_CMAP_SPARSE_MAX);
 #pragma nounroll
-                for (uint32_t i = 0; i < n; i++) {
-                  const uint32_t b = list[1u + i] & 0xFFu, lo = b & 0x55u, hi = (b >> 1) & 0x55u;
-                  r.n_het += __popc(lo & ~hi);
-                  r.n_hom += __popc(hi & ~lo);
+                  for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t b = list[1u + i] & 0xFFu, lo = b & 0x55u, hi = (b >> 1) & 0x55u;
+                    r.n_het += __popc(lo & ~hi);
+                    r.n_hom += __popc(hi & ~lo);
+                  }
+                  r.ac = r.n_het + 2u * r.n_hom;
+                  resolved = true;
+                } else if (g0.n_miss == 0) {
+                  cm_off = BVCF_NO_CMAP;  // nobody carries it and nobody is missing: ac == 0, the row is dropped (main.go:558-560)
+                  resolved = true;
                 }
-                r.ac = r.n_het + 2u * r.n_hom;
-                resolved = true;
-              } else if (first.n_miss == 0) {
-                cm_off = BVCF_NO_CMAP;  // nobody carries it and nobody is missing: ac == 0, the row is dropped (main.go:558-560)
-                resolved = true;
+                if (resolved) {
+                  a.results[task] = r;
+                  put_task(a, task, o_line, 0, o_cend, o_cend, BVCF_NO_CMAP);  // nothing to scan
+                  gr = &r;
+                }
               }
-              if (resolved) {
-                a.results[task] = r;
-                put_task(a, task, line, 0, cend, cend, BVCF_NO_CMAP);  // nothing to scan
-                gr = &r;
+              if (raw) {
+                // k_gt classifies the line's saved entries for this allele instead of reading the line again
+                resolved = true;
+                cm_off = cmap_of(a, o_map + used_before, maps);
+                put_task(a, task, o_line, k + 1, (o_cm0 & ~15u) + a.cmap_stride, o_cend, cm_off, kRawTask);
+              }
+              if (!resolved) {
+                cm_off = cmap_of(a, o_map + used_before, maps);
+                put_task(a, task, o_line, k + 1, o_sbegin, o_cend, cm_off);
               }
             }
-            if (raw) {
-              // k_gt classifies the line's saved entries for this allele instead of reading the line again
-              resolved = true;
-              cm_off = cmap_of(a, map_base + tasks_used, maps);
-              put_task(a, task, line, k + 1, (cm0 & ~15u) + a.cmap_stride, cend, cm_off, kRawTask);
-            }
-            if (!resolved) {
-              cm_off = cmap_of(a, map_base + tasks_used, maps);
-              put_task(a, task, line, k + 1, s_begin, cend, cm_off);
-            }
-            tasks_used++;
-          }
-          if (ns == 0) task = kNoTask;
-          if (fits) {
-            // type call, main.go:1004-1037 (single-ALT path: main.go:743,764)
-            uint8_t stype;
-            if (n_commas > 0)
-              stype = BVCF_SITE_MULTI;
-            else if (!e.mnp && e.kind == BVCF_ALT_DEL)
-              stype = BVCF_SITE_DEL;
-            else if (!e.mnp && e.kind == BVCF_ALT_INS)
-              stype = BVCF_SITE_INS;
-            else
-              stype = e.n > 1 ? BVCF_SITE_MNP : BVCF_SITE_SNP;
-            site_type = stype;
-            if (e.mnp) {
-              uint32_t j = 0;
+            if (ns == 0) task = kNoTask;
+            if (o_fits) {
+              // type call, main.go:1004-1037 (single-ALT path: main.go:743,764)
+              uint8_t stype;
+              if (o_commas > 0)
+                stype = BVCF_SITE_MULTI;
+              else if (!e.mnp && e.kind == BVCF_ALT_DEL)
+                stype = BVCF_SITE_DEL;
+              else if (!e.mnp && e.kind == BVCF_ALT_INS)
+                stype = BVCF_SITE_INS;
+              else
+                stype = e.n > 1 ? BVCF_SITE_MNP : BVCF_SITE_SNP;
+              stype_me = stype;
+              // slot of the line's j-th record
+              auto slot = [&](uint32_t j) -> uint32_t { return j == 0 ? o_line : o_extra + j - 1; };
+              if (e.mnp) {
+                uint32_t j = 0;
 #pragma nounroll
-              for (uint32_t i = 0; i < c.ref.len; i++) {
-                const uint8_t rb = hb[c.ref.off + i], ab = hb[t.off + i];
-                if (rb == ab) continue;
-                write_allele(a, slot(emitted + j), line, k, e, c.int_pos + (long long)i, rb, ab, stype, task, cm_off, gr);
-                j++;
+                for (uint32_t i = 0; i < c.ref.len; i++) {
+                  const uint8_t rb = ob[c.ref.off + i], ab = ob[t.off + i];
+                  if (rb == ab) continue;
+                  write_allele(a, slot(emitted_before + j), o_line, k, e, c.int_pos + (long long)i, rb, ab, stype, task, cm_off, gr);
+                  j++;
+                }
+              } else {
+                write_allele(a, slot(emitted_before), o_line, k, e, e.pos, e.ref, e.alt_base, stype, task, cm_off, gr);
               }
-            } else {
-              write_allele(a, slot(emitted), line, k, e, e.pos, e.ref, e.alt_base, stype, task, cm_off, gr);
             }
           }
-          emitted += e.n;
+        }
+        // ---- back to the lines: the sums up to and including the last of their tokens in this round
+        const uint32_t seg_end = min(pair0 + n_tok, q0 + (uint32_t)kWave) - q0 - 1u;  // (meaningful where `mine`)
+        const uint32_t from = (mine ? seg_end : (uint32_t)lane) * 4u;
+        const uint32_t em_in = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from, (int)(emitted_before + n_me));
+        const uint32_t us_in = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from, (int)(used_before + tk_me));
+        const uint32_t dr_in = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from, (int)((dropped_me || stop_me) ? 1u : 0u));
+        // (a line of one token takes that lane's type; with several tokens it is MULTIALLELIC, main.go:1004-1011)
+        const uint32_t st_in = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from, (int)stype_me);
+        if (mine) {
+          emitted = em_in;
+          tasks_used = us_in;
+          dropped = dr_in != 0u;
+          if (n_commas == 0) stype_line = st_in;
         }
       }
+    }
+    if (eval && n_commas > 0 && emitted && fits) stype_line = BVCF_SITE_MULTI;
+    if (eval) {
+      site_type = stype_line;
+      auto slot = [&](uint32_t j) -> uint32_t { return j == 0 ? line : extra_base + j - 1; };
       // reserved but unused slots must not look like records / tasks to the later kernels
       if (fits)
 #pragma nounroll

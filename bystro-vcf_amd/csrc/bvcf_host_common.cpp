@@ -344,7 +344,10 @@ void format_log(const bvcf_result *r, const uint8_t *block, std::string &log) {
   if (!r->n_errs) return;
   std::vector<uint32_t> idx(r->n_errs);
   for (uint32_t i = 0; i < r->n_errs; i++) idx[i] = i;
-  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return r->errs[x].line < r->errs[y].line; });
+  // (bvcf_err.pad: the message's place among its line's, where they were not logged in order)
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+    return r->errs[x].line != r->errs[y].line ? r->errs[x].line < r->errs[y].line : r->errs[x].pad < r->errs[y].pad;
+  });
   bvcf_line tl;
   bvcf_allele ta;
   for (uint32_t i : idx) {

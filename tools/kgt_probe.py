@@ -19,7 +19,8 @@ t, nbytes = bg.rows_device(cfg, 0, rows, pad=bv.DEVICE_PAD)
 ns = cfg.n_samples
 stride = ((ns + 3) // 4 + 15) & ~15
 n_alt = rows * 4 + 1024
-ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=1, max_lines=rows + 16, max_alleles=n_alt,
+# KGT_SLOTS=2: a ctx with two slots takes k_head_lean (the kernel of the default chain); the blocks still run one at a time
+ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=int(os.environ.get("KGT_SLOTS", "1")), max_lines=rows + 16, max_alleles=n_alt,
              cmap_bytes=min((n_alt + nbytes // (4 * ns + 8) + 16 * 8192) * stride + 4096, 0xFFFFFF00))
 chain, scan, counts = ctx.bench_device([t.data_ptr()], [nbytes], 12, slots=1)
 print(over, "chain ms", sum(chain) / len(chain), "counts", list(counts)[:8])
