@@ -842,6 +842,7 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   if (c->max_alleles < c->max_lines + 64) c->max_alleles = c->max_lines + 64;  // slot i belongs to line i
   c->max_cmap = p->cmap_bytes ? p->cmap_bytes : (c->max_lines + c->max_lines / 2) * (uint64_t)c->cmap_stride + (1ull << 20);
   if (c->max_cmap > 0xFFFFFF00ull) c->max_cmap = 0xFFFFFF00ull;  // cmap_off is 32-bit
+  if (c->max_cmap < 4096) c->max_cmap = 4096;  // (k_gt's prefetch reads a raw-list area's worth from the start of the arena)
   c->max_cmap = (c->max_cmap + 63) & ~63ull;
   // streaming path: lines are found by the genotype scan itself.  Its tile-local entry quota is
   // bounded because a line that passes the field count is at least n_header - 1 bytes long; for
