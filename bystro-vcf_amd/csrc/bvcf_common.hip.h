@@ -118,6 +118,10 @@ struct KernelArgs {
   uint32_t s1_fkey[4], s1_flen[4];
 };
 constexpr uint32_t kHasHeadBits = 0x80000000u;
+// StreamEntry.len only (k_order takes it out): the line's counts are right but its class map does not tell the dosage
+// (haploid calls, fields of other ploidy) -- GtResult.regular = 0, k_dosage scans the line itself.  (A line is far
+// shorter than 1 GiB.)
+constexpr uint32_t kNotRegular = 0x40000000u;
 
 // ------------------------------------------------------------------ wave helpers
 

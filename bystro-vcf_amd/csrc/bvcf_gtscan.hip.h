@@ -11,24 +11,31 @@ namespace bvcf_dev {
 
 // Exact restatement of one sample field of makeHetHomozygotes (main.go:1057-1190) for the
 // allele whose decimal text is itoa(a): byte-serial, used for irregular lines.
-// p = field start, cend = end of line content; a field ends at '\t' or cend.
-__device__ inline void classify_field(const uint8_t *buf, uint32_t p, uint32_t cend, uint32_t a, uint32_t a_ndigits,
-                                      uint32_t *cls, uint32_t *altc, uint32_t *gtc) {
-  auto getc = [&](uint32_t q) -> uint32_t { return q < cend ? (uint32_t)buf[q] : (uint32_t)'\t'; };
+// getc(i) = byte i of the field, '\t' from the field's end on.  *max_allele (optional): the highest allele number among
+// the field's tokens that are plain decimal numbers, 15 at most (what k_stream_gen needs to know before it promises
+// k_head that no sample carries a further ALT index).
+template <class G>
+__device__ inline void classify_field_g(G getc, uint32_t a, uint32_t a_ndigits, uint32_t *cls, uint32_t *altc, uint32_t *gtc,
+                                        uint32_t *max_allele = nullptr) {
   *altc = 0;
   *gtc = 0;
   *cls = BVCF_CLS_NONE;
+  if (max_allele) *max_allele = 0;
   // fast gate, main.go:1063-1064: (len == 3 || g[3] == ':') && g[1] in {'|','/'}
-  uint32_t c0 = getc(p), c1 = '\t', c2 = '\t', c3 = '\t';
+  uint32_t c0 = getc(0), c1 = '\t', c2 = '\t', c3 = '\t';
   if (c0 != '\t') {
-    c1 = getc(p + 1);
+    c1 = getc(1);
     if (c1 != '\t') {
-      c2 = getc(p + 2);
-      if (c2 != '\t') c3 = getc(p + 3);
+      c2 = getc(2);
+      if (c2 != '\t') c3 = getc(3);
     }
   }
   const bool have3 = c0 != '\t' && c1 != '\t' && c2 != '\t';
   if (have3 && (c3 == '\t' || c3 == ':') && (c1 == '|' || c1 == '/')) {
+    if (max_allele) {
+      const uint32_t d0 = c0 - '0', d2 = c2 - '0';
+      *max_allele = max(d0 <= 9u ? d0 : 0u, d2 <= 9u ? d2 : 0u);
+    }
     if (c0 == '0' && c2 == '0') {
       *gtc = 2;
       return;
@@ -58,26 +65,30 @@ __device__ inline void classify_field(const uint8_t *buf, uint32_t p, uint32_t c
   bool has_bar = false, has_slash = false;
   #pragma nounroll
   for (;; nf++) {
-    uint32_t ch = getc(p + nf);
+    uint32_t ch = getc(nf);
     if (ch == '\t' || ch == ':') break;
     has_bar |= ch == '|';
     has_slash |= ch == '/';
   }
   const uint32_t sep = has_bar ? '|' : (has_slash ? '/' : 0xFFFFFFFFu);
-  uint32_t alt_count = 0, gt_count = 0;
+  uint32_t alt_count = 0, gt_count = 0, top = 0;
   // token state
   uint32_t tlen = 0;
   unsigned long long val = 0;
   bool digits = true, lead0 = false, dot = false;
   #pragma nounroll
   for (uint32_t k = 0; k <= nf; k++) {
-    uint32_t ch = k < nf ? getc(p + k) : sep;
+    uint32_t ch = k < nf ? getc(k) : sep;
     if (k == nf || ch == sep) {
       if (tlen == 1 && dot) {  // allele == "." => whole sample missing, nothing counted
         *cls = BVCF_CLS_MISSING;
+        if (max_allele) *max_allele = top;
         return;
       }
-      if (tlen >= 1 && tlen <= 10 && digits && !lead0 && val == (unsigned long long)a) alt_count++;
+      if (tlen >= 1 && tlen <= 10 && digits && !lead0) {
+        if (val == (unsigned long long)a) alt_count++;
+        top = max(top, (uint32_t)(val < 15ull ? val : 15ull));
+      }
       gt_count++;
       tlen = 0;
       val = 0;
@@ -99,7 +110,14 @@ __device__ inline void classify_field(const uint8_t *buf, uint32_t p, uint32_t c
   }
   *gtc = gt_count;
   *altc = alt_count;
+  if (max_allele) *max_allele = top;
   if (alt_count != 0) *cls = alt_count == gt_count ? BVCF_CLS_HOM : BVCF_CLS_HET;
+}
+// p = field start, cend = end of line content; a field ends at '\t' or cend.
+__device__ inline void classify_field(const uint8_t *buf, uint32_t p, uint32_t cend, uint32_t a, uint32_t a_ndigits,
+                                      uint32_t *cls, uint32_t *altc, uint32_t *gtc, uint32_t *max_allele = nullptr) {
+  classify_field_g([&](uint32_t i) -> uint32_t { return p + i < cend ? (uint32_t)buf[p + i] : (uint32_t)'\t'; }, a, a_ndigits, cls, altc, gtc,
+                   max_allele);
 }
 
 // ---- regular sample region: exactly 4 bytes per sample, "x<sep>y<TAB>" ----

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kWgThreads) void k_order(KernelArgs a) {
     if (g >= a.max_lines) continue;
     const StreamEntry en = a.entries[i];
     a.line_off[g] = en.ls;
-    a.line_len[g] = en.len;  // (bit 31: line_bits[g] is valid)
+    a.line_len[g] = en.len & ~kNotRegular;  // (bit 31: line_bits[g] is valid)
     a.line_cmap[g] = en.cmap_off;
     if (en.len & kHasHeadBits) {
       const u32x4 *src = reinterpret_cast<const u32x4 *>(a.head_bits + (size_t)i * 16u);
@@ -503,7 +503,8 @@ __global__ __launch_bounds__(kWgThreads) void k_order(KernelArgs a) {
       r.n_hom = en.n_hom;
       r.n_miss = en.n_miss;
       r.n_fields = en.n_miss == kDeferred ? kDeferred : a.n_header - 9u;
-      r.regular = en.n_miss == kDeferred ? 0u : 1u;  // k_stream only lists counts of lines its regular scan accepted
+      // (k_stream only lists counts of lines its regular scan accepted; k_stream_gen marks lines with haploid / odd fields)
+      r.regular = (en.n_miss == kDeferred || (en.len & kNotRegular)) ? 0u : 1u;
       r.pad = 0;
       a.results[g] = r;
     }

@@ -25,6 +25,12 @@
 // digits or '.'); a line with any other field, or whose field count is not the header's, is listed as deferred
 // and k_gt scans it the byte-serial way, as before.  Counts then follow from the classes: ac = het + 2 hom,
 // an = 2 (samples - missing).
+// (Round 4 tried to keep polyploid / two-digit / empty fields in the kernel as well: a mark in the line's list where such
+// a field is met, the field found again and classified by the general branch's restatement when the line ends.  Parity
+// was green, and the kernel took 19 % longer on every GATK-shaped file (0.645 -> 0.766 ms per 2.4 GB block): it runs at
+// the limit of its scalar registers, and the cold code -- inlined, marked unlikely, or called out of line -- doubled the
+// scalar spills around the hot loop (28 -> 48-60) or cost a wave per SIMD (84 vector registers).  Not kept: such
+// fields are rare, the file shape is not)
 //
 // The class map of ALT #1 is a short list while few samples carry the allele (BVCF_ALLELE_CMAP_SPARSE, sorted and
 // merged per map byte when the line ends), a dense map staged in LDS otherwise.  A sample that carries a further
@@ -80,7 +86,9 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
   // allele towards an, not two) | how many of them carry ALT #1 (hom by class: alt == gt, main.go:1186; one allele
   // towards ac) << 16.  Taken here unless a dosage matrix is asked for (a haploid carrier's dosage is 1, its class 2).
   uint32_t hap = 0;
-  const bool hap_ok = a.dosage == nullptr;
+  // (with a dosage matrix too, round 4: a line with haploid calls is marked "not regular" in its entry, and k_dosage scans
+  // it itself instead of expanding its class map -- a haploid carrier's dosage is 1, its class 2)
+  const bool hap_ok = true;
   // wave-uniform: a haploid reference call with sub-fields ("0:...") has been seen -- a chrX-like file.  From then on the
   // packed-flag tiers take such a field for what it is (one allele towards an, nothing else) instead of sending its chunk
   // to the field-at-a-time code; files without them do not pay for the test
@@ -166,6 +174,7 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
     const uint32_t hap_all = __any(hap != 0) ? wave_sum(hap) : 0u;  // (ns <= 16 384: both halves stay below 2^16)
     st.ac = st.n_het + 2u * st.n_hom - (hap_all >> 16);
     st.an = 2u * (ns - st.n_miss) - (hap_all & 0xFFFFu);
+    const bool irregular = hap_all != 0u;  // the class map does not tell the dosage of a haploid carrier
     uint32_t cm_off = BVCF_NO_CMAP;
     if (maps) {
       const uint32_t slot = bcast0(map_slot());
@@ -240,7 +249,7 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
         }
       }
     }
-    commit(ls0, cend, st, false, cm_off);
+    commit(ls0, cend, st, false, cm_off, irregular);
   };
 
   // ---- the exact handler: one chunk, any state
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream_gen(KernelArgs a) {
     }
     return cmap_of(a, cm_next, true);
   };
-  auto commit = [&](uint32_t ls, uint32_t cend, const GtStats &st, bool deferred, uint32_t cm_off) {
+  auto commit = [&](uint32_t ls, uint32_t cend, const GtStats &st, bool deferred, uint32_t cm_off, bool irregular = false) {
     while (ls >= (tile + 1) * T) {
       if (lane == 0) a.census[tile] = n_local;
       tile++;
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream_gen(KernelArgs a) {
     if (lane == 0) {
       StreamEntry en;
       en.ls = ls;
-      en.len = cend - ls;
+      en.len = (cend - ls) | (irregular ? kNotRegular : 0u);
       en.ac = st.ac;
       en.an = st.an;
       en.n_het = st.n_het;

@@ -226,6 +226,24 @@ def test_regular_file_through_the_general_kernel_and_back(bv, monkeypatch):
         assert x == y
 
 
+def _dosage_rows_match_oracle(bv, vcf, ns):
+    """bvcf_params.want_dosage on the streaming path: the int8 rows of the output alleles equal the oracle's (any ploidy)"""
+    hdr_at = vcf.index(b"#CHROM")
+    body = vcf[vcf.index(b"\n", hdr_at) + 1:]
+    ctx = bv.Ctx(9 + ns, allow="", want_dosage=True, max_batch_bytes=len(body))
+    b = ctx.process(body)
+    ctx.close()
+    got = []
+    for i in range(len(b.lines)):
+        if b.lines[i]["status"] != 0:
+            continue
+        for k in b.record_slots(i):
+            if b.alleles[k]["ac"] != 0:
+                got.append([int(x) for x in b.dosage[k][:ns]])
+    want = [d for _, d in orc.run_dosage(vcf, {"allow": ""})]
+    assert got == want
+
+
 def _hap_rows(rng, ns, n_lines, p_hap, alts=("G",), dots=True):
     """chrX-style lines: a share of the samples (the same ones on every line: the males) has haploid calls"""
     males = [rng.random() < p_hap for _ in range(ns)]
@@ -249,7 +267,8 @@ def _hap_rows(rng, ns, n_lines, p_hap, alts=("G",), dots=True):
 def test_haploid_calls(bv, ns, p_hap):
     """one allele character per call (chrX males, chrY, chrM): the general branch's single token -- hom when it is the
     allele (alt == gt), one allele towards an (main.go:1130-1190).  Biallelic and multiallelic lines, '.' calls, with and
-    without a dosage matrix asked for (then such lines are left to k_gt: a haploid carrier's dosage is 1)"""
+    without a dosage matrix asked for (the line is then marked "not regular": k_dosage scans it itself, a haploid carrier's
+    dosage is 1 where its class is 2)"""
     rng = random.Random(ns)
     rows = _hap_rows(rng, ns, 40, p_hap, alts=("G", "G,T", "G,T,C"))
     # haploid calls at every byte alignment, as the last field, as the only odd field
@@ -262,10 +281,13 @@ def test_haploid_calls(bv, ns, p_hap):
     vcf = (vcfgen.header(ns) + "".join(rows)).encode()
     both(bv, vcf, {"allow": ""})
     both(bv, vcf, {"allow": "", "keepInfo": True}, max_batch_bytes=1 << 20)
+    _dosage_rows_match_oracle(bv, vcf, ns)
 
 
-def test_haploid_lines_are_not_deferred(bv, bvcf_path):
-    """biallelic lines with 5 % haploid calls stay inside k_stream_gen: no line gets a k_gt task"""
+@pytest.mark.parametrize("want_dosage", [False, True])
+def test_haploid_lines_are_not_deferred(bv, bvcf_path, want_dosage):
+    """biallelic lines with 5 % haploid calls stay inside k_stream_gen: no line gets a k_gt task -- with a dosage matrix
+    asked for as well (round 4: such a line is marked "not regular" and k_dosage scans it; it used to go back to k_gt)"""
     if bvcf_path != "streaming-general":
         pytest.skip("k_stream_gen only")
     import torch
@@ -273,10 +295,56 @@ def test_haploid_lines_are_not_deferred(bv, bvcf_path):
     rng = random.Random(5)
     body = "".join(_hap_rows(rng, ns, 64, 0.05, dots=True)).encode()
     t = torch.frombuffer(bytearray(body + b"\n" * bv.DEVICE_PAD), dtype=torch.uint8).cuda()
-    ctx = bv.Ctx(9 + ns, max_batch_bytes=len(body), allow="")
+    ctx = bv.Ctx(9 + ns, max_batch_bytes=len(body), allow="", want_dosage=want_dosage)
     try:
         chain, scan, counts = ctx.bench_device([t.data_ptr()], [len(body)], 2, slots=1)
     finally:
         ctx.close()
     assert counts[0] == 64          # every line listed
     assert counts[4] == counts[0]   # ... and no task slot past the lines' own: nothing left to k_gt
+
+
+def _odd_rows(rng, ns, n_lines, alts=("G",), odd=("0/1/1", "1/1/1", "0/0/0", "10/1", "1|12", "", "./1/0", "01/1", "1/0/0/0", "0|1|1|1|0", "2/2/1", "A/1"), per_line=3):
+    """mostly-reference lines with a few fields of other shapes: polyploid, alleles of two digits, empty, odd tokens"""
+    rows, pos = [], 50
+    for k in range(n_lines):
+        f = _ref_fields(rng, ns)
+        for _ in range(per_line):
+            i = rng.randrange(ns)
+            g = rng.choice(odd)
+            f[i] = g + (":%d:%d" % (rng.randint(0, 99), rng.randint(0, 99)) if rng.random() < 0.8 else "")
+        for _ in range(rng.randint(0, 3)):  # ordinary carriers beside them
+            f[rng.randrange(ns)] = "%s/%s:3:4" % (rng.choice("01."), rng.choice("01"))
+        pos += 7
+        rows.append(_line(pos, f, alt=alts[k % len(alts)]))
+    return rows
+
+
+@pytest.mark.parametrize("ns", [300, 2504])
+def test_polyploid_multidigit_and_empty_fields(bv, ns):
+    """fields the packed tiers do not classify -- "0/1/1", "10/1", "", "0|1|1|1|0", "A/1" (main.go:1126-1190, the general
+    branch) -- on biallelic and multiallelic lines (where they carry further ALT indices), at every byte alignment, as
+    the last field, beside ordinary carriers, more of them than a class list holds; rows, log and dosage rows equal the
+    oracle's on every device path (k_stream_gen defers such lines to k_gt: keeping them in the kernel was built in
+    round 4 and cost the kernel 19 % on every GATK-shaped file)"""
+    rng = random.Random(ns + 1)
+    rows = _odd_rows(rng, ns, 60, alts=("G", "G,T", "G,T,C", "G,T,C,GA,GC,GG,GT,AA,AC,AG,AT,TA"))
+    for sh in range(17):  # an odd field at every byte alignment, first, last, next to a carrier
+        f = _ref_fields(rng, ns)
+        f[5] = "0/0/%s:%s" % (sh % 2, "7" * (1 + sh))
+        f[6] = "0/1:1:1"
+        f[0] = "1/1/1:5:5" if sh % 3 == 0 else f[0]
+        f[ns - 1] = "0/1/0" if sh % 2 else "1|1|1:9:9"
+        rows.append(_line(9000 + sh, f))
+    # more odd fields than the list holds (such a line is deferred to k_gt), and a line that is dense with carriers
+    f = _ref_fields(rng, ns)
+    for i in range(0, 40, 2):
+        f[i] = "0/1/1:2:2"
+    rows.append(_line(9500, f))
+    f = ["0/1:1:1" if i % 3 == 0 else x for i, x in enumerate(_ref_fields(rng, ns))]
+    f[7] = "1/1/0:4:4"
+    rows.append(_line(9600, f))
+    vcf = (vcfgen.header(ns) + "".join(rows)).encode()
+    both(bv, vcf, {"allow": ""})
+    both(bv, vcf, {"allow": "", "keepInfo": True}, max_batch_bytes=1 << 20)
+    _dosage_rows_match_oracle(bv, vcf, ns)
