@@ -70,7 +70,7 @@ for prof, rows_p in (("c2", 1000000), ("c4", 262144)):
         tot_w += wr
     sec["chain_read_bytes_per_block"] = tot_r
     sec["chain_write_bytes_per_block"] = tot_w
-    dom = "k_sites2" if prof == "c2" else "k_stream"
+    dom = ("k_sites2p" if "k_sites2p" in sec["kernels"] else "k_sites2") if prof == "c2" else "k_stream"
     if dom in sec["kernels"]:
         t = sec["kernels"][dom]["read_bytes_per_launch"] + sec["kernels"][dom]["write_bytes_per_launch"]
         sec["traffic_bytes_per_launch_per_row" if prof == "c2" else "k_stream_traffic_bytes_per_launch_per_row"] = t / rows_p
