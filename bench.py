@@ -10,9 +10,10 @@ configs[2]: 2 504 samples, biallelic SNPs, ~10 166 B/row; by default 8 x 311 296
 per step, so the 20 steps of the driver's run visit 49.8 M rows -- eight times the 6.2 M rows of configs[2] -- in
 about 0.1 s).  A block is what one bvcf_submit takes (< 4 GiB: offsets are 32-bit); the blocks are generated on the
 device before timing and visited in order, 25 GB between two visits of the same byte (the Infinity Cache holds
-256 MiB), so every launch streams its text from HBM.  Blocks are dealt to `--slots` result slots (default 2, the
-library's default), each with its own HIP stream, exactly as bvcf_submit deals them: the short latency-bound kernels
-that end one block's chain overlap the next block's scan.  Records are independent: rank r owns its own rows (weak
+256 MiB), so every launch streams its text from HBM.  Blocks are dealt to `--slots` result slots (default 3 =
+bvcf_params.n_slots 3; the library's own default is 2, 1-2 % slower on configs[2] and 5 % on configs[3]), each with its
+own HIP stream, exactly as bvcf_submit deals them: the short latency-bound kernels that end one block's chain overlap
+the following blocks' scans.  Records are independent: rank r owns its own rows (weak
 scaling), no collective in the data path; the per-rank variant counts are summed over RCCL at the end.
 
 Prints ONE JSON line (rank 0):
@@ -20,9 +21,9 @@ Prints ONE JSON line (rank 0):
                 input).  achieved / frac: algorithmic text bytes per launch / its mean HIP-event duration with ONE
                 block at a time (the kernel alone on the GPU; a pass right after the timed region).  chain_frac:
                 the same bytes / the timed region's time per block (ms_per_step / blocks) / peak -- what the whole
-                chain sustains with two blocks in flight.  in_timed_region_*: the kernel's HIP-event duration inside
+                chain sustains with `--slots` blocks in flight.  in_timed_region_*: the kernel's HIP-event duration inside
                 the timed region, where it shares the CUs with the previous block's tail kernels (longer than the
-                time per block: two launches overlap; informational).
+                time per block: launches overlap; informational).
   e2e           (rank 0, N == 1) the CLI end to end: `bystro-vcf --in <file in /dev/shm> > /dev/null` over
                 configs[2]'s own 6.2 M rows (the rank's stream, written to /dev/shm once), every run kept with its
                 wall clock and its BVCF_TIMING stage split (`runs`; `cold` = the first exec of the CLI on the box,
@@ -122,9 +123,18 @@ def _stages_of(stderr_text):
     return None
 
 
-def _run_cli(args, cat_path=None, timeout_s=300):
+_SPLICE_PRODUCER = ("import fcntl, os, sys\n"
+                    "fd = os.open(sys.argv[1], os.O_RDONLY)\n"
+                    "fcntl.fcntl(1, 1031, 1 << 20)  # F_SETPIPE_SZ\n"
+                    "while os.splice(fd, 1, 1 << 20):\n"
+                    "    pass\n")
+
+
+def _run_cli(args, cat_path=None, timeout_s=300, splice=False):
     """one timed run of the CLI with stdout -> /dev/null.  cat_path: `cat <path> | bystro-vcf` through a real pipe
     (stdin is then the pipe's read end, as in the reference's `pigz -d -c in.vcf.gz | bystro-vcf`, README.md:10).
+    splice: the producer is not cat (read() + write(): two copies in one thread) but splice(2) of the file's page-cache
+    pages into the pipe (no copy on the producer's side): what the CLI's own pipe reader can take.
     -> {"wall_s", "stages"} or {"error"}"""
     env = dict(os.environ, BVCF_TIMING="json")
     t0 = time.perf_counter()
@@ -132,7 +142,7 @@ def _run_cli(args, cat_path=None, timeout_s=300):
     try:
         with open(os.devnull, "wb") as out, tempfile.TemporaryFile() as errf:
             if cat_path:
-                cat = subprocess.Popen(["cat", cat_path], stdout=subprocess.PIPE)
+                cat = subprocess.Popen([sys.executable, "-c", _SPLICE_PRODUCER, cat_path] if splice else ["cat", cat_path], stdout=subprocess.PIPE)
                 p = subprocess.Popen([CLI] + args, stdin=cat.stdout, stdout=out, stderr=errf, env=env)
                 cat.stdout.close()  # the CLI holds the read end now
             else:
@@ -157,15 +167,15 @@ def _run_cli(args, cat_path=None, timeout_s=300):
     return {"wall_s": wall, "stages": _stages_of(err)}
 
 
-def e2e_leg(what, args, rows, text_bytes, runs=2, cat_path=None, timeout_s=300, file_bytes=None):
+def e2e_leg(what, args, rows, text_bytes, runs=2, cat_path=None, timeout_s=300, file_bytes=None, splice=False):
     """`runs` runs of the CLI, every one kept (wall clock around the process, BVCF_TIMING=json stage split).  A run that
     does not come back within timeout_s is reported, not waited for: the bench line must not depend on this leg."""
-    out = {"input": what, "argv": " ".join((["cat", "FILE", "|"] if cat_path else []) + ["bystro-vcf"] + args),
+    out = {"input": what, "argv": " ".join((["splice(FILE -> pipe)" if splice else "cat FILE", "|"] if cat_path else []) + ["bystro-vcf"] + args),
            "rows": rows, "text_bytes": text_bytes, "runs": []}
     if file_bytes is not None:
         out["file_bytes"] = file_bytes
     for _ in range(runs):
-        r = _run_cli(args, cat_path, timeout_s)
+        r = _run_cli(args, cat_path, timeout_s, splice)
         if "error" in r:
             out["error"] = r["error"]
             break
@@ -482,6 +492,9 @@ def host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, release_
             line["e2e_stdin"] = {
                 "text": e2e_leg("cat <the e2e file: " + src + "> | bystro-vcf (stdin is a pipe) -> /dev/null", ["--devices", dev],
                                 f_rows, f_bytes, runs=1, cat_path=path, timeout_s=240),
+                "text_spliced": e2e_leg("the same file through a pipe whose producer does not copy (splice(2) of the page cache "
+                                        "into the pipe, 1 MiB at a time) | bystro-vcf -> /dev/null: the CLI's pipe reader, not cat's speed",
+                                        ["--devices", dev], f_rows, f_bytes, runs=1, cat_path=path, timeout_s=240, splice=True),
                 "bgzf": e2e_leg("cat <the BGZF file of e2e_bgzf> | bystro-vcf (stdin is a pipe) -> /dev/null", ["--devices", dev],
                                 f_rows, gz_text, runs=2, cat_path=gz, file_bytes=gz_bytes),
                 "note": "README.md:10,49 runs the reference as `pigz -d -c in.vcf.gz | bystro-vcf`; the BGZF pipe is that run "
@@ -553,9 +566,9 @@ def main():
                     help="sites-only input (profile c2): the full form of the results (128 bytes per line) instead of the packed one "
                          "(ABI 6, 32 bytes per line, what the CLI asks for)")
     ap.add_argument("--path", type=int, default=0, help="0 choose, 1 census path, 2 streaming path")
-    ap.add_argument("--slots", type=int, default=2,
+    ap.add_argument("--slots", type=int, default=3,
                     help="blocks in flight per GPU: block i runs on slot i %% slots, each slot on its own HIP stream, as "
-                         "bvcf_submit deals them (bvcf_params.n_slots, library default 2); 1 = strictly one block after "
+                         "bvcf_submit deals them (bvcf_params.n_slots; the library's default is 2); 1 = strictly one block after "
                          "the other")
     ap.add_argument("--golden", action="store_true",
                     help="experiment: real 1000-Genomes lines (tests/golden/1kg_chr1_20klines.vcf.gz, 19 747 rows "
@@ -703,7 +716,7 @@ def main():
                 "ms_per_block": ms_per_block,
                 "chain_ms_one_block_at_a_time": alone_chain_ms,
                 # informational: the kernel's duration inside the timed region, where it shares the CUs with the
-                # previous block's tail kernels -- two launches overlap, so this is longer than ms_per_block
+                # previous blocks' tail kernels -- launches overlap, so this is longer than ms_per_block
                 "in_timed_region_mean_launch_ms": gt_mean_ms,
                 "in_timed_region_frac": alg_bytes / (gt_mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if gt_mean_ms else None,
                 "in_timed_region_chain_latency_ms": chain_mean_ms,
