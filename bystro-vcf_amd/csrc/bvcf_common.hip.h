@@ -86,6 +86,8 @@ struct KernelArgs {
   const FilterTable *filters;
   uint32_t *census;      // [n_chunks] newline count per chunk -> exclusive prefix within group
   uint32_t *group_base;  // [n_groups]
+  uint32_t *s2_groups;       // k_census_tiles / k_sites2: line ends per group of kS2GroupTiles tiles, this batch's half ...
+  uint32_t *s2_groups_next;  // ... and the half of the slot's next batch, zeroed meanwhile
   uint32_t *line_off;    // [max_lines + 1]
   bvcf_line *lines;
   bvcf_allele *alleles;

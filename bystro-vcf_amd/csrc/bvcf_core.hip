@@ -30,6 +30,8 @@ struct Slot {
   // device
   uint8_t *d_in = nullptr;
   uint32_t *d_census = nullptr, *d_group = nullptr, *d_line_off = nullptr;
+  uint32_t *d_s2_groups = nullptr;  // k_census_tiles: two sets of group totals, used by the slot's batches in turn
+  uint32_t s2_parity = 0;           // ... which one the batch being launched adds to (make_args)
   bvcf_line *d_lines = nullptr;
   bvcf_allele *d_alleles = nullptr;
   bvcf_site *d_sites = nullptr, *h_sites = nullptr;  // packed ctxs only
@@ -112,7 +114,8 @@ struct bvcf_ctx {
   bool sites1 = false;  // ... or k_sites1 on its own, no census, the line numbers by look-back (BVCF_SITES=3)
   bool sites2 = false;  // ... or k_sites2 behind the census: tiles, the common lines on fast lanes (the default for such input)
   bool packed = false;  // ... and the batch comes back in the packed form (bvcf_params.packed_sites; k_sites2 only)
-  bool sites2_tile_census = true;  // ... its census per tile (k_count_tiles + one scan) instead of per chunk (BVCF_S2_CENSUS=chunk)
+  bool sites2_tile_census = true;  // ... its census per tile (k_census_tiles, no scan kernel) instead of per chunk (BVCF_S2_CENSUS=chunk)
+  uint32_t s2_groups_cap = 0;      // entries of one of a slot's two sets of group totals (k_census_tiles)
   int sites_grid = 0, sites1_grid = 0;
   uint32_t win_bytes = 64u << 10;  // wide: bytes of a line's sample region per wave of the split general scan
   uint32_t tile_bytes = 0, tile_quota = 0;
@@ -179,6 +182,7 @@ void free_slot(Slot &s) {
   hipFree(s.d_in);
   hipFree(s.d_census);
   hipFree(s.d_group);
+  hipFree(s.d_s2_groups);
   hipFree(s.d_line_off);
   hipFree(s.d_lines);
   hipFree(s.d_alleles);
@@ -364,8 +368,16 @@ int alloc_slot(bvcf_ctx *c, Slot &s) {
   const uint64_t in_cap = c->p.max_batch_bytes + BVCF_DEVICE_PAD;
   HIP_TRY(c, hipMalloc(&s.d_in, in_cap));
   s.cap_census = std::max<uint64_t>((c->p.max_batch_bytes + kChunk - 1) / kChunk + 1, s1_state_words((uint32_t)c->p.max_batch_bytes));
+  {  // (k_census_tiles: a count per tile and, behind them, a total per bundle; two sets of group totals, both zero to begin with)
+    const uint32_t nt = s2_n_tiles((uint32_t)c->p.max_batch_bytes) + 1u;
+    s.cap_census = std::max<uint64_t>(s.cap_census, (uint64_t)s2_bundle_off(nt) + s2_n_bundles(nt) + 64u);
+    c->s2_groups_cap = s2_n_groups(nt) + 2u;
+  }
   HIP_TRY(c, hipMalloc(&s.d_census, s.cap_census * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&s.d_group, (s.cap_census / kScanGroup + 2) * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&s.d_s2_groups, 2ull * c->s2_groups_cap * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemset(s.d_s2_groups, 0, 2ull * c->s2_groups_cap * sizeof(uint32_t)));
+  s.s2_parity = 0;
   HIP_TRY(c, hipMalloc(&s.d_counters, sizeof(BatchCounters)));
   HIP_TRY(c, hipHostMalloc(&s.h_counters, sizeof(BatchCounters), hipHostMallocDefault));
   if (c->fused) {
@@ -395,6 +407,8 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.filters = c->d_filters;
   a.census = s.d_census;
   a.group_base = s.d_group;
+  a.s2_groups = s.d_s2_groups + (s.s2_parity & 1u) * c->s2_groups_cap;
+  a.s2_groups_next = s.d_s2_groups + ((s.s2_parity & 1u) ^ 1u) * c->s2_groups_cap;
   a.line_off = s.d_line_off;
   a.lines = s.d_lines;
   a.alleles = s.d_alleles;
@@ -491,9 +505,8 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
   if (c->sites2 && c->sites2_tile_census) {
     // the census per tile, one scan level
     const uint32_t n_tiles = s2_n_tiles(a.nbytes);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_tiles + kWavesPerWg - 1) / kWavesPerWg, (uint64_t)c->n_cu * 8);
-    hipLaunchKernelGGL(k_count_tiles, dim3(grid ? grid : 1), dim3(kWgThreads), 0, st, a, n_tiles);
-    hipLaunchKernelGGL(k_scan_flat, dim3(1), dim3(1024), 0, st, a, n_tiles);
+    const uint32_t grid = s2_n_bundles(n_tiles);
+    hipLaunchKernelGGL(k_census_tiles, dim3(grid ? grid : 1), dim3(kWgThreads), 0, st, a, n_tiles, c->s2_groups_cap);
     if (ev_gt0) hipEventRecord(ev_gt0, st);
     if (a.sites)
       hipLaunchKernelGGL(k_sites2p, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, n_tiles, 0u);
@@ -653,6 +666,7 @@ static bool launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_de
 // the kernel chain of the batch in slot s over the resident text src[0 .. nbytes), the counter read-back and the event
 // bvcf_collect waits for
 int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
+  s.s2_parity ^= 1u;
   KernelArgs a = make_args(c, s, src, nbytes);
   s.used_gen = a.gen_stream != 0;
   HIP_TRY(c, hipEventRecord(s.ev_k0, s.stream));
@@ -1673,6 +1687,7 @@ int bvcf_bench_device_slots(bvcf_ctx *c, const void *const *dblocks, const size_
   for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
   for (int i = 0; i < iters; i++) {
     Slot &si = c->slots[(size_t)i % n_use];
+    si.s2_parity ^= 1u;
     KernelArgs a = make_args(c, si, (const uint8_t *)dblocks[i % n_blocks], nbytes[i % n_blocks]);
     HIP_TRY(c, hipEventRecord(ev[4 * i], si.stream));
     launch_chain(c, a, si.stream, ev[4 * i + 1], ev[4 * i + 2]);

@@ -86,6 +86,12 @@ constexpr uint32_t kS1LookWgs = kS1LookLoads * kWave * 8u;     // workgroups who
 static_assert((uint32_t)kS1Waves * kS1Tile < 0x8000u, "a workgroup's count fits 15 bits");
 __host__ __device__ inline uint32_t s1_n_tiles(uint32_t nbytes) { return (uint32_t)(((unsigned long long)nbytes + kS1Tile - 1u) / kS1Tile); }
 __host__ __device__ inline uint32_t s2_n_tiles(uint32_t nbytes) { return (uint32_t)(((unsigned long long)nbytes + kS2Tile - 1u) / kS2Tile); }
+// k_census_tiles (below): bundles of tiles, groups of bundles
+constexpr uint32_t kS2BundleTiles = 16, kS2GroupBundles = 32, kS2GroupTiles = kS2BundleTiles * kS2GroupBundles;
+__host__ __device__ inline uint32_t s2_n_bundles(uint32_t n_tiles) { return (n_tiles + kS2BundleTiles - 1u) / kS2BundleTiles; }
+__host__ __device__ inline uint32_t s2_n_groups(uint32_t n_tiles) { return (n_tiles + kS2GroupTiles - 1u) / kS2GroupTiles; }
+// (bundle totals follow the tile counts in KernelArgs.census, on a 64-entry boundary)
+__host__ __device__ inline uint32_t s2_bundle_off(uint32_t n_tiles) { return (n_tiles + kS2BundleTiles + 63u) & ~63u; }
 __host__ __device__ inline uint32_t s1_n_wgs(uint32_t n_tiles) { return (n_tiles + (uint32_t)kS1Waves - 1u) / (uint32_t)kS1Waves; }
 __host__ __device__ inline uint32_t s1_l1_off() { return 4u; }
 __host__ __device__ inline uint32_t s1_l0_off(uint32_t n_wgs) { return (s1_l1_off() + (n_wgs + kS1Group - 1u) / kS1Group + 3u) & ~3u; }  // 16-byte aligned
@@ -163,7 +169,16 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
   static_assert(kCensus || !kPacked, "the packed form is k_sites2's");
   // records past a line's first: behind the lines' slots -- whose number only the census knows in advance (packed: how
   // many lines get full records is not known either, so there too they follow slot max_lines)
-  const uint32_t extras_at = (kCensus && !packed) ? min(a.counters->n_lines, a.max_lines) : a.max_lines;
+  uint32_t extras_at = a.max_lines;
+  if constexpr (kCensus && !packed) {
+    if (n_chunks == 0u) {  // (the tile census is not scanned: the batch's lines are the sum of its groups)
+      uint32_t all = 0;
+      for (uint32_t j = (uint32_t)lane; j < s2_n_groups(n_tiles); j += kWave) all += a.s2_groups[j];
+      extras_at = min(wave_sum(all), a.max_lines);
+    } else {
+      extras_at = min(a.counters->n_lines, a.max_lines);
+    }
+  }
 
   // ---- the FILTER gate of the common lines (linePasses, main.go:447-454): up to four allowed values of up to four
   // bytes as dwords, nothing excluded -- prepared on the host (KernelArgs.s1_*).  mode 0: no such table (every line that
@@ -211,8 +226,19 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
       // terminators before the tile = the census prefix of its first chunk (k_count_eol / k_scan_*): asked for now, used
       // when the records are written
       const uint32_t c_first = tile_start / kChunk;
-      if (n_chunks == 0u) {  // the census was taken per tile (k_count_tiles) and scanned in one go
-        if (has_tile) rank_c = a.census[t];
+      if (n_chunks == 0u) {
+        // the census per tile (k_census_tiles), not scanned: every lane asks for its share of what lies in front of the
+        // tile -- lanes 0..15 the tiles of its bundle, lanes 32..63 the bundles of its group, all lanes the groups before
+        if (has_tile) {
+          const uint32_t ti = t % kS2BundleTiles, bundle = t / kS2BundleTiles, bi = bundle % kS2GroupBundles, grp = t / kS2GroupTiles;
+          const uint32_t l = (uint32_t)lane;
+          const bool tile_lane = l < ti, bundle_lane = l >= 32u && l - 32u < bi;
+          if (tile_lane | bundle_lane)
+            rank_c = a.census[tile_lane ? t - ti + l : s2_bundle_off(n_tiles) + bundle - bi + (l - 32u)];
+          if (l < grp) rank_g = a.s2_groups[l];  // (used where rank_c is: no wait here)
+          if (grp > kWave)                       // (a batch of more than 224 MiB: the further groups, at a load's latency)
+            for (uint32_t j = l + kWave; j < grp; j += kWave) rank_c += a.s2_groups[j];
+        }
       } else if (c_first < n_chunks) {
         rank_c = a.census[c_first];
         rank_g = a.group_base[c_first / kScanGroup];
@@ -345,7 +371,7 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
       if (base_known) return;
       base_known = true;
       if constexpr (kCensus) {
-        base = rank_c + rank_g;
+        base = n_chunks == 0u ? wave_sum(rank_c + rank_g) : rank_c + rank_g;
         return;
       }
       if (wiw == 0) {
@@ -814,7 +840,7 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
 #ifdef BVCF_EXP_TIMES
     if (lane == 0) g_wave_t[1][t & 32767u] = wall_clock64();
 #endif
-    if (!kCensus && has_tile && t + 1u == n_tiles && lane == 0) {
+    if ((!kCensus || n_chunks == 0u) && has_tile && t + 1u == n_tiles && lane == 0) {
       a.counters->n_lines = base + tile_eols;
       a.counters->lines_seen = base + tile_eols;
     }
@@ -847,88 +873,70 @@ __global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(3, 3
 }
 #endif  // BVCF_EXPERIMENTS
 
-// k_sites2's own census: terminators per TILE, one wave per tile and seven chunk loads in flight; census[t] then goes
-// through k_scan_top alone (20 k values per 142 MB: one workgroup's work), where the per-chunk census needs two scan levels
-__global__ __launch_bounds__(kWgThreads) void k_count_tiles(KernelArgs a, uint32_t n_tiles) {
+// k_sites2's own census: line ends per TILE, and no scan kernel behind it (round 4; k_scan_flat took 7 of the chain's
+// 77 us).  Three levels, none of them scanned: a workgroup counts one BUNDLE of 16 consecutive tiles (a wave four of
+// them, the next one's seven chunk loads in flight while one is counted) and stores the 16 raw counts, the bundle's total, and adds that to
+// its GROUP's total (32 bundles = 512 tiles = 3.5 MiB of text; one atomic per workgroup).  k_sites2 sums what lies in
+// front of a tile itself: the raw counts of its bundle on lanes 0..15 and the bundle totals of its group on lanes
+// 32..63 (one load), the totals of the groups before on all lanes (one load per 64 groups = 224 MiB), one wave sum.
+// The group totals start from zero without a kernel of their own: a slot keeps two sets, and workgroup 0 clears the one
+// the slot's NEXT batch will add to (nobody reads it meanwhile).  It also sets the batch counters, as k_scan_top does
+// on the paths without k_stream (n_lines / lines_seen: the wave of k_sites2 that holds the last tile).
+
+__global__ __launch_bounds__(kWgThreads) void k_census_tiles(KernelArgs a, uint32_t n_tiles, uint32_t groups_cap) {
+  static_assert(kWavesPerWg * 4u == kS2BundleTiles, "a wave counts four tiles of its workgroup's bundle");
+  __shared__ uint32_t s_cnt[kS2BundleTiles];
   const int lane = lane_id();
-  const uint32_t stride = gridDim.x * kWavesPerWg;
+  const uint32_t wiw = wave_in_wg();
   const uint32_t last_off = a.cap - 16u;
   constexpr uint32_t kN = kS2Tile / kChunk;
-  for (uint32_t t = wave_in_grid(); t < n_tiles; t += stride) {
-    const uint32_t base = t * kS2Tile;  // (n_tiles * kS2Tile < 2^32 + kS2Tile: blocks stay below 4 GiB)
-    const uint32_t tile_end = (uint32_t)min((unsigned long long)base + kS2Tile, (unsigned long long)a.nbytes);
-    u32x4 v[kN];
+  if (blockIdx.x == 0) {
+    for (uint32_t j = threadIdx.x; j < groups_cap; j += kWgThreads) a.s2_groups_next[j] = 0u;
+    if (threadIdx.x == 0) {
+      a.counters->n_lines = 0;
+      a.counters->n_alleles = 0;
+      a.counters->n_errs = 0;
+      a.counters->n_tasks = 0;
+      a.counters->lines_seen = 0;
+      a.counters->cmap_maps = 0;
+      a.counters->pad[0] = a.counters->pad[1] = 0;
+      a.counters->n_finish = 0;
+      a.counters->n_full = 0;
+      a.line_off[0] = 0u;
+    }
+  }
+  const uint32_t t0 = blockIdx.x * kS2BundleTiles + wiw * 4u;
+  // the wave's four tiles one after the other, the next one's chunks asked for before this one's are counted
+  auto ask = [&](u32x4 *v, uint32_t t) {
+    const uint32_t base = t < n_tiles ? t * kS2Tile : 0u;  // (n_tiles * kS2Tile < 2^32 + kS2Tile: blocks stay below 4 GiB)
 #pragma unroll
     for (uint32_t c = 0; c < kN; c++) v[c] = ld_stream(a.buf + min(base + c * kChunk + 16u * lane, last_off));
+  };
+  u32x4 v[2][kN];
+  ask(v[0], t0);
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    const uint32_t t = t0 + k;
+    if (k < 3) ask(v[(k + 1) & 1], t + 1u);
+    const uint32_t base = t * kS2Tile;
+    const uint32_t tile_end = (uint32_t)min((unsigned long long)base + kS2Tile, (unsigned long long)a.nbytes);
     uint32_t cnt = 0;
 #pragma unroll
-    for (uint32_t c = 0; c < kN; c++) cnt += __popc(eq_mask16(v[c], a.eol_byte) & bits_until(tile_end, base + c * kChunk + 16u * lane));
-    cnt = wave_sum(cnt);
-    if (lane == 0) a.census[t] = cnt;
+    for (uint32_t c = 0; c < kN; c++) cnt += __popc(eq_mask16(v[k & 1][c], a.eol_byte) & bits_until(tile_end, base + c * kChunk + 16u * lane));
+    cnt = t < n_tiles ? wave_sum(cnt) : 0u;
+    if (lane == 0) s_cnt[wiw * 4u + k] = cnt;
   }
-}
-
-// ... and its scan: census[0, n) -> exclusive prefixes in place, one workgroup, 32 values per thread and step from eight
-// independent 16-byte loads (k_scan_top's thread walks its share value by value -- fine for a few hundred group totals,
-// 26 us for the 20 k tiles of 142 MB).  Sets the batch counters as k_scan_top does on the paths without k_stream.
-__global__ __launch_bounds__(1024) void k_scan_flat(KernelArgs a, uint32_t n) {
-  __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_carry;
-  const int lane = lane_id();
-  const uint32_t w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_carry = 0u;
   __syncthreads();
-  constexpr uint32_t kPer = 32, kStep = 1024u * kPer;
-  u32x4 *const p4 = reinterpret_cast<u32x4 *>(a.census);  // (hipMalloc'ed: 16-byte aligned; its capacity covers the step's tail)
-  for (uint32_t base = 0; base < n; base += kStep) {
-    const uint32_t lo = base + threadIdx.x * kPer;
-    u32x4 v[kPer / 4];
+  if (threadIdx.x < kS2BundleTiles) {
+    const uint32_t mine = s_cnt[threadIdx.x];
+    a.census[blockIdx.x * kS2BundleTiles + threadIdx.x] = mine;  // (tiles past n_tiles: zeros, inside the bundle area's lead)
+    uint32_t tot = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < kPer / 4; i++) v[i] = lo + 4u * i < n ? p4[(lo >> 2) + i] : u32x4{0u, 0u, 0u, 0u};
-    uint32_t sum = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < kPer / 4; i++) {
-      const uint32_t at = lo + 4u * i;  // values past n (the buffer's stale tail) do not count
-      if (at + 1u >= n + 1u) v[i].x = 0u;
-      if (at + 1u >= n) v[i].y = 0u;
-      if (at + 2u >= n) v[i].z = 0u;
-      if (at + 3u >= n) v[i].w = 0u;
-      sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    for (uint32_t j = 0; j < kS2BundleTiles; j++) tot += s_cnt[j];
+    if (threadIdx.x == 0) {
+      a.census[s2_bundle_off(n_tiles) + blockIdx.x] = tot;
+      if (tot) atomicAdd(&a.s2_groups[blockIdx.x / kS2GroupBundles], tot);
     }
-    uint32_t wtot;
-    const uint32_t pre = wave_excl_scan(sum, &wtot);
-    if (lane == 0) s_wave[w] = wtot;
-    __syncthreads();
-    uint32_t run = s_carry + pre, total = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) {
-      const uint32_t x = s_wave[j];
-      run += j < w ? x : 0u;
-      total += x;
-    }
-#pragma unroll
-    for (uint32_t i = 0; i < kPer / 4; i++) {
-      const u32x4 e = v[i];
-      const u32x4 o = u32x4{run, run + e.x, run + e.x + e.y, run + e.x + e.y + e.z};
-      run += e.x + e.y + e.z + e.w;
-      if (lo + 4u * i < n) p4[(lo >> 2) + i] = o;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) s_carry += total;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const uint32_t all = s_carry;
-    a.counters->n_lines = all;
-    a.counters->n_alleles = 0;
-    a.counters->n_errs = 0;
-    a.counters->n_tasks = 0;
-    a.counters->lines_seen = all;
-    a.counters->cmap_maps = 0;
-    a.counters->pad[0] = a.counters->pad[1] = 0;
-    a.counters->n_finish = 0;
-    a.counters->n_full = 0;
-    a.line_off[0] = 0u;
   }
 }
 

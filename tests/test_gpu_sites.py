@@ -25,7 +25,7 @@ def bv():
 
 @pytest.fixture(autouse=True, params=["k_sites2-packed", "k_sites2-packed-chunk-census", "k_sites2", "k_sites2-chunk-census", "k_sites1", "k_sites"])
 def kernel(request, monkeypatch, bv):
-    """k_sites2 behind its census per tile (k_count_tiles, the default) and behind the per-chunk census of the other chains,
+    """k_sites2 behind its census per tile (k_census_tiles, the default) and behind the per-chunk census of the other chains,
     each with the packed and with the full form of the results"""
     name = request.param
     if name in ("k_sites1", "k_sites") and b"experiments" not in bv.lib.bvcf_version():
@@ -175,9 +175,39 @@ def test_sites_bench_shape_runs_of_many_windows(bv, kernel):
         assert (new.alleles[:300_000][f] == old.alleles[:300_000][f]).all(), f
 
 
+def test_batches_of_different_sizes_in_turn_on_the_same_slots(bv, kernel):
+    """k_census_tiles adds a batch's line ends to one of the slot's two sets of group totals and clears the other for the
+    slot's next batch: batches of very different sizes one after the other, on one slot and on three, each against a ctx
+    of its own"""
+    if not kernel.startswith("k_sites2"):
+        pytest.skip("k_sites2 behind its two censuses")
+    import benchgen as bg
+    cfg = bg.make_cfg("c2")
+    n_hdr = bg.n_header_fields(cfg)
+    sizes = [200_000, 7, 60_000, 1, 350_000, 3_000, 350_000, 40]
+    bodies = [bg.rows_host(cfg, 1_000 + 400_000 * i, n) for i, n in enumerate(sizes)]
+    cap = max(len(b) for b in bodies)
+    want = []
+    for b, n in zip(bodies, sizes):
+        ctx = bv.Ctx(n_hdr, max_batch_bytes=cap, max_lines=max(sizes) + 16, n_slots=1, packed_sites="packed" in kernel)
+        r = ctx.process(b)
+        want.append((r.lines.tobytes(), r.alleles[:n].tobytes()))
+        assert len(r.lines) == n
+        ctx.close()
+    for n_slots in (1, 3):
+        ctx = bv.Ctx(n_hdr, max_batch_bytes=cap, max_lines=max(sizes) + 16, n_slots=n_slots, packed_sites="packed" in kernel)
+        for rnd in range(2):
+            for i, b in enumerate(bodies):
+                r = ctx.process(b)
+                assert len(r.lines) == sizes[i], (n_slots, rnd, i)
+                assert r.lines.tobytes() == want[i][0], (n_slots, rnd, i)
+                assert r.alleles[:sizes[i]].tobytes() == want[i][1], (n_slots, rnd, i)
+        ctx.close()
+
+
 def test_sites_block_of_many_scan_steps(bv, kernel):
-    """a sites-only block of 1.9 M rows = 270 MB: 37 k tiles, i.e. more than k_scan_flat's one step of 32 768 values (the
-    carry between steps), line numbers past 2^20 -- against the census chain with k_head on the same block"""
+    """a sites-only block of 1.9 M rows = 270 MB: 37 k tiles in 74 groups of k_census_tiles (more than the 64 a
+    wave sums with one load), line numbers past 2^20 -- against the census chain with k_head on the same block"""
     if not kernel.startswith("k_sites2"):
         pytest.skip("k_sites2 behind its two censuses")
     import os
