@@ -62,6 +62,50 @@ def test_cli_device_lists_give_identical_output(bv, golden_1kg, devices):
     assert t["count_gather"] == "host"  # ctxs that share a device: RCCL has one rank per device
 
 
+def test_eight_workers_on_one_gpu_stay_within_the_cpu_share(bv, golden_1kg, tmp_path):
+    """`--devices 0,0,0,0,0,0,0,0` over a FILE (per-device range readers): the threads that copy and format are budgeted
+    over ALL workers from the CPU quota (bvcf_plan_threads), so eight workers start no more busy threads than one does;
+    the OS thread count of the running process is sampled from /proc as the evidence.  Output == the one-worker run's."""
+    import time
+    vcf, want_sorted, hdr = golden_1kg
+    path = tmp_path / "in.vcf"
+    path.write_bytes(vcf)
+    env = dict(os.environ, BVCF_TIMING="json")
+    runs = {}
+    for devices in ("0", "0,0,0,0,0,0,0,0"):
+        with open(tmp_path / "out.tsv", "wb") as out, open(tmp_path / "err.txt", "wb") as err:
+            p = subprocess.Popen([EXE, "--in", str(path), "--batchMB", "8", "--devices", devices], stdout=out, stderr=err, env=env)
+            peak = 0
+            while p.poll() is None:
+                try:
+                    for ln in open("/proc/%d/status" % p.pid):
+                        if ln.startswith("Threads:"):
+                            peak = max(peak, int(ln.split()[1]))
+                except OSError:
+                    pass
+                time.sleep(0.002)
+        assert p.returncode == 0, (tmp_path / "err.txt").read_bytes()[-400:]
+        t = _timing((tmp_path / "err.txt").read_bytes())
+        runs[devices] = (t, peak, (tmp_path / "out.tsv").read_bytes())
+    t1, peak1, out1 = runs["0"]
+    t8, peak8, out8 = runs["0,0,0,0,0,0,0,0"]
+    assert out8 == out1 and sorted(out1.split(b"\n")[1:-1]) == want_sorted
+    assert t8["devices_used"] == 8 and t8["lines_in"] == t1["lines_in"]
+    cpus = t8["threads"]["cpus"]
+    for t in (t1, t8):
+        assert t["threads"]["busy_total"] <= max(cpus, 2 * len(t["devices"])), t["threads"]
+    # what is not in busy_total waits: per worker its device thread and its readers' front threads; the writer, the main
+    # thread and the HIP runtime's own helpers (measured: about a dozen)
+    per_worker_waiting = 1 + max(1, t8["threads"]["readers_per_worker"])
+    note = "OS threads at peak: one worker %d, eight workers %d (cpus %d, busy threads planned %d / %d)" % (
+        peak1, peak8, cpus, t1["threads"]["busy_total"], t8["threads"]["busy_total"])
+    print(note)
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):  # (kept as evidence for DESIGN.md section 6)
+        with open(os.path.join(ROOT, "gpurun_out", "thread_counts.txt"), "a") as f:
+            f.write(note + "\n")
+    assert peak8 <= t8["threads"]["busy_total"] + 8 * per_worker_waiting + 24, (peak1, peak8, t8["threads"])
+
+
 def test_cli_count_gather_is_rccl_only_on_request(bv):
     """the end-of-run count gather: the host sums the ctxs' counters unless BVCF_RCCL=1 asks for the all-reduce (its
     communicator bring-up is inside the run's wall time); the totals are the same"""

@@ -50,6 +50,8 @@ cd $R
 python3 tools/derive_traffic.py $OUT > $OUT/k_gt_hbm_traffic.json 2> $OUT/derive.err || tail -3 $OUT/derive.err
 KERNEL=k_head_lean ARGS="--profile c4" TAG=k_head_lean_c4 bash tools/pmc_sq.sh > $OUT/pmc_sq_k_head_lean_c4.txt 2>&1
 KERNEL=k_sites2p ARGS="--profile c2" TAG=k_sites2p bash tools/pmc_sq.sh > $OUT/pmc_sq_k_sites2p.txt 2>&1
+KERNEL=k_stream_gen ARGS="--profile c5" TAG=k_stream_gen_c5 bash tools/pmc_sq.sh > $OUT/pmc_sq_k_stream_gen_c5.txt 2>&1
+KERNEL=k_stream ARGS="--path 2" TAG=k_stream_c3 bash tools/pmc_sq.sh > $OUT/pmc_sq_k_stream.txt 2>&1
 echo "sq done"
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 400 $OUT/bench_default.json
