@@ -505,8 +505,14 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
   if (c->sites2 && c->sites2_tile_census) {
     // the census per tile, one scan level
     const uint32_t n_tiles = s2_n_tiles(a.nbytes);
-    const uint32_t grid = s2_n_bundles(n_tiles);
-    hipLaunchKernelGGL(k_census_tiles, dim3(grid ? grid : 1), dim3(kWgThreads), 0, st, a, n_tiles, c->s2_groups_cap);
+    if (a.sites) {  // the packed form: no scan kernel, k_sites2p sums the census' three levels itself
+      const uint32_t grid = s2_n_bundles(n_tiles);
+      hipLaunchKernelGGL(k_census_tiles, dim3(grid ? grid : 1), dim3(kWgThreads), 0, st, a, n_tiles, c->s2_groups_cap);
+    } else {
+      const uint32_t grid = (uint32_t)std::min<uint64_t>((n_tiles + kWavesPerWg - 1) / kWavesPerWg, (uint64_t)c->n_cu * 8);
+      hipLaunchKernelGGL(k_count_tiles, dim3(grid ? grid : 1), dim3(kWgThreads), 0, st, a, n_tiles);
+      hipLaunchKernelGGL(k_scan_flat, dim3(1), dim3(1024), 0, st, a, n_tiles);
+    }
     if (ev_gt0) hipEventRecord(ev_gt0, st);
     if (a.sites)
       hipLaunchKernelGGL(k_sites2p, dim3(c->sites1_grid), dim3(kS1Threads), 0, st, a, n_tiles, 0u);

@@ -169,16 +169,7 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
   static_assert(kCensus || !kPacked, "the packed form is k_sites2's");
   // records past a line's first: behind the lines' slots -- whose number only the census knows in advance (packed: how
   // many lines get full records is not known either, so there too they follow slot max_lines)
-  uint32_t extras_at = a.max_lines;
-  if constexpr (kCensus && !packed) {
-    if (n_chunks == 0u) {  // (the tile census is not scanned: the batch's lines are the sum of its groups)
-      uint32_t all = 0;
-      for (uint32_t j = (uint32_t)lane; j < s2_n_groups(n_tiles); j += kWave) all += a.s2_groups[j];
-      extras_at = min(wave_sum(all), a.max_lines);
-    } else {
-      extras_at = min(a.counters->n_lines, a.max_lines);
-    }
-  }
+  const uint32_t extras_at = (kCensus && !packed) ? min(a.counters->n_lines, a.max_lines) : a.max_lines;
 
   // ---- the FILTER gate of the common lines (linePasses, main.go:447-454): up to four allowed values of up to four
   // bytes as dwords, nothing excluded -- prepared on the host (KernelArgs.s1_*).  mode 0: no such table (every line that
@@ -226,7 +217,9 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
       // terminators before the tile = the census prefix of its first chunk (k_count_eol / k_scan_*): asked for now, used
       // when the records are written
       const uint32_t c_first = tile_start / kChunk;
-      if (n_chunks == 0u) {
+      if (n_chunks == 0u && !kPacked) {  // the census was taken per tile (k_count_tiles) and scanned in one go
+        if (has_tile) rank_c = a.census[t];
+      } else if (n_chunks == 0u) {
         // the census per tile (k_census_tiles), not scanned: every lane asks for its share of what lies in front of the
         // tile -- lanes 0..15 the tiles of its bundle, lanes 32..63 the bundles of its group, all lanes the groups before
         if (has_tile) {
@@ -371,7 +364,7 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
       if (base_known) return;
       base_known = true;
       if constexpr (kCensus) {
-        base = n_chunks == 0u ? wave_sum(rank_c + rank_g) : rank_c + rank_g;
+        base = (kPacked && n_chunks == 0u) ? wave_sum(rank_c + rank_g) : rank_c + rank_g;
         return;
       }
       if (wiw == 0) {
@@ -840,7 +833,7 @@ __device__ __forceinline__ void s1_body(const KernelArgs &a, const uint32_t n_ti
 #ifdef BVCF_EXP_TIMES
     if (lane == 0) g_wave_t[1][t & 32767u] = wall_clock64();
 #endif
-    if ((!kCensus || n_chunks == 0u) && has_tile && t + 1u == n_tiles && lane == 0) {
+    if ((!kCensus || (kPacked && n_chunks == 0u)) && has_tile && t + 1u == n_tiles && lane == 0) {
       a.counters->n_lines = base + tile_eols;
       a.counters->lines_seen = base + tile_eols;
     }
@@ -872,6 +865,93 @@ __global__ __launch_bounds__(kS1Threads) __attribute__((amdgpu_waves_per_eu(3, 3
   s1_body<false, false>(a, n_tiles, 0u);
 }
 #endif  // BVCF_EXPERIMENTS
+
+// The census of the FULL form of the results (k_sites2; the packed form's k_sites2p takes k_census_tiles below, which
+// needs no scan kernel -- the full form's kernel has no register to spare for summing the levels itself: 59.7 -> 67.2 us
+// when it did): terminators per TILE, one wave per tile and seven chunk loads in flight; census[t] then goes
+// through k_scan_top alone (20 k values per 142 MB: one workgroup's work), where the per-chunk census needs two scan levels
+__global__ __launch_bounds__(kWgThreads) void k_count_tiles(KernelArgs a, uint32_t n_tiles) {
+  const int lane = lane_id();
+  const uint32_t stride = gridDim.x * kWavesPerWg;
+  const uint32_t last_off = a.cap - 16u;
+  constexpr uint32_t kN = kS2Tile / kChunk;
+  for (uint32_t t = wave_in_grid(); t < n_tiles; t += stride) {
+    const uint32_t base = t * kS2Tile;  // (n_tiles * kS2Tile < 2^32 + kS2Tile: blocks stay below 4 GiB)
+    const uint32_t tile_end = (uint32_t)min((unsigned long long)base + kS2Tile, (unsigned long long)a.nbytes);
+    u32x4 v[kN];
+#pragma unroll
+    for (uint32_t c = 0; c < kN; c++) v[c] = ld_stream(a.buf + min(base + c * kChunk + 16u * lane, last_off));
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < kN; c++) cnt += __popc(eq_mask16(v[c], a.eol_byte) & bits_until(tile_end, base + c * kChunk + 16u * lane));
+    cnt = wave_sum(cnt);
+    if (lane == 0) a.census[t] = cnt;
+  }
+}
+
+// ... and its scan: census[0, n) -> exclusive prefixes in place, one workgroup, 32 values per thread and step from eight
+// independent 16-byte loads (k_scan_top's thread walks its share value by value -- fine for a few hundred group totals,
+// 26 us for the 20 k tiles of 142 MB).  Sets the batch counters as k_scan_top does on the paths without k_stream.
+__global__ __launch_bounds__(1024) void k_scan_flat(KernelArgs a, uint32_t n) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  const int lane = lane_id();
+  const uint32_t w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_carry = 0u;
+  __syncthreads();
+  constexpr uint32_t kPer = 32, kStep = 1024u * kPer;
+  u32x4 *const p4 = reinterpret_cast<u32x4 *>(a.census);  // (hipMalloc'ed: 16-byte aligned; its capacity covers the step's tail)
+  for (uint32_t base = 0; base < n; base += kStep) {
+    const uint32_t lo = base + threadIdx.x * kPer;
+    u32x4 v[kPer / 4];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer / 4; i++) v[i] = lo + 4u * i < n ? p4[(lo >> 2) + i] : u32x4{0u, 0u, 0u, 0u};
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kPer / 4; i++) {
+      const uint32_t at = lo + 4u * i;  // values past n (the buffer's stale tail) do not count
+      if (at + 1u >= n + 1u) v[i].x = 0u;
+      if (at + 1u >= n) v[i].y = 0u;
+      if (at + 2u >= n) v[i].z = 0u;
+      if (at + 3u >= n) v[i].w = 0u;
+      sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    uint32_t wtot;
+    const uint32_t pre = wave_excl_scan(sum, &wtot);
+    if (lane == 0) s_wave[w] = wtot;
+    __syncthreads();
+    uint32_t run = s_carry + pre, total = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+      const uint32_t x = s_wave[j];
+      run += j < w ? x : 0u;
+      total += x;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kPer / 4; i++) {
+      const u32x4 e = v[i];
+      const u32x4 o = u32x4{run, run + e.x, run + e.x + e.y, run + e.x + e.y + e.z};
+      run += e.x + e.y + e.z + e.w;
+      if (lo + 4u * i < n) p4[(lo >> 2) + i] = o;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t all = s_carry;
+    a.counters->n_lines = all;
+    a.counters->n_alleles = 0;
+    a.counters->n_errs = 0;
+    a.counters->n_tasks = 0;
+    a.counters->lines_seen = all;
+    a.counters->cmap_maps = 0;
+    a.counters->pad[0] = a.counters->pad[1] = 0;
+    a.counters->n_finish = 0;
+    a.counters->n_full = 0;
+    a.line_off[0] = 0u;
+  }
+}
 
 // k_sites2's own census: line ends per TILE, and no scan kernel behind it (round 4; k_scan_flat took 7 of the chain's
 // 77 us).  Three levels, none of them scanned: a workgroup counts one BUNDLE of 16 consecutive tiles (a wave four of

@@ -19,6 +19,21 @@ pmc() {  # counter, tag, bench args...
   rocprofv3 --pmc $ctr --output-format csv -d /tmp/q_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --blocks 3 --no-cpu-baseline --no-e2e --no-real-data "$@" > $OUT/$tag.log 2>&1
   cp "$(find /tmp/q_$tag -name '*counter_collection.csv' | head -1)" $OUT/$tag.csv
 }
+if [ "$ONLY" = c2 ]; then  # (after a change to the sites-only chain alone: its files again, the rest stands)
+  : > $OUT/bench_unprofiled_lines_c2.json
+  python3 $R/bench.py --profile c2 --no-e2e --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/bench_unprofiled_lines_c2.json
+  python3 $R/bench.py --profile c2 --no-packed-sites --no-e2e --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/bench_unprofiled_lines_c2.json
+  stats bench_c2_sites_only_packed --profile c2
+  stats bench_c2_sites_only_packed_one_block_at_a_time --profile c2 --slots 1
+  stats bench_c2_sites_only_full_form_one_block_at_a_time --profile c2 --slots 1 --no-packed-sites
+  pmc FETCH_SIZE pmc_fetch_size_c2 --profile c2
+  pmc WRITE_SIZE pmc_write_size_c2 --profile c2
+  cd $R
+  python3 tools/derive_traffic.py $OUT > $OUT/k_gt_hbm_traffic.json 2> $OUT/derive.err || tail -3 $OUT/derive.err
+  KERNEL=k_sites2p ARGS="--profile c2" TAG=k_sites2p bash tools/pmc_sq.sh > $OUT/pmc_sq_k_sites2p.txt 2>&1
+  echo "c2 done"
+  exit 0
+fi
 # un-profiled bench lines of every profile, one call
 : > $OUT/bench_unprofiled_lines.json
 for prof in c3 c4 c2 c5 c5h; do
