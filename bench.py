@@ -36,6 +36,9 @@ Prints ONE JSON line (rank 0):
                 inflated on the device; prefix md5 against the oracle; whole-output sha256 against the oracle's
                 rows for that block, repeated.
   e2e_stdin     `cat file | bystro-vcf` through a real pipe, text and BGZF: the drop-in stdin surface.
+  e2e_eight_workers_one_gpu  `--devices d,d,d,d,d,d,d,d`: the product's multi-device partition (eight ctxs, per-worker
+                readers and formatter pools, one ordered writer) over the same files on the one GPU there is; whole
+                output hashed.
   e2e_c4        configs[3]'s rows (20 % multiallelic + 15 % indels) with --keepId --keepInfo through the CLI, the
                 whole output hashed against the oracle CLI's with the same flags.
   cpu_baseline  (rank 0, N == 1) the CPU oracle -- the C restatement of the reference algorithm, kind "port" -- over
@@ -500,6 +503,19 @@ def host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, release_
                 "note": "README.md:10,49 runs the reference as `pigz -d -c in.vcf.gz | bystro-vcf`; the BGZF pipe is that run "
                         "without pigz (the device inflates), the text pipe is what a decompressor in front would have to deliver",
             }
+            # the product's multi-device partition at configs[2]'s size on the one GPU there is: eight workers --
+            # eight ctxs, each with its own byte ranges of the file, readers and formatter pool, one ordered writer -- over
+            # the same 63 GB, text and BGZF; the whole text output hashed like the one-worker run's
+            eight = ",".join([dev] * 8)
+            w8 = {"text": e2e_leg(src + " -> bystro-vcf --in --devices " + eight + " (eight workers on one GPU)",
+                                  ["--in", path, "--devices", eight], f_rows, f_bytes, runs=1, timeout_s=180),
+                  "bgzf": e2e_leg("the BGZF file of e2e_bgzf -> bystro-vcf --in --devices " + eight, ["--in", gz, "--devices", eight],
+                                  f_rows, gz_text, runs=1, timeout_s=180, file_bytes=gz_bytes)}
+            if base and "output_sha256" in base.get("all_cores", {}):
+                w8["full_output_check"] = full_output_check(
+                    ["--in", path, "--devices", eight], base["all_cores"],
+                    "sha256 of all %d rows' output with eight workers, CLI vs the oracle run of cpu_baseline" % f_rows)
+            line["e2e_eight_workers_one_gpu"] = w8
             n_vis = torch.cuda.device_count()
             if n_vis > 1:
                 # (not part of `value`, which is this rank's GPU alone) the same files dealt range by range to every visible
