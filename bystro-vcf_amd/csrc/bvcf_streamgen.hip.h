@@ -100,6 +100,21 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
   uint32_t R = 0x3A302F30u;  // "0/0:" -- the reference genotype word of this file, adopted as seen
   bool done = false;
 
+#ifdef BVCF_EXP_TIMES
+  // (tools/gen_tiers.py) cycles per tier of the chunk loop: 0 loop top (wait, ring slot, flags), 1 packed-flag tier, 2 medium,
+  // 3 exact handler without 4 = its line ends (finish_line); 5..7: chunks through 1 / 2 / 3
+  unsigned long long gph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast_ = __builtin_readcyclecounter();
+#define GSTAMP(k)                                                   \
+  {                                                                 \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    gph_[k] += now_ - glast_;                                       \
+    glast_ = now_;                                                  \
+  }
+#define GCOUNT(k) gph_[k]++;
+#else
+#define GSTAMP(k)
+#define GCOUNT(k)
+#endif
   auto begin_line_samples = [&](uint32_t sb) {
     mode = kSamples;
     s_begin = sb;
@@ -281,6 +296,18 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
         uint32_t tot;
         const uint32_t pre = wave_excl_scan(__popc(mTr), &tot);
         uint32_t st = starts_all & rng;
+        // fields that are the reference word need nothing here (their TABs are counted above): the first start of each
+        // of the lane's dwords is compared with R up front, so that the field-at-a-time loop below -- two rounds for
+        // every line end otherwise, a lane's 16 bytes hold two ten-byte fields -- only runs for what is left
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          const uint32_t sq = (st >> (4u * q)) & 15u;
+          const uint32_t b = (uint32_t)__ffs(sq) - 1u;  // (no start: 0xFFFFFFFF, byte 3 of nothing that is looked at)
+          const uint32_t lo = q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w));
+          const uint32_t hw = q == 0 ? v.y : (q == 1 ? v.z : (q == 2 ? v.w : d4));
+          const uint32_t w = __builtin_amdgcn_alignbyte(hw, lo, b & 3u);
+          if (sq != 0u && w == R) st &= ~(1u << (4u * q + b));
+        }
         uint32_t cand = 0;
         bool seen_hapref = false;
 #pragma nounroll
@@ -340,7 +367,9 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
         } else if (cend == cs) {
           last_is_tab = (pl >> 31) != 0;
         }  // (cend < cs: the terminator's "\r" was in the previous chunk; a TAB before it is caught by the field test)
+        GSTAMP(3)
         finish_line(e, last_is_tab);
+        GSTAMP(4)
         cur = e + 1u;
         if (ls >= r1) {
           done = true;
@@ -575,6 +604,7 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
         mis = (h0 ? 0u : y0) | (h1 ? 0u : y1) | (h2 ? 0u : y2) | (h3 ? 0u : y3) | two_starts;
         hq = (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
       }
+      GSTAMP(0)
       if (!__any((mis | hard) != 0)) {
         hap += hq;
         tabs_lane = (uint32_t)__builtin_popcount(t0) + tabs_lane;
@@ -583,15 +613,24 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
         tabs_lane = (uint32_t)__builtin_popcount(t3) + tabs_lane;
         pl = lane_value(t3, kWave - 1) & 0x80000000u;
         handled = true;
+        GSTAMP(1)
+        GCOUNT(5)
       } else if (!__any(is_hard || two_starts != 0u)) {
         // (medium() looks at the first field start of a dword only: a dword with two -- a one-character field, i.e. a haploid
         // call without sub-fields -- sends the chunk to the exact handler)
         medium(t0, t1, t2, t3, S0, S1, S2, S3, u0, u1, u2, u3);
         pl = lane_value(t3, kWave - 1) & 0x80000000u;
         handled = true;
+        GSTAMP(2)
+        GCOUNT(6)
       }
     }
-    if (!handled) slow(v, (uint32_t)__builtin_amdgcn_readfirstlane((int)nv.x), cs);
+    if (!handled) {
+      GSTAMP(0)
+      slow(v, (uint32_t)__builtin_amdgcn_readfirstlane((int)nv.x), cs);
+      GSTAMP(3)
+      GCOUNT(7)
+    }
     v = nv;
     // (a lane's count shares a register with another in medium(): folded long before it could reach 16 bits)
     if (++since_fold >= 2048u) {
@@ -601,6 +640,10 @@ __device__ __forceinline__ void stream_general_run(const KernelArgs &a, uint32_t
     }
   }
   __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));  // no LDS-DMA may land after the wave has gone
+#ifdef BVCF_EXP_TIMES
+  if (lane == 0)
+    for (int k = 0; k < 8; k++) g_phase_t[k][wave_in_grid() & 32767u] = gph_[k];
+#endif
 }
 
 // ------------------------------------------------------------------ k_stream_gen: k_stream's frame around the general stream
