@@ -34,6 +34,20 @@ if [ "$ONLY" = c2 ]; then  # (after a change to the sites-only chain alone: its 
   echo "c2 done"
   exit 0
 fi
+if [ "$ONLY" = c5 ]; then  # (after a change to k_stream_gen alone)
+  : > $OUT/bench_unprofiled_lines_c5.json
+  for prof in c5 c5h; do
+    python3 $R/bench.py --profile $prof --no-e2e --no-cpu-baseline --no-real-data 2>/dev/null | grep '^{' >> $OUT/bench_unprofiled_lines_c5.json
+  done
+  stats bench_c5_general_stream_one_block_at_a_time --profile c5 --slots 1
+  stats bench_c5h_haploid_calls_one_block_at_a_time --profile c5h --slots 1
+  BVCF_GEN_STREAM=1 pmc FETCH_SIZE pmc_fetch_size_c5 --profile c5
+  BVCF_GEN_STREAM=1 pmc WRITE_SIZE pmc_write_size_c5 --profile c5
+  cd $R
+  KERNEL=k_stream_gen ARGS="--profile c5" TAG=k_stream_gen_c5 bash tools/pmc_sq.sh > $OUT/pmc_sq_k_stream_gen_c5.txt 2>&1
+  echo "c5 done"
+  exit 0
+fi
 # un-profiled bench lines of every profile, one call
 : > $OUT/bench_unprofiled_lines.json
 for prof in c3 c4 c2 c5 c5h; do
