@@ -103,7 +103,9 @@ def test_eight_workers_on_one_gpu_stay_within_the_cpu_share(bv, golden_1kg, tmp_
     if os.path.isdir(os.path.join(ROOT, "gpurun_out")):  # (kept as evidence for DESIGN.md section 6)
         with open(os.path.join(ROOT, "gpurun_out", "thread_counts.txt"), "a") as f:
             f.write(note + "\n")
-    assert peak8 <= t8["threads"]["busy_total"] + 8 * per_worker_waiting + 24, (peak1, peak8, t8["threads"])
+    # (measured: 19 with one worker, 50 with eight; a per-worker budget as before round 4 would start 8 x (2 x 4 + 8) = 128
+    # busy threads alone)
+    assert peak8 <= t8["threads"]["busy_total"] + 8 * per_worker_waiting + 48, (peak1, peak8, t8["threads"])
 
 
 def test_cli_count_gather_is_rccl_only_on_request(bv):
