@@ -11,7 +11,8 @@ i=0
 for set in $SETS; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pmc_${TAG}_$i
-  rocprofv3 --pmc ${set//,/ } --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 1 --warmup 0 --blocks 3 --no-cpu-baseline --no-e2e --no-real-data $ARGS > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "set $i failed"; tail -3 $R/gpurun_out/pmc_${TAG}_$i.log; }
+  timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc ${set//,/ } --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 1 --warmup 0 --blocks 3 --no-cpu-baseline --no-e2e --no-real-data $ARGS > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "set $i ($set) failed"; grep -m1 -i "exceeds\|error" $R/gpurun_out/pmc_${TAG}_$i.log; }
+  echo "set $i done" >&2
 done
 python3 - <<PY
 import csv, glob, collections
