@@ -293,6 +293,37 @@ def decompress(data, n_threads=0):
         return rc, fo.read(), kind.value.decode()
 
 
+def decompress_pipe(data, n_threads=16, piece=0, seed=0):
+    """the same through a PIPE (stdin's shape): a writer thread feeds `data` in pieces of `piece` bytes (0: random sizes up
+    to 3 MiB) -- text through a pipe is read by bvcf_input's splice fan-out when n_threads allows -> (rc, bytes, kind)"""
+    import random
+    import tempfile
+    import threading
+    r, w = os.pipe()
+    rng = random.Random(seed)
+
+    def feed():
+        try:
+            mv, off = memoryview(data), 0
+            while off < len(mv):
+                n = piece or rng.choice([1, 7, 4096, 65536, 100_000, 1 << 20, 3 << 20])
+                off += os.write(w, mv[off:off + n])
+        finally:
+            os.close(w)
+
+    t = threading.Thread(target=feed)
+    t.start()
+    try:
+        with tempfile.TemporaryFile() as fo:
+            kind = C.create_string_buffer(8)
+            rc = lib.bvcf_decompress_fd(r, fo.fileno(), n_threads, kind)
+            fo.seek(0)
+            return rc, fo.read(), kind.value.decode()
+    finally:
+        os.close(r)
+        t.join()
+
+
 class Batch:
     """numpy views (copied) of one collected bvcf_result"""
 

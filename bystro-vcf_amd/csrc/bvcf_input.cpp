@@ -11,7 +11,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
+#include <vector>
 
 namespace bvcf_input {
 
@@ -53,7 +57,11 @@ ByteSource::ByteSource(int fd, unsigned n_threads) : fd_(fd), n_threads_(n_threa
   // `pigz -dc in.vcf.gz | bystro-vcf`: a pipe hands over 64 KiB per read() by default; ask for the most the system
   // gives an unprivileged process (1 MiB, /proc/sys/fs/pipe-max-size) -- fewer system calls and context switches
   struct stat st;
-  if (fstat(fd_, &st) == 0 && S_ISFIFO(st.st_mode)) (void)fcntl(fd_, F_SETPIPE_SZ, 1 << 20);
+  if (fstat(fd_, &st) == 0 && S_ISFIFO(st.st_mode)) {
+    (void)fcntl(fd_, F_SETPIPE_SZ, 1 << 20);
+    fifo_ = true;
+  }
+  if (const char *e = getenv("BVCF_PIPE_FANOUT")) fanout_ok_ = *e != '0';  // (A/B and tests)
 }
 
 ByteSource::~ByteSource() {
@@ -61,6 +69,111 @@ ByteSource::~ByteSource() {
     inflateEnd(z_);
     delete z_;
   }
+  for (auto &p : fan_)
+    for (int &f : p)
+      if (f >= 0) close(f);
+}
+
+// Text from a pipe, `cap` bytes or to the end of input.  This thread hands the pipe's pages on, up to 1 MiB at a time and
+// in turn, to n_fan_ private pipes -- splice(2) between pipes moves page references, it copies nothing --; one thread per
+// private pipe copies what arrives there to its place in dst.  (A pipe's read() copies with the pipe locked, so several
+// readers of ONE pipe would only take turns.)
+ssize_t ByteSource::read_fifo_fanout(uint8_t *dst, size_t cap) {
+  if (!n_fan_) {
+    const unsigned k = fanout_threads(n_threads_);
+    if (!k) return kFanoutUnavailable;
+    for (unsigned i = 0; i < k; i++) {
+      if (pipe2(fan_[i], O_CLOEXEC) != 0) {
+        for (unsigned j = 0; j < i; j++) {
+          close(fan_[j][0]);
+          close(fan_[j][1]);
+          fan_[j][0] = fan_[j][1] = -1;
+        }
+        fan_[i][0] = fan_[i][1] = -1;
+        return kFanoutUnavailable;
+      }
+      (void)fcntl(fan_[i][1], F_SETPIPE_SZ, 1 << 20);  // (refused past the user's pipe-page allowance: 64 KiB then)
+    }
+    n_fan_ = k;
+  }
+  struct Job {
+    uint8_t *dst;
+    size_t n;
+  };
+  struct Lane {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> q;
+    bool done = false;
+    int err = 0;
+  };
+  std::vector<Lane> lanes(n_fan_);
+  auto copier = [&](unsigned k) {
+    Lane &L = lanes[k];
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(L.mu);
+        L.cv.wait(lk, [&] { return !L.q.empty() || L.done; });
+        if (L.q.empty()) return;
+        j = L.q.front();
+        L.q.pop_front();
+      }
+      size_t got = 0;
+      while (got < j.n) {  // (the bytes are in the private pipe already: this never waits for the producer)
+        const ssize_t g = ::read(fan_[k][0], j.dst + got, j.n - got);
+        if (g < 0 && errno == EINTR) continue;
+        if (g <= 0) {
+          std::lock_guard<std::mutex> lk(L.mu);
+          L.err = g < 0 ? errno : EIO;
+          return;
+        }
+        got += (size_t)g;
+      }
+    }
+  };
+  size_t total = 0;
+  int splice_err = 0;
+  unsigned k = 0;
+  std::vector<std::thread> th;
+  while (total < cap) {
+    const size_t want = std::min<size_t>(1u << 20, cap - total);
+    const ssize_t m = splice(fd_, nullptr, fan_[k][1], nullptr, want, SPLICE_F_MOVE);
+    if (m < 0 && errno == EINTR) continue;
+    if (m < 0) {
+      if (total == 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) return kFanoutUnavailable;  // (no threads yet)
+      splice_err = errno;
+      break;
+    }
+    if (m == 0) break;  // end of input
+    if (th.empty())
+      for (unsigned i = 0; i < n_fan_; i++) th.emplace_back(copier, i);
+    {
+      std::lock_guard<std::mutex> lk(lanes[k].mu);
+      lanes[k].q.push_back(Job{dst + total, (size_t)m});
+    }
+    lanes[k].cv.notify_one();
+    total += (size_t)m;
+    k = (k + 1) % n_fan_;
+  }
+  for (auto &L : lanes) {
+    {
+      std::lock_guard<std::mutex> lk(L.mu);
+      L.done = true;
+    }
+    L.cv.notify_one();
+  }
+  for (auto &x : th) x.join();
+  for (auto &L : lanes)
+    if (L.err) {
+      err_ = std::string("read: ") + strerror(L.err);
+      return -1;
+    }
+  if (splice_err) {
+    err_ = std::string("splice: ") + strerror(splice_err);
+    return -1;
+  }
+  return (ssize_t)total;
 }
 
 const char *ByteSource::kind() const {
@@ -181,6 +294,11 @@ ssize_t ByteSource::read_text(uint8_t *dst, size_t cap) {
       lseek(fd_, at + (off_t)total, SEEK_SET);
       return (ssize_t)total;
     }
+  }
+  if (fifo_ && fanout_ok_ && cap >= (4u << 20)) {
+    const ssize_t got = read_fifo_fanout(dst, cap);
+    if (got != kFanoutUnavailable) return got;
+    fanout_ok_ = false;
   }
   for (;;) {
     ssize_t got = ::read(fd_, dst, cap);

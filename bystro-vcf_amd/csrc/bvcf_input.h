@@ -21,6 +21,8 @@ namespace bvcf_input {
 class ByteSource {
  public:
   ByteSource(int fd, unsigned n_threads);
+  // copier threads a text pipe is read with for a given thread allowance (0: one plain read(); see read_fifo_fanout)
+  static unsigned fanout_threads(unsigned n_threads) { return n_threads >= 12 ? 4u : (n_threads >= 6 ? 2u : 0u); }
   ~ByteSource();
   ByteSource(const ByteSource &) = delete;
   ByteSource &operator=(const ByteSource &) = delete;
@@ -41,11 +43,19 @@ class ByteSource {
   enum Kind { kUnknown, kText, kGzip, kBgzf };
   bool fill_compressed();                       // append raw bytes from fd to cbuf_
   ssize_t read_text(uint8_t *dst, size_t cap);
+  ssize_t read_fifo_fanout(uint8_t *dst, size_t cap);  // kFanoutUnavailable: not possible here, nothing consumed
   ssize_t read_gzip(uint8_t *dst, size_t cap);
   ssize_t read_bgzf(uint8_t *dst, size_t cap);
 
+  static constexpr ssize_t kFanoutUnavailable = -3;
   int fd_;
   unsigned n_threads_;
+  // text from a pipe: the pipe's pages are handed on to a few private pipes (splice(2): no copy) whose readers copy them
+  // out side by side -- one thread's read() of a pipe copies ~8 GB/s, and a pipe's read() copies under the pipe's lock
+  bool fifo_ = false;
+  bool fanout_ok_ = true;
+  unsigned n_fan_ = 0;
+  int fan_[4][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
   Kind kind_ = kUnknown;
   bool fd_eof_ = false;
   std::vector<uint8_t> cbuf_;  // raw bytes not yet consumed

@@ -213,11 +213,13 @@ bvcf_thread_budget plan_threads(unsigned cpus, unsigned n_workers, int mode) {
     b.format_threads = std::min(32u, std::max(1u, share - 1));
     b.busy_total = n_workers * (1 + b.format_threads);
   } else {
-    // one reader for the whole stream
+    // one reader for the whole stream; a text pipe's pages are copied out by a few threads beside it
+    // (bvcf_input::ByteSource::fanout_threads: 4 from 12 CPUs up, 2 from 6, none below)
     b.readers = 0;
-    b.copy_threads = 1;
-    b.format_threads = std::min(32u, std::max(1u, cpus > n_workers ? (cpus - 1) / n_workers : 1u));
-    b.busy_total = 1 + n_workers * b.format_threads;
+    const unsigned fan = cpus >= 12 ? 4u : (cpus >= 6 ? 2u : 0u);
+    b.copy_threads = fan ? fan : 1u;
+    b.format_threads = std::min(32u, std::max(1u, cpus > n_workers + fan ? (cpus - 1 - fan) / n_workers : 1u));
+    b.busy_total = 1 + fan + n_workers * b.format_threads;
   }
   return b;
 }

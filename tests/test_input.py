@@ -34,6 +34,28 @@ def test_roundtrips(bv, n):
         assert kind == (name if n or name != "text" else "text")
 
 
+@pytest.mark.parametrize("n_threads", [2, 8, 16])
+def test_text_through_a_pipe(bv, n_threads, monkeypatch):
+    """stdin's shape: text from a pipe is handed on, page by page, to private pipes whose readers copy it out side by side
+    (bvcf_input.cpp: read_fifo_fanout; 2 threads: the plain read(), 8: two copiers, 16: four) -- every byte once and in order
+    whatever the sizes the producer writes, gzip and BGZF through the same pipe untouched by it"""
+    for n, seed in ((0, 1), (1, 2), (5_000_000, 3), (40_000_003, 4)):
+        data = payload(n, seed)
+        if n:
+            rc, out, kind = bv.decompress_pipe(data, n_threads, 0, seed)
+            assert rc == 0 and out == data and kind == "text", (n, n_threads)
+        for name, comp in (("gzip", gzip.compress(data, 1)), ("bgzf", bgzf.bgzf_compress(data, level=1))):
+            rc, out, kind = bv.decompress_pipe(comp, n_threads, 0, seed)
+            assert rc == 0 and out == data and kind == name, (name, n, n_threads)
+    data = payload(30_000_000, 9)
+    for piece in (1 << 20, 65536, 999_983):
+        rc, out, kind = bv.decompress_pipe(data, n_threads, piece)
+        assert rc == 0 and out == data
+    monkeypatch.setenv("BVCF_PIPE_FANOUT", "0")
+    rc, out, kind = bv.decompress_pipe(data, n_threads, 0, 5)
+    assert rc == 0 and out == data
+
+
 def test_bgzf_shapes(bv):
     data = payload(300_000, 2)
     # tiny blocks, no EOF marker, empty blocks in the middle, one thread and many

@@ -98,6 +98,8 @@ def test_thread_budget_fits_the_quota(bv):
                 assert b.copy_threads >= 1 and b.format_threads >= 1
                 per_worker = (b.readers or 0) * b.copy_threads + b.format_threads
                 busy = n * per_worker + (1 if mode == bv.MODE_STREAM else 0)
+                if mode == bv.MODE_STREAM and b.copy_threads > 1:
+                    busy += b.copy_threads  # (the copiers of a text pipe's pages, beside the one reader)
                 assert busy == b.busy_total
                 # everything that burns CPU fits the CPUs the process may use; with fewer than two per worker each
                 # worker still gets one reader and one formatter
