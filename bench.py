@@ -39,6 +39,7 @@ Prints ONE JSON line (rank 0):
   e2e_eight_workers_one_gpu  `--devices d,d,d,d,d,d,d,d`: the product's multi-device partition (eight ctxs, per-worker
                 readers and formatter pools, one ordered writer) over the same files on the one GPU there is; whole
                 output hashed.
+  e2e_c5        the same for GATK-style rows (GT:DP:GQ sample fields, 24 KB per row: k_stream_gen), default flags.
   e2e_c4        configs[3]'s rows (20 % multiallelic + 15 % indels) with --keepId --keepInfo through the CLI, the
                 whole output hashed against the oracle CLI's with the same flags.
   cpu_baseline  (rank 0, N == 1) the CPU oracle -- the C restatement of the reference algorithm, kind "port" -- over
@@ -531,25 +532,33 @@ def host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, release_
                 os.unlink(q)
         del files[:]
 
-        # ---- configs[3] end to end: --keepId --keepInfo, whole output against the oracle
-        if not args.no_e2e and not args.no_cpu_baseline and args.profile == "c3" and args.e2e_c4_rows > 0:
-            cfg4 = bg.make_cfg("c4")
-            r4 = SHAPES["c4"][0]
-            n4 = max(1, -(-args.e2e_c4_rows // r4))
-            path4, rows4, bytes4, where4 = write_e2e_file(
-                bg.header(cfg4), [], [r4 * (4 * cfg4.n_samples + 400)], n4 * r4, r4,
-                lambda b: bg.rows_device(cfg4, b * r4, r4, pad=bv.DEVICE_PAD))
-            files.append(path4)
-            torch.cuda.empty_cache()
-            flags = ["--keepId", "--keepInfo"]
-            base4 = cpu_baseline(path4, rows4, "c4", oracle_args=flags, four=False)
-            c4 = e2e_leg("%d rows, %.2f GB of BASELINE configs[3]'s synthetic stream (20%% multiallelic + 15%% indels) in %s -> bystro-vcf "
-                         "--in --keepId --keepInfo -> /dev/null" % (rows4, bytes4 / 1e9, where4),
-                         ["--in", path4, "--devices", dev] + flags, rows4, bytes4, runs=2)
-            c4["full_output_check"] = full_output_check(["--in", path4, "--devices", dev] + flags, base4["all_cores"],
-                                                        "sha256 of all %d rows' output with --keepId --keepInfo, CLI vs oracle CLI" % rows4)
-            c4["cpu_baseline"] = {k: base4[k] for k in ("value", "unit", "cores", "kind", "sample")}
-            line["e2e_c4"] = c4
+        # ---- two more files end to end, whole output against the oracle: configs[3] with --keepId --keepInfo, and GATK-style
+        # sample fields (GT:DP:GQ: the file shape most cohort VCFs have; k_stream_gen)
+        if not args.no_e2e and not args.no_cpu_baseline and args.profile == "c3":
+            for key, prof, want, flags, what in (
+                    ("e2e_c4", "c4", args.e2e_c4_rows, ["--keepId", "--keepInfo"], "BASELINE configs[3]'s synthetic stream (20% multiallelic + 15% indels)"),
+                    ("e2e_c5", "c5", args.e2e_c5_rows, [], "GATK-style rows (2 504 samples, GT:DP:GQ, 24 KB per row: not a BASELINE config)")):
+                if want <= 0:
+                    continue
+                cfg_x = bg.make_cfg(prof)
+                r_x = SHAPES[prof][0]
+                n_x = max(1, -(-want // r_x))
+                per_row = 25_000 if prof == "c5" else 4 * cfg_x.n_samples + 400
+                path_x, rows_x, bytes_x, where_x = write_e2e_file(
+                    bg.header(cfg_x), [], [r_x * per_row], n_x * r_x, r_x,
+                    lambda b, cfg_x=cfg_x, r_x=r_x: bg.rows_device(cfg_x, b * r_x, r_x, pad=bv.DEVICE_PAD))
+                files.append(path_x)
+                torch.cuda.empty_cache()
+                base_x = cpu_baseline(path_x, rows_x, prof, oracle_args=flags, four=False)
+                leg = e2e_leg("%d rows, %.2f GB of %s in %s -> bystro-vcf --in %s-> /dev/null" % (
+                                  rows_x, bytes_x / 1e9, what, where_x, " ".join(flags) + (" " if flags else "")),
+                              ["--in", path_x, "--devices", dev] + flags, rows_x, bytes_x, runs=2)
+                leg["full_output_check"] = full_output_check(
+                    ["--in", path_x, "--devices", dev] + flags, base_x["all_cores"],
+                    "sha256 of all %d rows' output%s, CLI vs oracle CLI" % (rows_x, " with " + " ".join(flags) if flags else ""))
+                leg["cpu_baseline"] = {k: base_x[k] for k in ("value", "unit", "cores", "kind", "sample")}
+                line[key] = leg
+                os.unlink(path_x)
     except Exception as exc:  # the host legs inform; the measured line above stands without them
         import traceback
         line.setdefault("host_legs_error", (repr(exc) + " @ " + traceback.format_exc().splitlines()[-3].strip())[:500])
@@ -576,6 +585,8 @@ def main():
                          "63 GB, written to /dev/shm -- fewer when it does not hold them)")
     ap.add_argument("--e2e-c4-rows", type=int, default=1_048_576,
                     help="rows of the configs[3] end-to-end leg (--keepId --keepInfo, whole output hashed against the oracle); 0 = skip")
+    ap.add_argument("--e2e-c5-rows", type=int, default=393_216,
+                    help="rows of the GATK-style (GT:DP:GQ) end-to-end leg, whole output hashed against the oracle; 0 = skip")
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
     ap.add_argument("--no-class-maps", action="store_true", help="experiment: counts only, no 2-bit class maps")
     ap.add_argument("--no-packed-sites", action="store_true",
