@@ -39,6 +39,7 @@ Prints ONE JSON line (rank 0):
   e2e_eight_workers_one_gpu  `--devices d,d,d,d,d,d,d,d`: the product's multi-device partition (eight ctxs, per-worker
                 readers and formatter pools, one ordered writer) over the same files on the one GPU there is; whole
                 output hashed.
+  e2e_c2        the same for configs[1]'s sites-only rows (20 M of them: the packed form end to end), default flags.
   e2e_c5        the same for GATK-style rows (GT:DP:GQ sample fields, 24 KB per row: k_stream_gen), default flags.
   e2e_c4        configs[3]'s rows (20 % multiallelic + 15 % indels) with --keepId --keepInfo through the CLI, the
                 whole output hashed against the oracle CLI's with the same flags.
@@ -537,13 +538,14 @@ def host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, release_
         if not args.no_e2e and not args.no_cpu_baseline and args.profile == "c3":
             for key, prof, want, flags, what in (
                     ("e2e_c4", "c4", args.e2e_c4_rows, ["--keepId", "--keepInfo"], "BASELINE configs[3]'s synthetic stream (20% multiallelic + 15% indels)"),
-                    ("e2e_c5", "c5", args.e2e_c5_rows, [], "GATK-style rows (2 504 samples, GT:DP:GQ, 24 KB per row: not a BASELINE config)")):
+                    ("e2e_c5", "c5", args.e2e_c5_rows, [], "GATK-style rows (2 504 samples, GT:DP:GQ, 24 KB per row: not a BASELINE config)"),
+                    ("e2e_c2", "c2", args.e2e_c2_rows, [], "BASELINE configs[1]'s synthetic stream (sites-only, biallelic: the packed form of the results)")):
                 if want <= 0:
                     continue
                 cfg_x = bg.make_cfg(prof)
                 r_x = SHAPES[prof][0]
                 n_x = max(1, -(-want // r_x))
-                per_row = 25_000 if prof == "c5" else 4 * cfg_x.n_samples + 400
+                per_row = 25_000 if prof == "c5" else (160 if prof == "c2" else 4 * cfg_x.n_samples + 400)
                 path_x, rows_x, bytes_x, where_x = write_e2e_file(
                     bg.header(cfg_x), [], [r_x * per_row], n_x * r_x, r_x,
                     lambda b, cfg_x=cfg_x, r_x=r_x: bg.rows_device(cfg_x, b * r_x, r_x, pad=bv.DEVICE_PAD))
@@ -585,6 +587,8 @@ def main():
                          "63 GB, written to /dev/shm -- fewer when it does not hold them)")
     ap.add_argument("--e2e-c4-rows", type=int, default=1_048_576,
                     help="rows of the configs[3] end-to-end leg (--keepId --keepInfo, whole output hashed against the oracle); 0 = skip")
+    ap.add_argument("--e2e-c2-rows", type=int, default=20_000_000,
+                    help="rows of the sites-only (configs[1]) end-to-end leg, whole output hashed against the oracle; 0 = skip")
     ap.add_argument("--e2e-c5-rows", type=int, default=393_216,
                     help="rows of the GATK-style (GT:DP:GQ) end-to-end leg, whole output hashed against the oracle; 0 = skip")
     ap.add_argument("--align16", action="store_true", help="experiment: 16-byte aligned sample regions")
