@@ -269,6 +269,7 @@ void Driver::sniff_input() {
   budget_ = plan_threads(hw_, (unsigned)n_dev_, (int)mode_);
   if (const char *t = getenv("BVCF_READ_THREADS")) budget_.copy_threads = (unsigned)std::max(1, atoi(t));  // tuning
   if (c_->n_format_threads) budget_.format_threads = std::max(1u, (unsigned)(c_->n_format_threads / n_dev_));
+  if (const char *t = getenv("BVCF_FORMAT_THREADS")) budget_.format_threads = (unsigned)std::max(1, atoi(t));  // tuning
 }
 
 void Driver::fail(const std::string &m, int code) {
