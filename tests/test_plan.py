@@ -360,6 +360,35 @@ def test_stream_mode_deals_blocks_round_robin(bv, tmp_path):
         for k, b in enumerate(blocks):
             assert b.range == k and b.worker == k % n_workers and b.piece == 0 and b.last_piece
         check_text_blocks(bv, data, blocks, n_workers, len(HDR), ranges=False)
+    # batches of 8 MiB: a text pipe's pages are then handed on to private pipes and copied out by several threads
+    # (bvcf_input.cpp: read_fifo_fanout) -- the blocks must come out the same, and the same as with the plain read()
+    big = HDR + make_body(rng, 60000, [300, 900])
+    seen = {}
+    for fanout in ("1", "0"):
+        os.environ["BVCF_PIPE_FANOUT"] = fanout
+        try:
+            r, w = os.pipe()
+            pid = os.fork()
+            if pid == 0:
+                os.close(r)
+                try:
+                    mv, off = memoryview(big), 0
+                    while off < len(mv):
+                        off += os.write(w, mv[off:off + 777_777])
+                finally:
+                    os._exit(0)
+            os.close(w)
+            try:
+                rc, mode, plan, blocks = bv.plan_fd(r, 2, 8 << 20, 1)
+            finally:
+                os.close(r)
+                os.waitpid(pid, 0)
+        finally:
+            os.environ.pop("BVCF_PIPE_FANOUT", None)
+        assert rc == 0 and mode == bv.MODE_STREAM and len(blocks) >= 3
+        check_text_blocks(bv, big, blocks, 2, len(HDR), ranges=False)
+        seen[fanout] = [(b.range, b.worker, b.file_off, b.nbytes) for b in blocks]
+    assert seen["1"] == seen["0"]
     # BGZF through a pipe: compressed batches, the same ownership rule
     text = HDR + make_body(rng, 4000, [300, 900])
     comp = bgzf.bgzf_compress(text, block=5000, level=1)
