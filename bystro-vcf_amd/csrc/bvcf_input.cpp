@@ -108,6 +108,7 @@ ssize_t ByteSource::read_fifo_fanout(uint8_t *dst, size_t cap) {
     int err = 0;
   };
   std::vector<Lane> lanes(n_fan_);
+  std::atomic<bool> copier_failed{false};  // (a copier that cannot read its pipe: stop handing pages on, they would pile up there)
   auto copier = [&](unsigned k) {
     Lane &L = lanes[k];
     for (;;) {
@@ -126,6 +127,7 @@ ssize_t ByteSource::read_fifo_fanout(uint8_t *dst, size_t cap) {
         if (g <= 0) {
           std::lock_guard<std::mutex> lk(L.mu);
           L.err = g < 0 ? errno : EIO;
+          copier_failed.store(true);
           return;
         }
         got += (size_t)g;
@@ -136,7 +138,7 @@ ssize_t ByteSource::read_fifo_fanout(uint8_t *dst, size_t cap) {
   int splice_err = 0;
   unsigned k = 0;
   std::vector<std::thread> th;
-  while (total < cap) {
+  while (total < cap && !copier_failed.load()) {
     const size_t want = std::min<size_t>(1u << 20, cap - total);
     const ssize_t m = splice(fd_, nullptr, fan_[k][1], nullptr, want, SPLICE_F_MOVE);
     if (m < 0 && errno == EINTR) continue;
