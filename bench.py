@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — variants/sec of the HIP per-line variant pipeline on 1KG-chr1-shaped synthetic VCF.
 
-    python bench.py --gpus N --steps K --warmup W            (N == 1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus 2 --cpu-dry      (no GPU: the N > 1 plumbing over gloo, the CPU oracle per rank; a test)
+
+With N > 1 and no launcher around it (WORLD_SIZE unset) the parent -- before any torch / GPU call -- starts
+torch.distributed.run as a child process, relays its stdout and exits with its code.
 
 One process per GPU.  A STEP = one pass of the whole kernel chain (line index, head/getAlleles, genotype scan,
 finish) over the rank's whole resident set: `--blocks` blocks of `--rows` synthetic rows each (BASELINE.json
@@ -16,7 +20,12 @@ own HIP stream, exactly as bvcf_submit deals them: the short latency-bound kerne
 the following blocks' scans.  Records are independent: rank r owns its own rows (weak
 scaling), no collective in the data path; the per-rank variant counts are summed over RCCL at the end.
 
-Prints ONE JSON line (rank 0):
+Rank 0 writes the WHOLE record to bench_full.json (next to this file, and under gpurun_out/ when that exists) and
+prints ONE compact JSON line (<= 3 KB: headline, config, roofline, cpu_baseline, one flat
+{wall_s, variants_per_min, steady_variants_per_s, sha256_equal} per end-to-end leg) as the LAST line of stdout.
+N > 1 adds ranks_seen (RCCL all-reduce of ones), per_rank_variants_per_s and e2e_all_devices (one
+`bystro-vcf --devices 0,..,N-1` process over configs[2]-shaped text and BGZF, whole output hashed against the oracle's).
+The whole record holds:
   roofline      the dominant kernel (k_stream on the streaming path, k_gt on the census path, k_sites on sites-only
                 input).  achieved / frac: algorithmic text bytes per launch / its mean HIP-event duration with ONE
                 block at a time (the kernel alone on the GPU; a pass right after the timed region).  chain_frac:
@@ -570,6 +579,244 @@ def host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, release_
                 os.unlink(q)
 
 
+def all_devices_leg(line, args, cfg, bg, bv, blocks, sizes, world, release_device):
+    """N > 1, rank 0, after the timed region: the product's own multi-device run -- ONE `bystro-vcf --devices 0,..,N-1`
+    process, contiguous byte ranges of the file dealt to N workers (one ctx per GPU), one ordered writer -- over
+    configs[2]-shaped rows as text and as BGZF; the whole text output hashed against the oracle CLI's (the checker; no
+    cpu_baseline at N > 1)."""
+    import torch
+    files = []
+    try:
+        hdr = bg.header(cfg)
+        first0 = rank_blocks(0, args.blocks, args.rows)[0]
+        path, f_rows, f_bytes, where = write_e2e_file(
+            hdr, blocks, sizes, args.all_devices_rows, args.rows,
+            lambda b: bg.rows_device(cfg, first0 + b * args.rows, args.rows, pad=bv.DEVICE_PAD))
+        files.append(path)
+        n_blk = f_rows // args.rows
+        import bgzf as _bg
+        b0 = blocks[0][:sizes[0]].cpu().numpy()
+        members = bgzf_of(memoryview(b0), threads=usable_cpus())
+        del b0
+        gz = path + ".gz"
+        files.append(gz)
+        with open(gz, "wb") as f:
+            f.write(bgzf_of(memoryview(hdr)))
+            for _ in range(n_blk):
+                f.write(members)
+            f.write(_bg.bgzf_block(b""))
+        gz_bytes, gz_text = os.path.getsize(gz), len(hdr) + n_blk * sizes[0]
+        del members
+        release_device()
+        blocks.clear()
+        torch.cuda.empty_cache()
+        devs = ",".join(str(d) for d in range(world))
+        src = "%d rows, %.2f GB of the same synthetic stream in %s" % (f_rows, f_bytes / 1e9, where)
+        out = {"devices": devs,
+               "text": e2e_leg(src + " -> bystro-vcf --in --devices " + devs, ["--in", path, "--devices", devs], f_rows, f_bytes,
+                               runs=2, timeout_s=240),
+               "bgzf": e2e_leg("the same rows as BGZF (block 0 of the stream %d times, %.2f GB) -> bystro-vcf --in x.vcf.gz --devices %s"
+                               % (n_blk, gz_bytes / 1e9, devs), ["--in", gz, "--devices", devs], f_rows, gz_text, runs=2,
+                               timeout_s=240, file_bytes=gz_bytes)}
+        rc_o, hx_o, n_o, _, _ = _hash_stdout([ORACLE, "--in", path, "--threads", str(min(usable_cpus(), 64))], algo="sha256")
+        chk = full_output_check(["--in", path, "--devices", devs], {"output_sha256": hx_o, "output_bytes": n_o},
+                                "sha256 of all %d rows' output over %d devices, CLI vs the oracle CLI" % (f_rows, world))
+        chk["equal"] = chk["equal"] and rc_o == 0
+        out["full_output_check"] = chk
+        line["e2e_all_devices"] = out
+    except Exception as exc:  # informs; the measured line stands without it
+        line["host_legs_error"] = repr(exc)[:300]
+    finally:
+        for q in files:
+            if os.path.exists(q):
+                os.unlink(q)
+
+
+LIBRARY_DEFAULT_SLOTS = 2  # bvcf_params.n_slots == 0 (include/bvcf.h)
+LINE_LIMIT = 3072  # bytes: the driver keeps 8 KB of stdout; the verdict asks for <= 3 KB
+
+
+def _sig(x, n=5):
+    """floats to n significant digits (the line is a record, not a data file)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (n, x))
+
+
+def _leg_summary(leg):
+    """ONE flat summary of an end-to-end leg: {wall_s, variants_per_min, steady_variants_per_s, sha256_equal}"""
+    if not isinstance(leg, dict):
+        return None
+    if "wall_s" not in leg:
+        return {"error": str(leg.get("error", "no run"))[:80]}
+    chk = leg.get("full_output_check")
+    out = {"wall_s": _sig(leg["wall_s"], 4), "variants_per_min": _sig(leg.get("variants_per_min"), 4),
+           "steady_variants_per_s": _sig(leg.get("steady_variants_per_s"), 4),
+           "sha256_equal": (bool(chk["equal"]) if isinstance(chk, dict) and "equal" in chk else None)}
+    if "error" in leg:
+        out["error"] = str(leg["error"])[:80]
+    return out
+
+
+def compact_line(full):
+    """the ONE line the driver reads (last line of stdout, <= LINE_LIMIT bytes): headline, config, roofline,
+    cpu_baseline and one flat summary per end-to-end leg.  Everything else stays in bench_full.json."""
+    line = {k: _sig(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                              "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    line["config"] = {k: _sig(cfg[k]) for k in ("workload", "rows_per_step_per_gpu", "rows_per_block", "resident_blocks_per_gpu",
+                                                 "bytes_per_row", "n_samples", "input", "blocks_in_flight", "flags") if k in cfg}
+    rf = full.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = {k: _sig(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                           "algorithmic_bytes_per_launch", "mean_launch_ms", "chain_frac")}
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {k: _sig(cb.get(k)) for k in ("value", "unit", "cores", "kind")}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample_short") or cb.get("sample", ""))[:120]
+    for k in ("variants_per_min", "text_GBps", "ranks_seen", "value_at_library_default_slots"):
+        if k in full:
+            line[k] = _sig(full[k])
+    if "per_rank_variants_per_s" in full:
+        line["per_rank_variants_per_s"] = [_sig(v, 4) for v in full["per_rank_variants_per_s"]]
+    if isinstance(full.get("real_data"), dict) and "frac" in full["real_data"]:
+        line["real_data_frac"] = _sig(full["real_data"]["frac"], 4)
+    for key in ("e2e", "e2e_bgzf", "e2e_c2", "e2e_c4", "e2e_c5"):
+        if key in full:
+            line[key] = _leg_summary(full[key])
+    for key, subs in (("e2e_stdin", ("text", "text_spliced", "bgzf")), ("e2e_eight_workers_one_gpu", ("text", "bgzf")),
+                      ("e2e_all_devices", ("text", "bgzf"))):
+        grp = full.get(key)
+        if isinstance(grp, dict):
+            for sub in subs:
+                if sub in grp:
+                    sm = _leg_summary(grp[sub])
+                    if sub == "text" and isinstance(grp.get("full_output_check"), dict):
+                        sm["sha256_equal"] = bool(grp["full_output_check"].get("equal"))
+                    line["%s_%s" % (key, sub)] = sm
+    if "host_legs_error" in full:
+        line["host_legs_error"] = str(full["host_legs_error"])[:160]
+    line["full"] = "bench_full.json"
+    txt = json.dumps(line, separators=(",", ":"))
+    # never let the record outgrow what the driver reads: drop the least important keys first
+    for k in ("real_data_frac", "e2e_eight_workers_one_gpu_bgzf", "e2e_stdin_text_spliced", "e2e_all_devices_bgzf",
+              "e2e_eight_workers_one_gpu_text", "e2e_stdin_bgzf", "e2e_stdin_text", "per_rank_variants_per_s"):
+        if len(txt) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+        txt = json.dumps(line, separators=(",", ":"))
+    assert len(txt) <= LINE_LIMIT, len(txt)
+    return txt
+
+
+def emit(full):
+    """bench_full.json next to bench.py (and under gpurun_out/ when it exists), then the compact line as the LAST line
+    of stdout"""
+    blob = json.dumps(full, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(blob)
+            except OSError:
+                pass
+    sys.stdout.flush()
+    print(compact_line(full), flush=True)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` without a launcher: this parent -- which has made no GPU call and has imported neither
+    torch nor the library -- starts one rank per GPU as a CHILD process (torch.distributed.run), relays its stdout and
+    exits with its code; rank 0's compact line is repeated at the end if anything was printed after it."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    last_json, last = None, None
+    for raw in p.stdout:
+        ln = raw.decode(errors="replace").rstrip("\n")
+        print(ln, flush=True)
+        last = ln
+        if ln.startswith('{"metric"'):
+            last_json = ln
+    rc = p.wait()
+    if last_json is not None and last is not last_json:
+        print(last_json, flush=True)
+    return rc
+
+
+def cpu_dry(args):
+    """--cpu-dry: the N > 1 plumbing of this file -- launch, rank shards, barrier, max-over-ranks clock, the count
+    reduction, rank 0's line -- over gloo with NO GPU: every rank runs the CPU oracle (the checker, as tests/test_dist_cpu.py
+    does) over its own small shard.  It measures nothing about the product and says so in `metric`."""
+    import torch
+    import torch.distributed as dist
+    import benchgen as bg
+    import oracle_lib as orc
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, n_blocks = min(args.rows, 400), min(args.blocks, 2)
+    cfg = bg.make_cfg(args.profile, **({"n_samples": args.samples} if args.samples else {}))
+    hdr = bg.header(cfg)
+    texts = [hdr + bg.rows_host(cfg, first, rows) for first in rank_blocks(rank, n_blocks, rows)]
+
+    def step():
+        n = 0
+        for t in texts:
+            rc, _, _, k = orc.run(t)
+            assert rc == 0
+            n += k
+        return n
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n_var = sum(step() for _ in range(args.steps))
+    if world > 1:
+        dist.barrier()
+    mine = time.perf_counter() - t0
+    elapsed, total = reduce_over_ranks(mine, n_var, "cpu", world)
+    ones, rates = rank_census(n_var / mine, "cpu", world)
+    if rank == 0:
+        emit({"metric": "cpu-dry plumbing check (oracle per rank over gloo; NOT the product, NOT variants/sec of anything shipped)",
+              "value": total / elapsed, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "u8", "data": "synthetic",
+              "config": {"workload": "cpu-dry: " + WORKLOADS[args.profile], "rows_per_step_per_gpu": rows * n_blocks, "rows_per_block": rows,
+                         "resident_blocks_per_gpu": n_blocks, "n_samples": cfg.n_samples, "input": "host memory (no GPU)"},
+              "ranks_seen": ones, "per_rank_variants_per_s": rates, "rows_in_timed_region": int(total)})
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def rank_census(my_rate, device, world):
+    """(ranks seen = all-reduce of ones, every rank's own variants/s): the N > 1 line shows that every rank took part"""
+    import torch
+    import torch.distributed as dist
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    rates = torch.zeros(world, dtype=torch.float64, device=device)
+    rates[int(os.environ.get("RANK", "0")) if world > 1 else 0] = my_rate
+    if world > 1:
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        dist.all_reduce(rates, op=dist.ReduceOp.SUM)
+    return int(one.item()), [float(v) for v in rates.tolist()]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -604,23 +851,39 @@ def main():
     ap.add_argument("--golden", action="store_true",
                     help="experiment: real 1000-Genomes lines (tests/golden/1kg_chr1_20klines.vcf.gz, 19 747 rows "
                          "replicated to --rows) instead of the synthetic model")
+    ap.add_argument("--cpu-dry", action="store_true",
+                    help="no GPU: the launch / shard / reduce plumbing over gloo with the CPU oracle per rank (a test of this "
+                         "file's N > 1 path, not a measurement)")
+    ap.add_argument("--all-devices-rows", type=int, default=6_200_000,
+                    help="N > 1: rows of rank 0's `bystro-vcf --devices 0,..,N-1` leg after the timed region; 0 = skip")
     args = ap.parse_args()
     d_rows, d_blocks = SHAPES[args.profile]
     args.rows = args.rows or d_rows
     args.blocks = args.blocks or d_blocks
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (before anything here touches torch or the GPU)
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.cpu_dry:
+        return cpu_dry(args)
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
+    host_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # a host-side group for the wait at the very end (rank 0 runs the CLI over every device then: the other ranks
+        # must not sit in a spinning RCCL kernel on theirs)
+        import datetime
+        host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30))
 
     import benchgen as bg
     import bystro_vcf_amd as bv
@@ -683,14 +946,23 @@ def main():
 
     assert counts[0] == args.rows, counts
     # the final count gather over RCCL/xGMI (and the slowest rank's clock)
+    my_rate = args.rows * n_launch / elapsed
     elapsed, total_variants = reduce_over_ranks(elapsed, args.rows * n_launch, "cuda", world)
+    ranks_seen, per_rank = rank_census(my_rate, "cuda", world)
     # outside the timed region (rank 0): the same chain strictly one block after the other, for the dominant
     # kernel's duration when it has the GPU to itself
-    alone_ms, alone_chain_ms = None, None
+    alone_ms, alone_chain_ms, default_slots_rate = None, None, None
     if rank == 0:
         a_chain, alone, _ = ctx.bench_device(ptrs, sizes, max(args.blocks, 8), slots=1)
         alone_ms = sum(alone) / len(alone)
         alone_chain_ms = sum(a_chain) / len(a_chain)
+        if world == 1 and args.slots != LIBRARY_DEFAULT_SLOTS:
+            # the same timed region with the library's default number of blocks in flight (bvcf_params.n_slots = 0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.bench_device(ptrs, sizes, n_launch, slots=LIBRARY_DEFAULT_SLOTS)
+            torch.cuda.synchronize()
+            default_slots_rate = args.rows * n_launch / (time.perf_counter() - t1)
 
     if rank == 0:
         mean_bytes = sum(sizes) / len(sizes)
@@ -737,6 +1009,9 @@ def main():
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": (pmc * args.rows) if pmc else None,
+                # NOT measured in this run (PMC counters need rocprofv3 around the process): the per-row figure of the
+                # committed counter passes, times this run's rows per launch
+                "traffic_source": "profiles/k_gt_hbm_traffic.json (rocprofv3 --pmc passes, tools/derive_traffic.py); not measured in this run" if pmc else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "mean_launch_ms": alone_ms,
                 "how": "HIP events around the kernel on its launch stream, one block at a time (the kernel alone on the GPU), "
@@ -755,6 +1030,12 @@ def main():
             "text_GBps": sum(sizes) * world / (elapsed / args.steps) / 1e9,
             "variants_per_min": total_variants / elapsed * 60,
         }
+        if default_slots_rate:
+            line["value_at_library_default_slots"] = default_slots_rate
+            line["config"]["library_default_slots"] = LIBRARY_DEFAULT_SLOTS
+        if world > 1:
+            line["ranks_seen"] = ranks_seen
+            line["per_rank_variants_per_s"] = per_rank
         if world == 1 and streaming and args.profile == "c3" and not args.golden and not args.no_real_data:
             try:
                 line["real_data"] = real_data_leg(bv, bg, cfg, local_rank, args, kernel, achieved)
@@ -763,7 +1044,16 @@ def main():
         want_host_legs = world == 1 and not args.golden and not (args.no_e2e and args.no_cpu_baseline)
         if want_host_legs:
             host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, ctx.close)
-        print(json.dumps(line))
+    if world > 1:
+        # every rank lets go of its device (the CLI of rank 0 is about to use all of them), then waits on the host
+        if rank == 0 and args.all_devices_rows > 0 and not args.no_e2e and not args.golden:
+            all_devices_leg(line, args, cfg, bg, bv, blocks, sizes, world, ctx.close)
+        ctx.close()
+        blocks.clear()
+        torch.cuda.empty_cache()
+        dist.barrier(group=host_group)
+    if rank == 0:
+        emit(line)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -123,6 +123,7 @@ struct bvcf_ctx {
   uint32_t cmap_stride = 0;
   uint32_t dosage_stride = 0;  // 0 unless want_dosage
   uint64_t max_lines = 0, max_alleles = 0, max_cmap = 0;
+  uint64_t need_extras = 0;  // packed / k_sites1 ctxs: extra ALT records of the last batch that did not fit (they sit behind slot max_lines)
   FilterTable *d_filters = nullptr;
   uint32_t s1_fmode = 0, s1_fkey[4] = {0, 0, 0, 0}, s1_flen[4] = {0, 0, 0, 0};  // k_sites1's view of the allow list
   std::vector<Slot> slots;
@@ -672,10 +673,12 @@ static bool launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_de
 // the kernel chain of the batch in slot s over the resident text src[0 .. nbytes), the counter read-back and the event
 // bvcf_collect waits for
 int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
+  HIP_TRY(c, hipEventRecord(s.ev_k0, s.stream));
+  // (k_census_tiles of THIS chain zeroes the other parity's group totals for the slot's next batch: the flip and the
+  // launch go together, nothing that can return early sits between them)
   s.s2_parity ^= 1u;
   KernelArgs a = make_args(c, s, src, nbytes);
   s.used_gen = a.gen_stream != 0;
-  HIP_TRY(c, hipEventRecord(s.ev_k0, s.stream));
   launch_chain(c, a, s.stream, nullptr, nullptr);
   const bool names = c->names_on && s.d_name_lists;
   if (names) launch_names(c, a, make_name_args(c, s), s.stream);
@@ -1095,6 +1098,8 @@ int bvcf_reserve(bvcf_ctx *c, uint64_t lines, uint64_t alleles, uint64_t cmap_by
   if (lines > 0xFFFFFFF0ull || alleles > 0xFFFFFFF0ull) return BVCF_E_ARG;
   c->max_lines = std::max<uint64_t>(c->max_lines, lines);
   c->max_alleles = std::max<uint64_t>(std::max<uint64_t>(c->max_alleles, alleles), c->max_lines + 64);
+  if (c->sites1 || c->packed)
+    c->max_alleles = std::min<uint64_t>(std::max<uint64_t>(c->max_alleles, c->max_lines + c->need_extras + c->need_extras / 4 + 64), 0xFFFFFFF0ull);
   c->max_cmap = std::min<uint64_t>(std::max<uint64_t>(c->max_cmap, (cmap_bytes + 63) & ~63ull), 0xFFFFFF00ull);
   HIP_TRY(c, hipSetDevice(c->device));
   for (auto &s : c->slots) {
@@ -1354,6 +1359,9 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     r->need_lines = ctr.n_lines;
     r->need_alleles = need_alleles;
     r->need_cmap_bytes = cmap_bytes;
+    // (the extras of a packed ctx follow slot cap_lines: once the lines grow, so does where they start -- bvcf_reserve
+    // adds them to the NEW line capacity, need_alleles alone is relative to the old one)
+    c->need_extras = (c->sites1 || c->packed) ? (uint64_t)ctr.n_alleles : 0;
     c->err = "batch exceeds reserved result capacity";
     release();
     return BVCF_E_CAPACITY;

@@ -382,7 +382,8 @@ void Driver::device_main(DevWorker *W) {
     const double t0 = now_s();
     int r = bvcf_collect(W->ctx, &res);
     n_collects++;
-    if (r == BVCF_E_CAPACITY) {
+    // (a batch can ask twice: what it needs of one array may only show once another has grown)
+    for (int grown = 0; r == BVCF_E_CAPACITY && grown < 4; grown++) {
       // drop what is in flight here, let the formatter finish with the arrays that are about to be reallocated,
       // grow, resubmit everything still queued on this device
       wait_formatted(n_jobs);

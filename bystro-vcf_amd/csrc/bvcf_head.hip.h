@@ -551,7 +551,8 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
           return ex - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(seg_lane * 4u), (int)ex);
         };
         const uint32_t stop_me = (pl && e.stop) ? 1u : 0u;
-        const bool dropped_me = o_dropped != 0u || seg_excl(stop_me) != 0u;
+        const uint32_t stops_before = seg_excl(stop_me);  // (wave-wide DPP scan + bpermute: every lane takes part, no short circuit)
+        const bool dropped_me = o_dropped != 0u || stops_before != 0u;
         const bool live = pl && !dropped_me;
         const uint32_t n_me = live ? e.n : 0u;
         const uint32_t tk_me = (live && ns > 0 && k > 0 && e.n > 0) ? 1u : 0u;

@@ -3,6 +3,7 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <poll.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
@@ -138,10 +139,22 @@ ssize_t ByteSource::read_fifo_fanout(uint8_t *dst, size_t cap) {
   int splice_err = 0;
   unsigned k = 0;
   std::vector<std::thread> th;
+  // (a copier that has failed no longer empties its pipe: a blocking splice into it would never return, so the wait for
+  // room there and for input is a poll that looks at the flag every 100 ms)
+  auto wait_ready = [&](int fd, short ev) {
+    struct pollfd pf = {fd, ev, 0};
+    while (!copier_failed.load()) {
+      const int r = poll(&pf, 1, 100);
+      if (r > 0 || (r < 0 && errno != EINTR)) return;
+    }
+  };
   while (total < cap && !copier_failed.load()) {
     const size_t want = std::min<size_t>(1u << 20, cap - total);
-    const ssize_t m = splice(fd_, nullptr, fan_[k][1], nullptr, want, SPLICE_F_MOVE);
-    if (m < 0 && errno == EINTR) continue;
+    wait_ready(fan_[k][1], POLLOUT);
+    wait_ready(fd_, POLLIN);
+    if (copier_failed.load()) break;
+    const ssize_t m = splice(fd_, nullptr, fan_[k][1], nullptr, want, SPLICE_F_MOVE | SPLICE_F_NONBLOCK);
+    if (m < 0 && (errno == EINTR || errno == EAGAIN)) continue;
     if (m < 0) {
       if (total == 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) return kFanoutUnavailable;  // (no threads yet)
       splice_err = errno;

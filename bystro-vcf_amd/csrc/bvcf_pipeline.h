@@ -18,6 +18,7 @@
 #include "bvcf_host_internal.h"
 #include "../../include/bvcf_plan.h"
 
+#include <atomic>
 #include <sched.h>
 
 #include <set>
@@ -198,6 +199,7 @@ struct DevWorker {
   std::set<uint64_t> done_early;  // ... and these above it
   // the worker's readers hand their ranges over in order: next_push = the worker-local number of the range whose turn it is
   uint64_t next_push = 0;
+  std::atomic<unsigned> readers_done{0};  // range_text_reader: the LAST of the worker's readers stops its buffer pool
   // timing
   double t_warm = 0, t_ctx = 0, t_submit = 0, t_gpu = 0, t_fmt_wait = 0, t_first_submit = 0, t_starved = 0, t_fmt = 0, t_read = 0;
   uint64_t n_blocks = 0, n_bytes = 0;

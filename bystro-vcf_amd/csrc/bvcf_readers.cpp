@@ -309,7 +309,9 @@ void Driver::range_text_reader(DevWorker *W, unsigned r) {
     hold.reset();
     push_in_turn(W, j, out);
   }
-  W->pool->stop();
+  // (the pool's allocator threads stop pinning more buffers once nobody will ask for one: only when the LAST reader is
+  // through -- a reader with no range of its own must not end the pool under its sibling, which may not hold a buffer yet)
+  if (W->readers_done.fetch_add(1) + 1 == stride) W->pool->stop();
   {
     std::lock_guard<std::mutex> lk(W->mu);
     W->t_read += t_read;

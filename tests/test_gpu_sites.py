@@ -284,3 +284,37 @@ def test_packed_form_record_by_record(bv, kernel):
             assert (a[f] == b[f]).all(), (i, f)
     key = lambda e: (int(e["line"]), int(e["alt_no"]), int(e["code"]))
     assert sorted(map(key, new.errs)) == sorted(map(key, old.errs)) and len(old.errs) > 0
+
+
+def test_packed_ctx_grows_lines_and_extra_alt_records_together(bv, kernel):
+    """short sites-only lines (about 21 bytes against the 48-byte floor of the first reservation) with three ALTs each:
+    the batch overflows on lines AND carries far more than 64 extra ALT records, which a packed ctx keeps behind slot
+    cap_lines -- growing the lines moves where they start, so the reservation must grow with the NEW line capacity
+    (round 4's advisor finding: the second collect failed with "batch exceeds reserved result capacity").  Library level
+    with the driver's own growth rule, then the CLI."""
+    import os
+    import subprocess
+    n = 30_000
+    body = "".join("1\t%d\t.\tA\tC,G,T\t.\t.\t.\n" % (100 + i) for i in range(n)).encode()
+    vcf = H8.encode() + body
+    ctx = bv.Ctx(8, allow="", max_batch_bytes=len(body), max_lines=256, max_alleles=320, packed_sites="packed" in kernel)
+    try:
+        need = None
+        for _ in range(4):
+            ctx.submit(body)
+            r = bv.Result()
+            rc = bv.lib.bvcf_collect(ctx.h, bv.C.byref(r))
+            if rc != bv.E_CAPACITY:
+                break
+            need = (r.need_lines, r.need_alleles)
+            ctx.reserve(r.need_lines + r.need_lines // 4 + 64, r.need_alleles + r.need_alleles // 4 + 64, r.need_cmap_bytes + 4096)
+        assert need is not None and rc == 0, (rc, need)
+        assert r.n_lines == n
+    finally:
+        ctx.close()
+    out = both(bv, vcf, {"allow": ""})
+    assert out.count(b"\n") == 3 * n
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bystro-vcf_amd", "bystro-vcf")
+    p = subprocess.run([exe, "--allowFilter", "", "--batchMB", "1"], input=vcf, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert p.stdout == (bv.string_header() + "\n").encode() + out
