@@ -671,7 +671,7 @@ def compact_line(full):
     rf = full.get("roofline")
     if isinstance(rf, dict):
         line["roofline"] = {k: _sig(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
-                                                           "algorithmic_bytes_per_launch", "mean_launch_ms", "chain_frac")}
+                                                           "algorithmic_bytes_per_launch", "mean_launch_ms", "chain_frac", "chain_ms_one_block_at_a_time")}
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         line["cpu_baseline"] = {k: _sig(cb.get(k)) for k in ("value", "unit", "cores", "kind")}

@@ -666,6 +666,9 @@ __global__ __launch_bounds__(kWgThreads) void k_stream_gen(KernelArgs a) {
   uint32_t *list = reinterpret_cast<uint32_t *>(s_gen + (uint32_t)kWavesPerWg * ((uint32_t)kGenRing * kChunk + stage_bytes)) + wave_in_wg() * 64u;
   const int lane = lane_id();
   const uint32_t wave = wave_in_grid();
+#ifdef BVCF_EXP_TIMES
+  if (lane == 0 && wave < 32768u) g_wave_t[0][wave] = wall_clock64();
+#endif
   const uint32_t n_waves = gridDim.x * kWavesPerWg;
   const uint32_t ns = a.n_samples;
   const uint32_t nb = a.nbytes;
@@ -733,6 +736,9 @@ __global__ __launch_bounds__(kWgThreads) void k_stream_gen(KernelArgs a) {
   }
   if (lane == 0 && seen) atomicAdd(&a.counters->lines_seen, seen);
   if (lane == 0 && n_regular) atomicAdd(&a.counters->n_other_shape, n_regular);
+#ifdef BVCF_EXP_TIMES
+  if (lane == 0 && wave < 32768u) g_wave_t[1][wave] = wall_clock64();
+#endif
 }
 
 }  // namespace bvcf_dev

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of two libbvcf builds (not a test): alternates BVCF_LIB between the given .so files
 and prints per-build medians of the dominant kernel and of the chain.
-usage: python tools/ab_bench.py libA.so libB.so [rounds] [-- extra bench.py args]"""
+usage: python tools/ab_bench.py libA.so libB.so [libC.so ...] [rounds] [-- extra bench.py args]"""
 import json
 import os
 import statistics
@@ -14,8 +14,9 @@ extra = []
 if "--" in args:
     k = args.index("--")
     args, extra = args[:k], args[k + 1:]
-libs = args[:2]
-rounds = int(args[2]) if len(args) > 2 else 4
+libs = [x for x in args if x.endswith(".so")]
+rest = [x for x in args if not x.endswith(".so")]
+rounds = int(rest[0]) if rest else 4
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
