@@ -27,7 +27,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 DEVICE_PAD = 64
 NO_CMAP = 0xFFFFFFFF
 
@@ -46,7 +46,7 @@ PLAN_EXPORTS = ["bvcf_plan_text_ranges", "bvcf_plan_bgzf_ranges", "bvcf_cut_text
 
 # every symbol include/bvcf.h declares
 EXPORTS = [
-    "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_set_sample_names", "bvcf_alloc_pinned", "bvcf_alloc_pinned_near", "bvcf_warmup",
+    "bvcf_create", "bvcf_destroy", "bvcf_last_error", "bvcf_version", "bvcf_reserve", "bvcf_set_sample_names", "bvcf_set_row_format", "bvcf_alloc_pinned", "bvcf_alloc_pinned_near", "bvcf_warmup",
     "bvcf_free_pinned", "bvcf_submit", "bvcf_submit_device", "bvcf_submit_bgzf", "bvcf_collect", "bvcf_counters", "bvcf_sum_counters",
     "bvcf_allreduce_counters", "bvcf_device_count", "bvcf_device_pci_bus_id", "bvcf_path", "bvcf_config_defaults", "bvcf_string_header", "bvcf_format_tsv", "bvcf_run_buffer", "bvcf_run_fd", "bvcf_decompress_fd", "bvcf_bgzf_inflate_device", "bvcf_free",
     "bvcf_arrow_open", "bvcf_arrow_append", "bvcf_arrow_close",
@@ -60,7 +60,7 @@ class Params(C.Structure):
         ("want_dosage", C.c_uint8), ("want_name_lists", C.c_uint8), ("allow_filter", C.c_char_p), ("exclude_filter", C.c_char_p),
         ("max_batch_bytes", C.c_uint64), ("max_lines", C.c_uint32), ("max_alleles", C.c_uint32),
         ("cmap_bytes", C.c_uint64), ("n_slots", C.c_uint32), ("path", C.c_uint32),
-        ("packed_sites", C.c_uint32), ("reserved", C.c_uint32),
+        ("packed_sites", C.c_uint32), ("render_sites", C.c_uint32),
     ]
 
 
@@ -86,10 +86,12 @@ class Result(C.Structure):
         ("n_lines_seen", C.c_uint64), ("dosage", C.c_void_p), ("dosage_stride", C.c_uint32), ("reserved2", C.c_uint32),
         ("name_lists", C.c_void_p), ("names", C.c_void_p), ("n_name_bytes", C.c_uint64),
         ("text", C.c_void_p), ("n_text_bytes", C.c_uint64), ("head_off", C.c_void_p),
-        ("sites", C.c_void_p), ("n_full_lines", C.c_uint32), ("reserved3", C.c_uint32),
+        ("sites", C.c_void_p), ("n_full_lines", C.c_uint32), ("n_row_cuts", C.c_uint32),
+        ("rows", C.c_void_p), ("n_row_bytes", C.c_uint64), ("row_cuts", C.c_void_p), ("n_ok_sites", C.c_uint64),
     ]
 
 
+ROW_CUT_DTYPE = np.dtype([("line", "<u4"), ("slot", "<u4"), ("off", "<u8")])
 LINE_DTYPE = np.dtype([
     ("off", "<u4"), ("len", "<u4"), ("fend", "<u4", (9,)), ("rec_first", "<u4"), ("n_rec", "<u4"),
     ("n_fields", "<u4"), ("gt_task", "<u4"), ("status", "u1"), ("site_type", "u1"), ("pad", "u1", (2,))])
@@ -340,6 +342,11 @@ class Batch:
             return np.frombuffer(C.string_at(ptr, n * dt.itemsize), dtype=dt).copy()
 
         self.sites = None
+        # bvcf_params.render_sites: the rows of the lines the packed form settles, and where the other lines' rows belong
+        self.rows = C.string_at(r.rows, r.n_row_bytes) if r.rows and r.n_row_bytes else b""
+        self.row_cuts = arr(r.row_cuts, r.n_row_cuts, ROW_CUT_DTYPE) if r.row_cuts else np.zeros(0, dtype=ROW_CUT_DTYPE)
+        self.n_ok_sites = r.n_ok_sites
+        self.rendered = bool(r.rows) or (not r.sites and r.n_row_cuts > 0) or bool(r.n_ok_sites)
         if r.sites:
             # the packed form of a file without samples (bvcf_params.packed_sites): expanded here into the arrays of the full
             # form, so that line i is lines[i] and its first record alleles[i] whichever way the batch came back
@@ -347,9 +354,15 @@ class Batch:
             self.full_lines = arr(r.lines, r.n_full_lines, LINE_DTYPE)
             raw = arr(r.alleles, r.n_alleles, ALLELE_DTYPE)
             self.lines, self.alleles = self._expand(self.sites, self.full_lines, raw, r.n_lines)
+        elif r.row_cuts:
+            # rendered rows (bvcf_params.render_sites): only the lines left to the host have records -- lines[cut.slot]
+            self.full_lines = arr(r.lines, r.n_full_lines, LINE_DTYPE)
+            self.lines = self.full_lines
+            self.alleles = arr(r.alleles, r.n_alleles, ALLELE_DTYPE)
         else:
             self.lines = arr(r.lines, r.n_lines, LINE_DTYPE)
             self.alleles = arr(r.alleles, r.n_alleles, ALLELE_DTYPE)
+        self.n_lines = r.n_lines
         self.errs = arr(r.errs, r.n_errs, ERR_DTYPE)
         self.cmap = arr(r.cmap, r.n_cmap_bytes, np.dtype("u1"))
         # want_dosage: one int8 row per alleles[] slot (rows of slots without a record hold garbage)
@@ -449,7 +462,8 @@ class Ctx:
 
     def __init__(self, n_header_fields, allow="PASS,.", exclude="", device=0, eol_chars=1, eol_byte=b"\n",
                  max_batch_bytes=0, max_lines=0, max_alleles=0, cmap_bytes=0, n_slots=0, want_class_maps=True,
-                 path=0, want_dosage=False, sample_names=None, delimiter=";", packed_sites=False):
+                 path=0, want_dosage=False, sample_names=None, delimiter=";", packed_sites=False, render_sites=False,
+                 empty_field="!", keep_pos=False, keep_id=False, keep_info=False):
         p = Params()
         p.abi_version = ABI_VERSION
         p.device = device
@@ -466,12 +480,16 @@ class Ctx:
         p.cmap_bytes = cmap_bytes
         p.n_slots = n_slots
         p.path = path
-        p.packed_sites = int(packed_sites)
+        p.packed_sites = int(packed_sites or render_sites)
+        p.render_sites = int(render_sites)
         p.want_name_lists = int(sample_names is not None)
         self.h = C.c_void_p()
         rc = lib.bvcf_create(C.byref(self.h), C.byref(p))
         if rc:
             raise BvcfError(rc, lib.bvcf_last_error(None).decode())
+        if render_sites:
+            lib.bvcf_set_row_format.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+            self._check(lib.bvcf_set_row_format(self.h, empty_field.encode(), int(keep_pos), int(keep_id), int(keep_info)))
         if sample_names is not None:  # device-side rendering of the het / hom / missing name lists
             enc = [x.encode() if isinstance(x, str) else x for x in sample_names]
             ptrs = (C.c_char_p * max(len(enc), 1))(*enc)

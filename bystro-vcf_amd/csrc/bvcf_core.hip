@@ -35,6 +35,13 @@ struct Slot {
   bvcf_line *d_lines = nullptr;
   bvcf_allele *d_alleles = nullptr;
   bvcf_site *d_sites = nullptr, *h_sites = nullptr;  // packed ctxs only
+  // bvcf_params.render_sites: the stream of rendered rows, the lines left to the host, the scan's group arrays and totals
+  uint8_t *d_rows = nullptr, *h_rows = nullptr;
+  uint64_t cap_rows = 0, rows_precopied = 0;  // (precopied: bytes of the stream that went to the host behind the kernels)
+  bvcf_row_cut *d_row_cuts = nullptr, *h_row_cuts = nullptr;
+  uint32_t cap_row_cuts = 0, cap_render_groups = 0;
+  unsigned long long *d_rgroup_bytes = nullptr, *d_rtotals = nullptr, *h_rtotals = nullptr;
+  uint32_t *d_rgroup_full = nullptr;
   bvcf_err *d_errs = nullptr;
   uint8_t *d_cmap = nullptr;
   int8_t *d_dosage = nullptr;
@@ -119,6 +126,11 @@ struct bvcf_ctx {
   int sites_grid = 0, sites1_grid = 0;
   uint32_t win_bytes = 64u << 10;  // wide: bytes of a line's sample region per wave of the split general scan
   uint32_t tile_bytes = 0, tile_quota = 0;
+  // bvcf_params.render_sites (packed ctxs): rows made on the device; the format comes with bvcf_set_row_format
+  bool render = false, row_fmt_set = false;
+  double row_ratio = 0;  // row bytes per byte of text in the last batch: how much of the next stream is copied ahead
+  uint8_t *d_row_fmt = nullptr;  // "chr" | "\tSNP\t" | the constant tail
+  uint32_t row_tail_len = 0, row_keep_pos = 0, row_keep_id = 0, row_keep_info = 0;
   uint32_t n_samples = 0;
   uint32_t cmap_stride = 0;
   uint32_t dosage_stride = 0;  // 0 unless want_dosage
@@ -189,6 +201,14 @@ void free_slot(Slot &s) {
   hipFree(s.d_alleles);
   hipFree(s.d_sites);
   hipHostFree(s.h_sites);
+  hipFree(s.d_rows);
+  hipHostFree(s.h_rows);
+  hipFree(s.d_row_cuts);
+  hipHostFree(s.h_row_cuts);
+  hipFree(s.d_rgroup_bytes);
+  hipFree(s.d_rgroup_full);
+  hipFree(s.d_rtotals);
+  hipHostFree(s.h_rtotals);
   hipFree(s.d_errs);
   hipFree(s.d_cmap);
   hipFree(s.d_dosage);
@@ -327,7 +347,8 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
   HIP_TRY(c, hipMalloc(&s.d_alleles, c->max_alleles * sizeof(bvcf_allele)));
   if (c->packed) {
     HIP_TRY(c, hipMalloc(&s.d_sites, (c->max_lines + 64) * sizeof(bvcf_site)));
-    HIP_TRY(c, hipHostMalloc(&s.h_sites, (c->max_lines + 64) * sizeof(bvcf_site), hipHostMallocDefault));
+    if (!c->render)  // (rendered rows: the site records never leave the device)
+      HIP_TRY(c, hipHostMalloc(&s.h_sites, (c->max_lines + 64) * sizeof(bvcf_site), hipHostMallocDefault));
   }
   HIP_TRY(c, hipMalloc(&s.d_errs, c->max_alleles * sizeof(bvcf_err)));
   HIP_TRY(c, hipMalloc(&s.d_cmap, c->max_cmap + 64));
@@ -670,9 +691,93 @@ static bool launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_de
   return true;
 }
 
+// bvcf_params.render_sites: the slot's row stream and the list of the lines left to the host
+int ensure_render_buffers(bvcf_ctx *c, Slot &s, uint64_t need_rows = 0) {
+  // (what a batch of a typical file takes, not the worst case -- a row is a third of its line in a dbSNP-like file, and
+  // pinned memory costs 0.25 ms per megabyte to get: a batch whose rows outgrow the stream grows it, bvcf_collect)
+  const uint64_t extra = c->row_keep_info ? c->p.max_batch_bytes : 0;
+  const uint64_t want_rows = std::max<uint64_t>(need_rows, c->p.max_batch_bytes / 2 + extra + (1u << 20));
+  const uint32_t want_cuts = (uint32_t)std::min<uint64_t>(c->max_lines + 64, 0xFFFFFFF0ull);
+  const uint32_t want_groups = (uint32_t)((c->max_lines + kRenderGroup - 1) / kRenderGroup + 2);
+  // (the stream on its own: when a batch's rows outgrew it, the prefixes k_render_scan left in the group arrays are what
+  // the second k_render_rows works from)
+  if (!s.d_rows || s.cap_rows < want_rows) {
+    HIP_TRY(c, hipStreamSynchronize(s.stream));
+    hipFree(s.d_rows);
+    hipHostFree(s.h_rows);
+    s.d_rows = s.h_rows = nullptr;
+    s.cap_rows = 0;
+    HIP_TRY(c, hipMalloc(&s.d_rows, want_rows));
+    HIP_TRY(c, hipHostMalloc(&s.h_rows, want_rows, hipHostMallocDefault));
+    s.cap_rows = want_rows;
+  }
+  if (!s.d_row_cuts || s.cap_row_cuts < want_cuts || s.cap_render_groups < want_groups) {
+    HIP_TRY(c, hipStreamSynchronize(s.stream));
+    hipFree(s.d_row_cuts);
+    hipHostFree(s.h_row_cuts);
+    hipFree(s.d_rgroup_bytes);
+    hipFree(s.d_rgroup_full);
+    s.d_row_cuts = s.h_row_cuts = nullptr;
+    s.d_rgroup_bytes = nullptr;
+    s.d_rgroup_full = nullptr;
+    s.cap_row_cuts = s.cap_render_groups = 0;
+    HIP_TRY(c, hipMalloc(&s.d_row_cuts, (size_t)want_cuts * sizeof(bvcf_row_cut)));
+    HIP_TRY(c, hipHostMalloc(&s.h_row_cuts, (size_t)want_cuts * sizeof(bvcf_row_cut), hipHostMallocDefault));
+    HIP_TRY(c, hipMalloc(&s.d_rgroup_bytes, (size_t)want_groups * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc(&s.d_rgroup_full, (size_t)want_groups * sizeof(uint32_t)));
+    s.cap_row_cuts = want_cuts;
+    s.cap_render_groups = want_groups;
+  }
+  if (!s.d_rtotals) {
+    HIP_TRY(c, hipMalloc(&s.d_rtotals, 4 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipHostMalloc(&s.h_rtotals, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  return BVCF_OK;
+}
+
+// ... and its three kernels behind k_sites2p (bvcf_render.hip.h), the totals on their way to the host
+RenderArgs make_render_args(bvcf_ctx *c, Slot &s, const KernelArgs &a) {
+  RenderArgs ra{};
+  ra.sites = a.sites;
+  ra.text = a.buf;
+  ra.rows = s.d_rows;
+  ra.rows_cap = s.cap_rows;
+  ra.cuts = s.d_row_cuts;
+  ra.cuts_cap = s.cap_row_cuts;
+  ra.n_groups_cap = s.cap_render_groups - 2u;
+  ra.group_bytes = s.d_rgroup_bytes;
+  ra.group_full = s.d_rgroup_full;
+  ra.totals = s.d_rtotals;
+  ra.counters = a.counters;
+  ra.fmt = c->d_row_fmt;
+  ra.tail_len = c->row_tail_len;
+  ra.keep_pos = c->row_keep_pos;
+  ra.keep_id = c->row_keep_id;
+  ra.keep_info = c->row_keep_info;
+  return ra;
+}
+int launch_render(bvcf_ctx *c, Slot &s, const KernelArgs &a) {
+  const RenderArgs ra = make_render_args(c, s, a);
+  HIP_TRY(c, hipMemsetAsync(s.d_rtotals, 0, 4 * sizeof(unsigned long long), s.stream));
+  const uint32_t grid = (uint32_t)c->n_cu * 8u;
+  hipLaunchKernelGGL(k_render_len, dim3(grid), dim3(kWgThreads), 0, s.stream, ra);
+  hipLaunchKernelGGL(k_render_scan, dim3(1), dim3(1024), 0, s.stream, ra);
+  hipLaunchKernelGGL(k_render_rows, dim3(grid), dim3(kWgThreads), 0, s.stream, ra);
+  HIP_TRY(c, hipGetLastError());
+  return BVCF_OK;
+}
+
 // the kernel chain of the batch in slot s over the resident text src[0 .. nbytes), the counter read-back and the event
 // bvcf_collect waits for
 int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
+  if (c->render) {
+    if (!c->row_fmt_set) {
+      c->err = "bvcf_params.render_sites needs bvcf_set_row_format before the first batch";
+      return BVCF_E_ARG;
+    }
+    const int rc = ensure_render_buffers(c, s);
+    if (rc) return rc;
+  }
   HIP_TRY(c, hipEventRecord(s.ev_k0, s.stream));
   // (k_census_tiles of THIS chain zeroes the other parity's group totals for the slot's next batch: the flip and the
   // launch go together, nothing that can return early sits between them)
@@ -683,10 +788,20 @@ int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
   const bool names = c->names_on && s.d_name_lists;
   if (names) launch_names(c, a, make_name_args(c, s), s.stream);
   HIP_TRY(c, hipGetLastError());
+  if (c->render) {
+    const int rc = launch_render(c, s, a);
+    if (rc) return rc;
+  }
   HIP_TRY(c, hipEventRecord(s.ev_k1, s.stream));
   HIP_TRY(c, hipMemcpyAsync(s.h_counters, s.d_counters, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.stream));
-  if (names)
-    HIP_TRY(c, hipMemcpyAsync(s.h_name_total, s.d_name_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
+  if (c->render) {
+    HIP_TRY(c, hipMemcpyAsync(s.h_rtotals, s.d_rtotals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
+    // (Tried: as much of the stream as the last batch's rows-per-text ratio predicts copied to the host right here,
+    // behind the kernels, so that it crosses beside the next batches' uploads.  The slot's host buffer may still be read by
+    // the caller then -- results stay valid until the n_slots-th following COLLECT, a submit comes earlier -- and with a
+    // second buffer to make it legal the run was no faster: a sites-only run waits for the uploads, 40 GB/s.)
+    s.rows_precopied = 0;
+  }
   s.heads = s.is_bgzf && c->n_samples > 0 && s.d_head_off && nbytes > 0;
   if (s.heads) {
     HeadArgs h;
@@ -827,6 +942,7 @@ void bvcf_destroy(bvcf_ctx *c) {
   hipSetDevice(c->device);
   for (auto &s : c->slots) free_slot(s);
   hipFree(c->d_filters);
+  hipFree(c->d_row_fmt);
   hipFree(c->d_name_off);
   hipFree(c->d_name_text);
   delete c;
@@ -957,6 +1073,7 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   }
   if (const char *e = getenv("BVCF_S2_CENSUS")) c->sites2_tile_census = strcmp(e, "chunk") != 0;  // (A/B and parity tests)
   c->packed = c->sites2 && p->packed_sites != 0;
+  c->render = c->packed && p->render_sites != 0;
   per_cu = 0;
 #ifdef BVCF_EXPERIMENTS
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sites, kSitesThreads, 0) != hipSuccess || per_cu < 1)
@@ -1084,6 +1201,42 @@ int bvcf_set_sample_names(bvcf_ctx *c, const char *const *names, const uint32_t 
   c->names_on = true;
   for (auto &s : c->slots) {
     const int rc = alloc_names(c, s, std::max<uint64_t>(s.cap_names, c->p.max_batch_bytes / 2 + (1u << 20)));
+    if (rc) return rc;
+  }
+  return BVCF_OK;
+}
+
+int bvcf_set_row_format(bvcf_ctx *c, const char *empty_field, int keep_pos, int keep_id, int keep_info) {
+  if (!c) return BVCF_E_ARG;
+  if (c->in_flight) {
+    c->err = "bvcf_set_row_format with batches in flight";
+    return BVCF_E_BUSY;
+  }
+  const char *empty = empty_field ? empty_field : "!";
+  if (strlen(empty) > 16) {
+    c->err = "bvcf_set_row_format: --emptyField longer than 16 bytes (render the rows on the host: render_sites = 0)";
+    return BVCF_E_ARG;
+  }
+  // "chr" | "\tSNP\t" | the tail of a line without samples: three empty lists with their zero ratios, ac, an, sampleMaf
+  // (main.go:612-670 with no carriers)
+  std::string fmt = "chr\tSNP\t";
+  std::string tail = "\t";
+  for (int q = 0; q < 3; q++) {
+    tail += empty;
+    tail += "\t0\t";
+  }
+  tail += "0\t0\t0";
+  fmt += tail;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->d_row_fmt) HIP_TRY(c, hipMalloc(&c->d_row_fmt, 128));
+  HIP_TRY(c, hipMemcpy(c->d_row_fmt, fmt.data(), fmt.size(), hipMemcpyHostToDevice));
+  c->row_tail_len = (uint32_t)tail.size();
+  c->row_keep_pos = keep_pos != 0;
+  c->row_keep_id = keep_id != 0;
+  c->row_keep_info = keep_info != 0;
+  c->row_fmt_set = true;
+  for (auto &s : c->slots) {  // (now, while the caller is still setting up, not inside its first submits)
+    const int rc = ensure_render_buffers(c, s);
     if (rc) return rc;
   }
   return BVCF_OK;
@@ -1369,7 +1522,36 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   // the packed form: a site record per line, full records (lines[], their first alleles) only for the n_full lines that
   // asked for them
   const uint32_t n_first = c->packed ? std::min<uint32_t>(ctr.n_full, ctr.n_lines) : ctr.n_lines;
-  if (c->packed && ctr.n_lines)
+  // (rendered rows: the site records stay on the device; the stream and the list of the lines left to the host come back)
+  uint64_t row_bytes = 0, n_row_cuts = 0, n_ok_sites = 0;
+  if (c->render) {
+    row_bytes = s.h_rtotals[0];
+    n_row_cuts = s.h_rtotals[1];
+    n_ok_sites = s.h_rtotals[2];
+    if (n_row_cuts > s.cap_row_cuts) {
+      c->err = "internal error: more lines left to the host than the batch has lines";
+      release();
+      return BVCF_E_HIP;
+    }
+    if (row_bytes > s.cap_rows) {
+      // the stream was too small and k_render_rows wrote nothing: grow it and write again (the prefixes stand)
+      const int rc = ensure_render_buffers(c, s, row_bytes + row_bytes / 4 + (1u << 20));
+      if (rc) {
+        release();
+        return rc;
+      }
+      KernelArgs a = make_args(c, s, s.src, s.nbytes);
+      hipLaunchKernelGGL(k_render_rows, dim3((uint32_t)c->n_cu * 8u), dim3(kWgThreads), 0, s.stream, make_render_args(c, s, a));
+      HIP_TRY(c, hipGetLastError());
+      s.rows_precopied = 0;
+    }
+    if (row_bytes > s.rows_precopied)
+      HIP_TRY(c, hipMemcpyAsync(s.h_rows + s.rows_precopied, s.d_rows + s.rows_precopied, row_bytes - s.rows_precopied,
+                                hipMemcpyDeviceToHost, s.stream));
+    if (s.nbytes) c->row_ratio = (double)row_bytes / (double)s.nbytes;
+    if (n_row_cuts)
+      HIP_TRY(c, hipMemcpyAsync(s.h_row_cuts, s.d_row_cuts, n_row_cuts * sizeof(bvcf_row_cut), hipMemcpyDeviceToHost, s.stream));
+  } else if (c->packed && ctr.n_lines)
     HIP_TRY(c, hipMemcpyAsync(s.h_sites, s.d_sites, ctr.n_lines * sizeof(bvcf_site), hipMemcpyDeviceToHost, s.stream));
   if (n_first)
     HIP_TRY(c, hipMemcpyAsync(s.h_lines, s.d_lines, (size_t)n_first * sizeof(bvcf_line), hipMemcpyDeviceToHost, s.stream));
@@ -1449,6 +1631,13 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   // (packed form: the verdict of line i is in its site record, or in the full record that one points at)
   auto verdict_of = [&](uint32_t i) -> uint32_t {
     if (!c->packed) return s.h_lines[i].status;
+    if (c->render) {
+      // (only lines with full records log anything: found among the cuts, which are in line order)
+      const bvcf_row_cut *lo = s.h_row_cuts, *hi = s.h_row_cuts + n_row_cuts;
+      const bvcf_row_cut *it = std::lower_bound(lo, hi, i, [](const bvcf_row_cut &q, uint32_t v) { return q.line < v; });
+      if (it == hi || it->line != i || it->slot >= n_first) return (uint32_t)BVCF_LINE_FIELDS;
+      return s.h_lines[it->slot].status;
+    }
     const bvcf_site &st = s.h_sites[i];
     if (!(st.status & BVCF_SITE_FULL)) return st.status;
     return st.full_idx < n_first ? s.h_lines[st.full_idx].status : (uint32_t)BVCF_LINE_FIELDS;
@@ -1473,14 +1662,22 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   r->text = was_bgzf ? s.h_text : nullptr;
   r->n_text_bytes = was_bgzf ? text_bytes : 0;
   r->head_off = (was_bgzf && s.heads) ? s.h_head_off : nullptr;
-  r->sites = c->packed ? s.h_sites : nullptr;
+  r->sites = (c->packed && !c->render) ? s.h_sites : nullptr;
   r->n_full_lines = c->packed ? n_first : 0u;
+  r->rows = c->render ? s.h_rows : nullptr;
+  r->n_row_bytes = row_bytes;
+  r->row_cuts = c->render ? s.h_row_cuts : nullptr;
+  r->n_row_cuts = (uint32_t)n_row_cuts;
+  r->n_ok_sites = n_ok_sites;
   r->name_lists = names ? s.h_name_lists : nullptr;
   r->names = names ? s.h_names : nullptr;
   r->n_name_bytes = name_bytes;
 
   uint64_t ok = 0, ac0 = 0, recs = 0;
-  if (c->packed)
+  if (c->render) {
+    ok += n_ok_sites;
+    recs += n_ok_sites;
+  } else if (c->packed)
     for (uint32_t i = 0; i < ctr.n_lines; i++) {
       const bvcf_site &st = s.h_sites[i];
       if (!(st.status & BVCF_SITE_FULL)) {

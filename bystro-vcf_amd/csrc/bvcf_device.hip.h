@@ -43,6 +43,9 @@
 // ... and, kept as BVCF_SITES=3, the same body without the census (the text is read once, and it is slower):
 //   k_sites1       the tile's line count published at once, the line numbers found by a decoupled look-back
 //
+// ... and, on request (bvcf_params.render_sites, bvcf_render.hip.h), behind k_sites2p:
+//   k_render_len / k_render_scan / k_render_rows   the TSV rows of the lines the packed form settles, in input order
+//
 // Everything is byte/integer work over the line bytes; no MFMA.  The genotype scans are bound by
 // VALU issue at 57-70 % of the HBM peak.
 // Loads are 16 B per lane, 1 KiB per wave-instruction, from the dword at or before the byte the
@@ -60,5 +63,6 @@
 #include "bvcf_head.hip.h"
 #include "bvcf_sites.hip.h"
 #include "bvcf_sites1.hip.h"
+#include "bvcf_render.hip.h"
 #include "bvcf_names.hip.h"
 #include "bvcf_inflate.hip.h"

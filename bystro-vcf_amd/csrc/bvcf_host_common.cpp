@@ -122,6 +122,16 @@ const char *row_of(const bvcf_result *r, const uint8_t *block, uint32_t li, cons
 // biallelic SNP with its position taken verbatim (main.go:735-745).
 LineView line_view(const bvcf_result *r, uint32_t li, bvcf_line *tl, bvcf_allele *ta) {
   LineView v;
+  if (!r->sites && r->row_cuts) {
+    // rendered rows (bvcf_params.render_sites): only the lines left to the host are ever looked at, and their records are
+    // where their cut says (the cuts are in line order)
+    const bvcf_row_cut *lo = r->row_cuts, *hi = r->row_cuts + r->n_row_cuts;
+    const bvcf_row_cut *it = std::lower_bound(lo, hi, li, [](const bvcf_row_cut &q, uint32_t x) { return q.line < x; });
+    const uint32_t slot = (it != hi && it->line == li && it->slot < r->n_full_lines) ? it->slot : 0u;
+    v.L = &r->lines[slot];
+    v.A0 = &r->alleles[slot];
+    return v;
+  }
   if (!r->sites) {
     v.L = &r->lines[li];
     v.A0 = &r->alleles[li];
@@ -424,6 +434,37 @@ void format_log(const bvcf_result *r, const uint8_t *block, std::string &log) {
 void format_parts(const bvcf_config *c, const bvcf_result *r, const uint8_t *block, const Names &nm, const Ratios *rt,
                   WorkPool *pool, std::vector<std::string> &parts) {
   const unsigned nt = pool ? pool->size() : 1;
+  if (!r->sites && r->row_cuts) {
+    // The rows of this batch were made on the device (bvcf_params.render_sites): the batch's TSV is the stream, with the
+    // rows of the lines left to the host (indels, several ALTs, ...: their cuts, in line order and so in stream order) put in
+    // at their offsets.  Parts are byte ranges of the stream: a part copies its bytes and formats the cut lines that fall
+    // into it.
+    const uint64_t B = r->n_row_bytes;
+    uint32_t n_parts = 1;
+    if (nt > 1 && B >= (1u << 20)) n_parts = (uint32_t)std::min<uint64_t>(4 * nt, B >> 18);
+    if (parts.size() < n_parts) parts.resize(n_parts);
+    for (auto &p : parts) p.clear();
+    auto one = [&](uint32_t t) {
+      const uint64_t lo = B * t / n_parts, hi = B * (t + 1) / n_parts;
+      const bool last = t + 1 == n_parts;
+      const bvcf_row_cut *cb = r->row_cuts, *ce = r->row_cuts + r->n_row_cuts;
+      const bvcf_row_cut *it = std::lower_bound(cb, ce, lo, [](const bvcf_row_cut &q, uint64_t x) { return q.off < x; });
+      std::string &out = parts[t];
+      out.reserve((size_t)(hi - lo) + 256);
+      uint64_t pos = lo;
+      for (; it != ce && (it->off < hi || (last && it->off == hi)); ++it) {
+        out.append((const char *)r->rows + pos, (size_t)(it->off - pos));
+        pos = it->off;
+        format_lines(c, r, block, nm, rt, it->line, it->line + 1, out);
+      }
+      out.append((const char *)r->rows + pos, (size_t)(hi - pos));
+    };
+    if (n_parts == 1)
+      one(0);
+    else
+      pool->run(n_parts, one);
+    return;
+  }
   uint32_t n_parts = 1;
   if (nt > 1 && r->n_lines >= 4 * nt) n_parts = std::min<uint32_t>(4 * nt, r->n_lines / 32u);
   if (n_parts < 1) n_parts = 1;
@@ -616,6 +657,11 @@ int prepare_run(Run &R, std::string *msg, const uint8_t *data, size_t n_data, bo
     // full form, for A/B and parity tests)
     const char *e = getenv("BVCF_PACKED_SITES");
     p.packed_sites = R.pre.header.size() <= 9 && !(e && *e == '0');
+    // ... and the rows of the lines the packed form settles are made on the device (bvcf_params.render_sites, ABI 7: a
+    // sites-only run is otherwise bound by the formatter threads; BVCF_RENDER_SITES=0: the host formats every row, for A/B
+    // and parity tests)
+    const char *e2 = getenv("BVCF_RENDER_SITES");
+    p.render_sites = p.packed_sites && R.want_rows && !(e2 && *e2 == '0') && strlen(or_default(R.cfg->empty_field, "!")) <= 16;
   }
   p.allow_filter = R.cfg->allow_filter;
   p.exclude_filter = R.cfg->exclude_filter;
@@ -682,6 +728,14 @@ int create_ctx(const Run &R, int device, bvcf_ctx **ctx, std::string *msg) {
                                or_default(R.cfg->field_delimiter, ";"));
     if (rc) {
       *msg = std::string("bvcf_set_sample_names: ") + bvcf_last_error(*ctx);
+      bvcf_destroy(*ctx);
+      *ctx = nullptr;
+    }
+  }
+  if (rc == BVCF_OK && p.render_sites) {
+    rc = bvcf_set_row_format(*ctx, or_default(R.cfg->empty_field, "!"), R.cfg->keep_pos, R.cfg->keep_id, R.cfg->keep_info);
+    if (rc) {
+      *msg = std::string("bvcf_set_row_format: ") + bvcf_last_error(*ctx);
       bvcf_destroy(*ctx);
       *ctx = nullptr;
     }

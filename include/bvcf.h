@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BVCF_ABI_VERSION 6
+#define BVCF_ABI_VERSION 7
 
 typedef enum {
   BVCF_OK = 0,
@@ -129,7 +129,12 @@ typedef struct {
                                  bvcf_allele records only for the lines that need them (anything but a plain SNP).  A
                                  sites-only line is ~140 bytes of text; its full records are 128.  Ignored (sites == NULL)
                                  when the file has samples */
-  uint32_t reserved;
+  uint32_t render_sites;      /* ABI 7, packed ctxs only: 1 = the TSV rows of the lines the packed form settles (a biallelic SNP of
+                                 a file without samples: its row is the CHROM and POS bytes, REF, ALT, trTv and a constant
+                                 tail, main.go:586-695,735-745) are rendered ON THE DEVICE, in input order, into
+                                 bvcf_result.rows; the site records then stay on the device (sites == NULL) and the lines
+                                 the host still has to format -- the BVCF_SITE_FULL ones -- are listed in row_cuts with the
+                                 place of their rows in the stream.  Needs bvcf_set_row_format. */
 } bvcf_params;
 
 /* one input line; 64 bytes */
@@ -207,6 +212,13 @@ typedef struct {
   uint32_t len[3];
 } bvcf_names;
 
+/* one line whose rows the host makes, and where they go in bvcf_result.rows; 16 bytes */
+typedef struct bvcf_row_cut {
+  uint32_t line;   /* line number in the batch */
+  uint32_t slot;   /* its records: lines[slot], alleles[slot] */
+  uint64_t off;    /* byte offset in rows[] in front of which its rows belong */
+} bvcf_row_cut;
+
 /* a collected batch.  All pointers are library-owned pinned host memory of the slot the batch ran in.  Collects fill
  * the ctx's n_slots slots in turn, so the pointers stay valid until the n_slots-th following bvcf_collect on the same
  * ctx (with n_slots = 1: the next one), or bvcf_reserve / bvcf_destroy. */
@@ -257,7 +269,15 @@ typedef struct {
    * the slots of the lines as always (lines[j].rec_first).  bvcf_err.line stays the line number.  NULL otherwise. */
   const bvcf_site *sites;
   uint32_t n_full_lines;
-  uint32_t reserved3;
+  uint32_t n_row_cuts;
+  /* bvcf_params.render_sites (ABI 7): rows[0 .. n_row_bytes) are the rows of the lines the packed form settles, in input
+   * order, each with its "\n".  row_cuts lists, by line number, the n_row_cuts == n_full_lines lines that are NOT in there
+   * (BVCF_SITE_FULL: their records are lines[slot] / alleles[slot] ...): the rows the caller makes of line row_cuts[j].line
+   * belong at byte row_cuts[j].off of the stream.  n_ok_sites = the rendered rows (for the caller's counts). */
+  const uint8_t *rows;
+  uint64_t n_row_bytes;
+  const bvcf_row_cut *row_cuts;
+  uint64_t n_ok_sites;
 } bvcf_result;
 
 /* ---- lifecycle ---- */
@@ -271,6 +291,9 @@ int bvcf_reserve(bvcf_ctx *ctx, uint64_t lines, uint64_t alleles, uint64_t cmap_
  * lists of its output alleles as text, and the caller's TSV assembly copies three strings per row instead
  * of walking the class map name by name.  Call once, before the first bvcf_submit.  n must be the ctx's sample count. */
 int bvcf_set_sample_names(bvcf_ctx *ctx, const char *const *names, const uint32_t *lens, uint32_t n, const char *delimiter);
+/* bvcf_params.render_sites: what the rendered rows depend on besides the line -- the --emptyField text (at most 16 bytes;
+ * NULL = "!") and which of the optional columns are on (main.go:674-692).  Call once, before the first bvcf_submit. */
+int bvcf_set_row_format(bvcf_ctx *ctx, const char *empty_field, int keep_pos, int keep_id, int keep_info);
 
 /* pinned host memory for blocks handed to bvcf_submit (hipHostMalloc) */
 void *bvcf_alloc_pinned(size_t nbytes);

@@ -39,16 +39,17 @@ def test_exports_every_declared_symbol(bv):
 
 def test_struct_layouts_match_header(bv, tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "bvcf.h"\n#include "bvcf_plan.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "bvcf.h"\n#include "bvcf_plan.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(bvcf_line),sizeof(bvcf_allele),sizeof(bvcf_err),sizeof(bvcf_params),"
                    "sizeof(bvcf_result),sizeof(bvcf_config),sizeof(bvcf_range_plan),sizeof(bvcf_text_cut),"
-                   "sizeof(bvcf_thread_budget),sizeof(bvcf_plan_block),sizeof(bvcf_site));return 0;}\n")
+                   "sizeof(bvcf_thread_budget),sizeof(bvcf_plan_block),sizeof(bvcf_site),sizeof(bvcf_row_cut));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert sizes == [bv.LINE_DTYPE.itemsize, bv.ALLELE_DTYPE.itemsize, bv.ERR_DTYPE.itemsize,
                      C.sizeof(bv.Params), C.sizeof(bv.Result), C.sizeof(bv.Config), C.sizeof(bv.RangePlan),
-                     C.sizeof(bv.TextCut), C.sizeof(bv.ThreadBudget), C.sizeof(bv.PlanBlock), bv.SITE_DTYPE.itemsize]
+                     C.sizeof(bv.TextCut), C.sizeof(bv.ThreadBudget), C.sizeof(bv.PlanBlock), bv.SITE_DTYPE.itemsize,
+                     bv.ROW_CUT_DTYPE.itemsize]
 
 
 def test_header_known_answers(bv, known_answers):

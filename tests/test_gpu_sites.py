@@ -23,11 +23,14 @@ def bv():
     return b
 
 
-@pytest.fixture(autouse=True, params=["k_sites2-packed", "k_sites2-packed-chunk-census", "k_sites2", "k_sites2-chunk-census", "k_sites1", "k_sites"])
+@pytest.fixture(autouse=True, params=["k_sites2-packed-rendered", "k_sites2-packed", "k_sites2-packed-chunk-census", "k_sites2", "k_sites2-chunk-census",
+                                      "k_sites1", "k_sites"])
 def kernel(request, monkeypatch, bv):
     """k_sites2 behind its census per tile (k_census_tiles, the default) and behind the per-chunk census of the other chains,
-    each with the packed and with the full form of the results"""
+    each with the packed and with the full form of the results; the packed form also with the rows of the lines it settles
+    rendered on the device (bvcf_params.render_sites: the host driver's default for a file without samples)"""
     name = request.param
+    monkeypatch.setenv("BVCF_RENDER_SITES", "1" if name.endswith("rendered") else "0")
     if name in ("k_sites1", "k_sites") and b"experiments" not in bv.lib.bvcf_version():
         pytest.skip("%s is only in builds with -DBVCF_EXPERIMENTS" % name)
     monkeypatch.setenv("BVCF_SITES", {"k_sites1": "3", "k_sites": "1"}.get(name, "2"))
@@ -318,3 +321,72 @@ def test_packed_ctx_grows_lines_and_extra_alt_records_together(bv, kernel):
     p = subprocess.run([exe, "--allowFilter", "", "--batchMB", "1"], input=vcf, capture_output=True, timeout=300)
     assert p.returncode == 0, p.stderr[-500:]
     assert p.stdout == (bv.string_header() + "\n").encode() + out
+
+
+@pytest.mark.parametrize("flags", [{}, {"keepPos": True}, {"keepId": True, "keepInfo": True}, {"keepPos": True, "keepId": True, "keepInfo": True, "emptyField": "NA"},
+                                   {"emptyField": "sixteen_bytes_xx"}, {"emptyField": "seventeen_bytes_x"}])
+def test_rendered_rows_are_the_oracles_rows(bv, kernel, flags):
+    """bvcf_params.render_sites through the C-ABI: a file of plain SNP lines that all pass is settled on the fast lanes, so
+    the stream the device renders IS the oracle's output, byte for byte, for every combination of the optional columns and
+    --emptyField (17 bytes of it: the library refuses, the host driver then formats itself); lines that do not pass leave
+    nothing; a mixed file comes back as the stream plus the cuts of the lines left to the host, and through the host driver
+    as the oracle's rows."""
+    if not kernel.endswith("rendered"):
+        pytest.skip("the rendered form")
+    rng = random.Random(5)
+    rows, pos = [], 100
+    for i in range(20_000):
+        pos += rng.randint(1, 500)
+        chrom = rng.choice(["1", "chr7", "X", "c", "chrUn_KI270742v1", "22"])
+        ref = rng.choice("ACGT")
+        alt = rng.choice([b for b in "ACGT" if b != ref])
+        flt = "PASS" if i % 11 else "q10"
+        rows.append("\t".join([chrom, str(pos), "rs%d" % i if i % 3 else ".", ref, alt, "%d" % rng.randint(1, 999), flt,
+                               "AC=%d;AF=0.%04d" % (rng.randint(1, 5000), rng.randint(1, 9999))]))
+    vcf = (H8 + "\n".join(rows) + "\n").encode()
+    rc_o, out_o, log_o, n_o = orc.run(vcf, flags)
+    assert rc_o == 0 and out_o.count(b"\n") == sum(1 for i in range(20_000) if i % 11)
+    both(bv, vcf, flags)
+    body = vcf[len(H8):]
+    kw = dict(empty_field=flags.get("emptyField", "!"), keep_pos=flags.get("keepPos", False), keep_id=flags.get("keepId", False),
+              keep_info=flags.get("keepInfo", False))
+    if len(kw["empty_field"]) > 16:
+        with pytest.raises(bv.BvcfError):
+            bv.Ctx(8, max_batch_bytes=len(body), render_sites=True, **kw)
+        return
+    ctx = bv.Ctx(8, max_batch_bytes=len(body), render_sites=True, **kw)
+    try:
+        b = ctx.process(body)
+        assert b.sites is None and len(b.row_cuts) == 0 and b.n_lines == 20_000
+        assert b.n_ok_sites == out_o.count(b"\n")
+        assert b.rows == out_o
+        # a mixed block: every fifth line an insertion (left to the host: a cut at its place in the stream)
+        mixed = []
+        for i, ln in enumerate(rows[:5000]):
+            f = ln.split("\t")
+            if i % 5 == 0:
+                f[4] = f[3] + "TT"
+            mixed.append("\t".join(f))
+        mbody = ("\n".join(mixed) + "\n").encode()
+        b = ctx.process(mbody)
+        # (an insertion that also fails the FILTER gate may be settled on the fast lanes as FILTER: no cut then)
+        cut_lines = b.row_cuts["line"].tolist()
+        assert cut_lines == sorted(cut_lines) and {i for i in range(0, 5000, 5) if i % 11} <= set(cut_lines) <= set(range(0, 5000, 5))
+        assert (np.diff(b.row_cuts["off"].astype(np.int64)) >= 0).all() and b.row_cuts["off"][-1] <= len(b.rows)
+        rc_m, out_m, _, _ = orc.run(H8.encode() + mbody, flags)
+        want = [r for r in out_m.split(b"\n")[:-1] if b"\tSNP\t" in r]
+        assert b.rows == b"".join(r + b"\n" for r in want)
+        both(bv, H8.encode() + mbody, flags, max_batch_bytes=1 << 18)
+    finally:
+        ctx.close()
+    if not flags:
+        # rows longer than their lines (16-byte lines, 38-byte rows): the stream, sized for a typical file, grows
+        short = "".join("1\t%d\t.\tA\tC\t.\t.\t.\n" % (i % 9 + 1) for i in range(400_000)).encode()
+        rc_s, out_s, _, _ = orc.run(H8.encode() + short, {"allow": ""})
+        ctx = bv.Ctx(8, allow="", max_batch_bytes=len(short), max_lines=400_100, render_sites=True)
+        try:
+            for _ in range(2):
+                b = ctx.process(short)
+                assert len(b.rows) > len(short) // 2 + (1 << 20) and b.rows == out_s
+        finally:
+            ctx.close()
