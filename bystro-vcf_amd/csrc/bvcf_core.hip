@@ -802,6 +802,8 @@ int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
     // second buffer to make it legal the run was no faster: a sites-only run waits for the uploads, 40 GB/s.)
     s.rows_precopied = 0;
   }
+  if (names)
+    HIP_TRY(c, hipMemcpyAsync(s.h_name_total, s.d_name_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
   s.heads = s.is_bgzf && c->n_samples > 0 && s.d_head_off && nbytes > 0;
   if (s.heads) {
     HeadArgs h;
