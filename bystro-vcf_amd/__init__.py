@@ -380,13 +380,19 @@ class Batch:
     @staticmethod
     def _expand(sites, full_lines, raw_alleles, n):
         lines = np.zeros(n, dtype=LINE_DTYPE)
-        alleles = raw_alleles.copy()
-        if len(alleles) < n:
-            alleles = np.concatenate([alleles, np.zeros(n - len(alleles), dtype=ALLELE_DTYPE)])
+        # the batch's alleles[]: the n_full first records, the further alleles right behind them (rec_first points there);
+        # expanded: slot i for line i, the further alleles behind the n lines
+        n_full = len(full_lines)
+        extras = raw_alleles[n_full:]
+        alleles = np.concatenate([np.zeros(n, dtype=ALLELE_DTYPE), extras])
         full = (sites["status"] & SITE_FULL) != 0
         fi = sites["full_idx"][full]
-        assert len(set(fi.tolist())) == len(fi) and (fi < len(full_lines)).all(), "full_idx: distinct slots below n_full_lines"
-        lines[full] = full_lines[fi]
+        assert len(set(fi.tolist())) == len(fi) and (fi < n_full).all(), "full_idx: distinct slots below n_full_lines"
+        moved = full_lines.copy()
+        multi = moved["n_rec"] > 1
+        assert (moved["rec_first"][multi] >= n_full).all() and (moved["rec_first"][multi] + moved["n_rec"][multi] - 1 <= len(raw_alleles)).all()
+        moved["rec_first"][multi] = moved["rec_first"][multi] - n_full + n
+        lines[full] = moved[fi]
         assert (full_lines[fi]["gt_task"] == np.nonzero(full)[0]).all(), "a full record names its line"
         firsts = raw_alleles[fi].copy()
         # packed lines: a SNP with its position taken verbatim (or a line that failed the gate: no record)
@@ -401,7 +407,6 @@ class Batch:
         lines["n_fields"][pk] = sites["n_fields"][pk]
         lines["gt_task"][pk] = np.nonzero(pk)[0]
         lines["status"][pk] = sites["status"][pk]
-        alleles[:n] = np.zeros(n, dtype=ALLELE_DTYPE)
         idx = np.nonzero(pk)[0]
         alleles["line"][idx] = idx
         alleles["alt_len"][idx] = 1

@@ -36,6 +36,9 @@ struct Slot {
   bvcf_allele *d_alleles = nullptr;
   bvcf_site *d_sites = nullptr, *h_sites = nullptr;  // packed ctxs only
   // bvcf_params.render_sites: the stream of rendered rows, the lines left to the host, the scan's group arrays and totals
+  // packed ctxs: the pinned copies of the full records are sized for what such files need (a few lines in a hundred
+  // leave the fast lanes), not for every line -- pinning costs 0.25 ms per megabyte at ctx set-up; bvcf_collect grows them
+  uint64_t hcap_recs = 0, hcap_errs = 0;  // h_lines: hcap_recs; h_alleles: 2 * hcap_recs (first records, then the further ones)
   uint8_t *d_rows = nullptr, *h_rows = nullptr;
   uint64_t cap_rows = 0, rows_precopied = 0;  // (precopied: bytes of the stream that went to the host behind the kernels)
   bvcf_row_cut *d_row_cuts = nullptr, *h_row_cuts = nullptr;
@@ -364,10 +367,20 @@ int alloc_results(bvcf_ctx *c, Slot &s) {
     HIP_TRY(c, hipMalloc(&s.d_line_bits, c->max_lines * 8 * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&s.d_finish_items, (c->max_lines + c->max_alleles) * sizeof(uint32_t)));
   }
-  HIP_TRY(c, hipHostMalloc(&s.h_lines, c->max_lines * sizeof(bvcf_line), hipHostMallocDefault));
-  HIP_TRY(c, hipHostMalloc(&s.h_alleles, c->max_alleles * sizeof(bvcf_allele), hipHostMallocDefault));
-  HIP_TRY(c, hipHostMalloc(&s.h_errs, c->max_alleles * sizeof(bvcf_err), hipHostMallocDefault));
-  HIP_TRY(c, hipHostMalloc(&s.h_cmap, c->max_cmap + 64, hipHostMallocDefault));
+  if (c->packed) {
+    s.hcap_recs = std::max<uint64_t>(4096, c->max_lines / 16);
+    s.hcap_errs = std::max<uint64_t>(4096, c->max_lines / 16);
+    HIP_TRY(c, hipHostMalloc(&s.h_lines, s.hcap_recs * sizeof(bvcf_line), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&s.h_alleles, 2 * s.hcap_recs * sizeof(bvcf_allele), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&s.h_errs, s.hcap_errs * sizeof(bvcf_err), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&s.h_cmap, 4096, hipHostMallocDefault));  // (no samples: no class maps)
+  } else {
+    s.hcap_recs = s.hcap_errs = 0;
+    HIP_TRY(c, hipHostMalloc(&s.h_lines, c->max_lines * sizeof(bvcf_line), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&s.h_alleles, c->max_alleles * sizeof(bvcf_allele), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&s.h_errs, c->max_alleles * sizeof(bvcf_err), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&s.h_cmap, c->max_cmap + 64, hipHostMallocDefault));
+  }
   if (c->dosage_stride) {
     HIP_TRY(c, hipMalloc(&s.d_dosage, c->max_alleles * c->dosage_stride + 64));
     HIP_TRY(c, hipHostMalloc(&s.h_dosage, c->max_alleles * c->dosage_stride + 64, hipHostMallocDefault));
@@ -1555,9 +1568,41 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
       HIP_TRY(c, hipMemcpyAsync(s.h_row_cuts, s.d_row_cuts, n_row_cuts * sizeof(bvcf_row_cut), hipMemcpyDeviceToHost, s.stream));
   } else if (c->packed && ctr.n_lines)
     HIP_TRY(c, hipMemcpyAsync(s.h_sites, s.d_sites, ctr.n_lines * sizeof(bvcf_site), hipMemcpyDeviceToHost, s.stream));
+  if (c->packed) {
+    // the host's copies hold the n_first full records and, right behind them, the further alleles (on the device those
+    // follow slot cap_lines: rec_first is moved accordingly once they are here); grown when a batch needs more
+    const uint64_t need_recs = std::max<uint64_t>(n_first, ((uint64_t)n_first + ctr.n_alleles + 1) / 2);  // (h_alleles holds 2 * hcap_recs)
+    if (need_recs > s.hcap_recs || ctr.n_errs > s.hcap_errs) {
+      const uint64_t want_recs = std::max<uint64_t>(s.hcap_recs, need_recs + need_recs / 2 + 64);
+      const uint64_t want_errs = std::max<uint64_t>(s.hcap_errs, (uint64_t)ctr.n_errs + ctr.n_errs / 2 + 64);
+      hipHostFree(s.h_lines);
+      hipHostFree(s.h_alleles);
+      hipHostFree(s.h_errs);
+      s.h_lines = nullptr;
+      s.h_alleles = nullptr;
+      s.h_errs = nullptr;
+      s.hcap_recs = s.hcap_errs = 0;
+      if (hipHostMalloc(&s.h_lines, want_recs * sizeof(bvcf_line), hipHostMallocDefault) != hipSuccess ||
+          hipHostMalloc(&s.h_alleles, 2 * want_recs * sizeof(bvcf_allele), hipHostMallocDefault) != hipSuccess ||
+          hipHostMalloc(&s.h_errs, want_errs * sizeof(bvcf_err), hipHostMallocDefault) != hipSuccess) {
+        c->err = "hipHostMalloc failed (full records of a packed batch)";
+        s.cap_lines = 0;  // (alloc_results starts over at the slot's next use)
+        release();
+        return BVCF_E_NOMEM;
+      }
+      s.hcap_recs = want_recs;
+      s.hcap_errs = want_errs;
+    }
+  }
   if (n_first)
     HIP_TRY(c, hipMemcpyAsync(s.h_lines, s.d_lines, (size_t)n_first * sizeof(bvcf_line), hipMemcpyDeviceToHost, s.stream));
-  if (c->sites1 || c->packed) {
+  if (c->packed) {
+    if (n_first)
+      HIP_TRY(c, hipMemcpyAsync(s.h_alleles, s.d_alleles, (size_t)n_first * sizeof(bvcf_allele), hipMemcpyDeviceToHost, s.stream));
+    if (ctr.n_alleles)
+      HIP_TRY(c, hipMemcpyAsync(s.h_alleles + n_first, s.d_alleles + extras_at, (size_t)ctr.n_alleles * sizeof(bvcf_allele),
+                                hipMemcpyDeviceToHost, s.stream));
+  } else if (c->sites1) {
     if (n_first)
       HIP_TRY(c, hipMemcpyAsync(s.h_alleles, s.d_alleles, (size_t)n_first * sizeof(bvcf_allele), hipMemcpyDeviceToHost, s.stream));
     if (ctr.n_alleles)
@@ -1644,6 +1689,9 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     if (!(st.status & BVCF_SITE_FULL)) return st.status;
     return st.full_idx < n_first ? s.h_lines[st.full_idx].status : (uint32_t)BVCF_LINE_FIELDS;
   };
+  if (c->packed)  // (the further alleles sit right behind the n_first first records here, behind slot cap_lines on the device)
+    for (uint32_t j = 0; j < n_first; j++)
+      if (s.h_lines[j].rec_first >= extras_at) s.h_lines[j].rec_first = s.h_lines[j].rec_first - (uint32_t)extras_at + n_first;
   uint32_t n_errs = 0;
   for (uint32_t i = 0; i < ctr.n_errs; i++) {
     const bvcf_err &er = s.h_errs[i];
@@ -1651,7 +1699,7 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
   }
   r->status = BVCF_OK;
   r->n_lines = ctr.n_lines;
-  r->n_alleles = (uint32_t)n_alleles;
+  r->n_alleles = c->packed ? n_first + ctr.n_alleles : (uint32_t)n_alleles;
   r->n_errs = n_errs;
   r->n_cmap_bytes = cmap_bytes;
   r->n_lines_seen = ctr.lines_seen;

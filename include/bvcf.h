@@ -265,8 +265,9 @@ typedef struct {
   const uint32_t *head_off;  /* [n_lines]; entries of lines that did not pass (status FIELDS / FILTER) are undefined */
   /* bvcf_params.packed_sites on a file without samples: sites[i] describes line i (n_lines of them); lines[] then
    * holds only the n_full_lines records of the lines marked BVCF_SITE_FULL, in no particular order (lines[j].gt_task is
-   * the line number), alleles[j] is the first output allele of lines[j], and the further alleles of such lines sit past
-   * the slots of the lines as always (lines[j].rec_first).  bvcf_err.line stays the line number.  NULL otherwise. */
+   * the line number), alleles[j] is the first output allele of lines[j], and the further alleles of such lines follow the
+   * n_full_lines first records (lines[j].rec_first >= n_full_lines; n_alleles = n_full_lines + the further ones).
+   * bvcf_err.line stays the line number.  NULL otherwise. */
   const bvcf_site *sites;
   uint32_t n_full_lines;
   uint32_t n_row_cuts;
