@@ -29,6 +29,8 @@ for i in range(n_cases):
     eol = "\r\n" if rng.random() < float(os.environ.get("SOAK_CRLF", "0.1")) else "\n"
     vcf = vcfgen.gen_vcf(seed0 + i, n_lines, ns, fmt_extra, weird, eol)
     cfg = rng.choice([{"allow": ""}, {}, {"keepId": True, "keepInfo": True, "keepPos": True, "exclude": "q10"}])
+    if rng.random() < 0.3:  # (round 5: the tail of a rendered sites-only row is made of it)
+        cfg = dict(cfg, emptyField=rng.choice(["NA", ".", "sixteen_bytes_xx", "seventeen_bytes_x", ""]))
     rc_o, out_o, log_o, n_o = orc.run(vcf, cfg)
     want_dos = orc.run_dosage(vcf, cfg) if ns else []
     for path in ("1", "2", "2g", "2a", "wide"):
@@ -41,6 +43,8 @@ for i in range(n_cases):
         os.environ.pop("BVCF_WIDE", None)
         os.environ.pop("BVCF_WIDE_WIN", None)
         os.environ["BVCF_DEVICE_NAMES"] = rng.choice(["0", "1"])  # host join / device-rendered name lists
+        os.environ["BVCF_RENDER_SITES"] = rng.choice(["0", "1", "1"])  # sites-only files: rows by the host / on the device
+        os.environ["BVCF_PACKED_SITES"] = rng.choice(["0", "1", "1", "1"])
         if path == "wide":
             os.environ["BVCF_WIDE"] = "1"
             os.environ["BVCF_WIDE_WIN"] = str(rng.choice([64, 100, 777, 1024, 4096, 65536]))
