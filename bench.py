@@ -48,7 +48,8 @@ The whole record holds:
   e2e_eight_workers_one_gpu  `--devices d,d,d,d,d,d,d,d`: the product's multi-device partition (eight ctxs, per-worker
                 readers and formatter pools, one ordered writer) over the same files on the one GPU there is; whole
                 output hashed.
-  e2e_c2        the same for configs[1]'s sites-only rows (20 M of them: the packed form end to end), default flags.
+  e2e_c2        the same for configs[1]'s sites-only rows (20 M of them: the packed form end to end, rows rendered on the
+                device), default flags; e2e_c2_bgzf: the same rows as a BGZF file (what dbSNP / gnomAD sites files are).
   e2e_c5        the same for GATK-style rows (GT:DP:GQ sample fields, 24 KB per row: k_stream_gen), default flags.
   e2e_c4        configs[3]'s rows (20 % multiallelic + 15 % indels) with --keepId --keepInfo through the CLI, the
                 whole output hashed against the oracle CLI's with the same flags.
@@ -570,6 +571,48 @@ def host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, release_
                 leg["cpu_baseline"] = {k: base_x[k] for k in ("value", "unit", "cores", "kind", "sample")}
                 line[key] = leg
                 os.unlink(path_x)
+                if prof == "c2":
+                    # the shape such files come in (dbSNP / gnomAD sites: .vcf.gz): the same number of rows as BGZF -- block
+                    # 0's member stream n_x times -- inflated on the device, rows rendered there, only the lines left to
+                    # the host come back as text; whole output against the oracle's rows of block 0, n_x times
+                    import bgzf as _bg
+                    t0, nb0 = bg.rows_device(cfg_x, 0, r_x, pad=bv.DEVICE_PAD)
+                    b0 = t0[:nb0].cpu().numpy()
+                    del t0
+                    hdr_x = bg.header(cfg_x)
+                    blk0 = path_x + ".block0"
+                    files.append(blk0)
+                    with open(blk0, "wb") as f:
+                        f.write(hdr_x)
+                        f.write(memoryview(b0))
+                    members = bgzf_of(memoryview(b0), threads=usable_cpus())
+                    del b0
+                    gz_x = path_x + ".gz"
+                    files.append(gz_x)
+                    with open(gz_x, "wb") as f:
+                        f.write(bgzf_of(memoryview(hdr_x)))
+                        for _ in range(n_x):
+                            f.write(members)
+                        f.write(_bg.bgzf_block(b""))
+                    del members
+                    gz_bytes_x, gz_text_x = os.path.getsize(gz_x), len(hdr_x) + n_x * nb0
+                    gleg = e2e_leg("%d sites-only rows as BGZF (level 6, %.3f GB for %.2f GB of text: block 0's members %d times) -> "
+                                   "bystro-vcf --in x.vcf.gz -> /dev/null" % (n_x * r_x, gz_bytes_x / 1e9, gz_text_x / 1e9, n_x),
+                                   ["--in", gz_x, "--devices", dev], n_x * r_x, gz_text_x, runs=2, file_bytes=gz_bytes_x)
+                    po = subprocess.run([ORACLE, "--in", blk0, "--threads", str(usable_cpus())], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                    ob = po.stdout
+                    cut = ob.index(b"\n") + 1
+                    h = hashlib.sha256(ob[:cut])
+                    for _ in range(n_x):
+                        h.update(memoryview(ob)[cut:])
+                    rc_g, hx_g, n_g, _, _ = _hash_stdout([CLI, "--in", gz_x, "--devices", dev], algo="sha256")
+                    gleg["full_output_check"] = {"what": "sha256 of all %d rows' output vs the oracle's rows for block 0, %d times" % (n_x * r_x, n_x),
+                                                 "hip_sha256": hx_g, "oracle_sha256": h.hexdigest(), "output_bytes": n_g,
+                                                 "equal": rc_g == 0 and po.returncode == 0 and hx_g == h.hexdigest() and n_g == cut + n_x * (len(ob) - cut)}
+                    del ob
+                    line["e2e_c2_bgzf"] = gleg
+                    for q in (blk0, gz_x):
+                        os.unlink(q)
     except Exception as exc:  # the host legs inform; the measured line above stands without them
         import traceback
         line.setdefault("host_legs_error", (repr(exc) + " @ " + traceback.format_exc().splitlines()[-3].strip())[:500])
@@ -683,7 +726,7 @@ def compact_line(full):
         line["per_rank_variants_per_s"] = [_sig(v, 4) for v in full["per_rank_variants_per_s"]]
     if isinstance(full.get("real_data"), dict) and "frac" in full["real_data"]:
         line["real_data_frac"] = _sig(full["real_data"]["frac"], 4)
-    for key in ("e2e", "e2e_bgzf", "e2e_c2", "e2e_c4", "e2e_c5"):
+    for key in ("e2e", "e2e_bgzf", "e2e_c2", "e2e_c2_bgzf", "e2e_c4", "e2e_c5"):
         if key in full:
             line[key] = _leg_summary(full[key])
     for key, subs in (("e2e_stdin", ("text", "text_spliced", "bgzf")), ("e2e_eight_workers_one_gpu", ("text", "bgzf")),
@@ -701,7 +744,7 @@ def compact_line(full):
     line["full"] = "bench_full.json"
     txt = json.dumps(line, separators=(",", ":"))
     # never let the record outgrow what the driver reads: drop the least important keys first
-    for k in ("real_data_frac", "e2e_eight_workers_one_gpu_bgzf", "e2e_stdin_text_spliced", "e2e_all_devices_bgzf",
+    for k in ("real_data_frac", "e2e_eight_workers_one_gpu_bgzf", "e2e_stdin_text_spliced", "e2e_all_devices_bgzf", "e2e_c2_bgzf",
               "e2e_eight_workers_one_gpu_text", "e2e_stdin_bgzf", "e2e_stdin_text", "per_rank_variants_per_s"):
         if len(txt) <= LINE_LIMIT:
             break

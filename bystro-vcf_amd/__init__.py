@@ -91,7 +91,8 @@ class Result(C.Structure):
     ]
 
 
-ROW_CUT_DTYPE = np.dtype([("line", "<u4"), ("slot", "<u4"), ("off", "<u8")])
+ROW_CUT_DTYPE = np.dtype([("line", "<u4"), ("slot", "<u4"), ("off", "<u8"), ("text_off", "<u4"), ("reserved", "<u4")])
+NO_TEXT_OFF = 0xFFFFFFFF
 LINE_DTYPE = np.dtype([
     ("off", "<u4"), ("len", "<u4"), ("fend", "<u4", (9,)), ("rec_first", "<u4"), ("n_rec", "<u4"),
     ("n_fields", "<u4"), ("gt_task", "<u4"), ("status", "u1"), ("site_type", "u1"), ("pad", "u1", (2,))])

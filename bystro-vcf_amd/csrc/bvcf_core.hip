@@ -43,7 +43,12 @@ struct Slot {
   uint64_t cap_rows = 0, rows_precopied = 0;  // (precopied: bytes of the stream that went to the host behind the kernels)
   bvcf_row_cut *d_row_cuts = nullptr, *h_row_cuts = nullptr;
   uint32_t cap_row_cuts = 0, cap_render_groups = 0;
+  uint64_t cap_host_cuts = 0;
   unsigned long long *d_rgroup_bytes = nullptr, *d_rtotals = nullptr, *h_rtotals = nullptr;
+  unsigned long long *d_rgroup_ctext = nullptr;  // BGZF batches: the text of the lines left to the host, packed (k_render_rows)
+  uint8_t *d_cut_text = nullptr;
+  uint64_t cap_cut_text = 0;
+  bool cut_text_on = false;  // the batch in flight was launched with it
   uint32_t *d_rgroup_full = nullptr;
   bvcf_err *d_errs = nullptr;
   uint8_t *d_cmap = nullptr;
@@ -210,6 +215,8 @@ void free_slot(Slot &s) {
   hipHostFree(s.h_row_cuts);
   hipFree(s.d_rgroup_bytes);
   hipFree(s.d_rgroup_full);
+  hipFree(s.d_rgroup_ctext);
+  hipFree(s.d_cut_text);
   hipFree(s.d_rtotals);
   hipHostFree(s.h_rtotals);
   hipFree(s.d_errs);
@@ -705,12 +712,14 @@ static bool launch_inflate(int n_cu, const uint8_t *d_comp, const BgzfDesc *d_de
 }
 
 // bvcf_params.render_sites: the slot's row stream and the list of the lines left to the host
-int ensure_render_buffers(bvcf_ctx *c, Slot &s, uint64_t need_rows = 0) {
+int ensure_render_buffers(bvcf_ctx *c, Slot &s, uint64_t need_rows = 0, uint64_t need_host_cuts = 0) {
   // (what a batch of a typical file takes, not the worst case -- a row is a third of its line in a dbSNP-like file, and
-  // pinned memory costs 0.25 ms per megabyte to get: a batch whose rows outgrow the stream grows it, bvcf_collect)
+  // pinned memory costs 0.25 ms per megabyte to get: a batch whose rows outgrow the stream grows it, bvcf_collect; the
+  // pinned copy of the cuts is sized like the full records of a packed ctx: a sixteenth of the lines, grown on demand)
   const uint64_t extra = c->row_keep_info ? c->p.max_batch_bytes : 0;
-  const uint64_t want_rows = std::max<uint64_t>(need_rows, c->p.max_batch_bytes / 2 + extra + (1u << 20));
+  const uint64_t want_rows = std::max<uint64_t>(need_rows, c->p.max_batch_bytes / 8 * 3 + extra + (1u << 20));
   const uint32_t want_cuts = (uint32_t)std::min<uint64_t>(c->max_lines + 64, 0xFFFFFFF0ull);
+  const uint64_t want_host_cuts = std::max<uint64_t>(need_host_cuts, std::max<uint64_t>(4096, c->max_lines / 16));
   const uint32_t want_groups = (uint32_t)((c->max_lines + kRenderGroup - 1) / kRenderGroup + 2);
   // (the stream on its own: when a batch's rows outgrew it, the prefixes k_render_scan left in the group arrays are what
   // the second k_render_rows works from)
@@ -724,22 +733,34 @@ int ensure_render_buffers(bvcf_ctx *c, Slot &s, uint64_t need_rows = 0) {
     HIP_TRY(c, hipHostMalloc(&s.h_rows, want_rows, hipHostMallocDefault));
     s.cap_rows = want_rows;
   }
+  if (!s.h_row_cuts || s.cap_host_cuts < want_host_cuts) {
+    hipHostFree(s.h_row_cuts);
+    s.h_row_cuts = nullptr;
+    s.cap_host_cuts = 0;
+    HIP_TRY(c, hipHostMalloc(&s.h_row_cuts, (size_t)want_host_cuts * sizeof(bvcf_row_cut), hipHostMallocDefault));
+    s.cap_host_cuts = want_host_cuts;
+  }
   if (!s.d_row_cuts || s.cap_row_cuts < want_cuts || s.cap_render_groups < want_groups) {
     HIP_TRY(c, hipStreamSynchronize(s.stream));
     hipFree(s.d_row_cuts);
-    hipHostFree(s.h_row_cuts);
     hipFree(s.d_rgroup_bytes);
     hipFree(s.d_rgroup_full);
-    s.d_row_cuts = s.h_row_cuts = nullptr;
+    hipFree(s.d_rgroup_ctext);
+    s.d_row_cuts = nullptr;
     s.d_rgroup_bytes = nullptr;
     s.d_rgroup_full = nullptr;
+    s.d_rgroup_ctext = nullptr;
     s.cap_row_cuts = s.cap_render_groups = 0;
     HIP_TRY(c, hipMalloc(&s.d_row_cuts, (size_t)want_cuts * sizeof(bvcf_row_cut)));
-    HIP_TRY(c, hipHostMalloc(&s.h_row_cuts, (size_t)want_cuts * sizeof(bvcf_row_cut), hipHostMallocDefault));
     HIP_TRY(c, hipMalloc(&s.d_rgroup_bytes, (size_t)want_groups * sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc(&s.d_rgroup_full, (size_t)want_groups * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&s.d_rgroup_ctext, (size_t)want_groups * sizeof(unsigned long long)));
     s.cap_row_cuts = want_cuts;
     s.cap_render_groups = want_groups;
+  }
+  if (s.is_bgzf && !s.d_cut_text) {  // (a few lines in a hundred: an eighth of the batch and 1 MiB; more falls back to the whole text)
+    s.cap_cut_text = c->p.max_batch_bytes / 8 + (1u << 20);
+    HIP_TRY(c, hipMalloc(&s.d_cut_text, s.cap_cut_text));
   }
   if (!s.d_rtotals) {
     HIP_TRY(c, hipMalloc(&s.d_rtotals, 4 * sizeof(unsigned long long)));
@@ -767,10 +788,19 @@ RenderArgs make_render_args(bvcf_ctx *c, Slot &s, const KernelArgs &a) {
   ra.keep_pos = c->row_keep_pos;
   ra.keep_id = c->row_keep_id;
   ra.keep_info = c->row_keep_info;
+  ra.lines = a.lines;
+  static const bool cut_text_off = [] {  // (BVCF_CUT_TEXT=0: the whole text of a BGZF batch comes back, for A/B and parity tests)
+    const char *e = getenv("BVCF_CUT_TEXT");
+    return e && *e == '0';
+  }();
+  ra.cut_text = (s.is_bgzf && s.d_cut_text && !cut_text_off) ? s.d_cut_text : nullptr;
+  ra.cut_text_cap = s.cap_cut_text;
+  ra.group_ctext = s.d_rgroup_ctext;
   return ra;
 }
 int launch_render(bvcf_ctx *c, Slot &s, const KernelArgs &a) {
   const RenderArgs ra = make_render_args(c, s, a);
+  s.cut_text_on = ra.cut_text != nullptr;
   HIP_TRY(c, hipMemsetAsync(s.d_rtotals, 0, 4 * sizeof(unsigned long long), s.stream));
   const uint32_t grid = (uint32_t)c->n_cu * 8u;
   hipLaunchKernelGGL(k_render_len, dim3(grid), dim3(kWgThreads), 0, s.stream, ra);
@@ -1250,10 +1280,18 @@ int bvcf_set_row_format(bvcf_ctx *c, const char *empty_field, int keep_pos, int 
   c->row_keep_id = keep_id != 0;
   c->row_keep_info = keep_info != 0;
   c->row_fmt_set = true;
-  for (auto &s : c->slots) {  // (now, while the caller is still setting up, not inside its first submits)
-    const int rc = ensure_render_buffers(c, s);
+  // (now, while the caller is still setting up, not inside its first submits; the slots side by side: pinning is what
+  // takes the time, and the runtime pins from several threads at once)
+  std::vector<int> rcs(c->slots.size(), BVCF_OK);
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < c->slots.size(); k++)
+    th.emplace_back([c, k, &rcs]() {
+      hipSetDevice(c->device);
+      rcs[k] = ensure_render_buffers(c, c->slots[k]);
+    });
+  for (auto &t : th) t.join();
+  for (int rc : rcs)
     if (rc) return rc;
-  }
   return BVCF_OK;
 }
 
@@ -1360,7 +1398,10 @@ int bvcf_submit_bgzf(bvcf_ctx *c, const uint8_t *comp, size_t n_comp, size_t n_o
     // the host copies of the text, for every slot at once and side by side (pinning 64 MiB takes 13-25 ms).  With
     // samples only the line heads come back, a few percent of the text: a sixteenth of a batch to start with (bvcf_collect
     // grows a slot's buffer when a batch needs more)
-    const uint64_t want = c->n_samples ? c->p.max_batch_bytes / 16 + (1u << 20) : c->p.max_batch_bytes + BVCF_DEVICE_PAD;
+    // (no samples, rows rendered on the device: only the lines left to the host come back -- an eighth of a batch and 1 MiB,
+    // the size of the device's buffer for them; a batch that falls back to its whole text grows the slot's copy, bvcf_collect)
+    const uint64_t want = c->n_samples ? c->p.max_batch_bytes / 16 + (1u << 20)
+                                       : (c->render ? c->p.max_batch_bytes / 8 + (1u << 20) : c->p.max_batch_bytes + BVCF_DEVICE_PAD);
     std::vector<std::thread> th;
     for (auto &q : c->slots)
       if (!q.h_text)
@@ -1548,6 +1589,13 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
       release();
       return BVCF_E_HIP;
     }
+    if (n_row_cuts > s.cap_host_cuts) {
+      const int rc = ensure_render_buffers(c, s, 0, n_row_cuts + n_row_cuts / 2 + 64);
+      if (rc) {
+        release();
+        return rc;
+      }
+    }
     if (row_bytes > s.cap_rows) {
       // the stream was too small and k_render_rows wrote nothing: grow it and write again (the prefixes stand)
       const int rc = ensure_render_buffers(c, s, row_bytes + row_bytes / 4 + (1u << 20));
@@ -1641,8 +1689,26 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
     }
     if (ctr.n_lines) HIP_TRY(c, hipMemcpyAsync(s.h_head_off, s.d_head_off, ctr.n_lines * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
     if (text_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_text, s.d_heads, text_bytes, hipMemcpyDeviceToHost, s.stream));
+  } else if (was_bgzf && c->render && s.cut_text_on && s.h_rtotals[3] <= s.cap_cut_text && s.h_rtotals[3] < 0xFFFFFFFFull) {
+    // rendered rows: the host only reads the lines left to it -- their bytes, packed (bvcf_row_cut.text_off), not the
+    // batch's whole text
+    text_bytes = s.h_rtotals[3];
+    if (text_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_text, s.d_cut_text, text_bytes, hipMemcpyDeviceToHost, s.stream));
   } else if (was_bgzf && s.nbytes) {
     text_bytes = s.nbytes;
+    if (text_bytes > s.cap_h_text) {  // (a rendered ctx keeps a small copy buffer: see bvcf_submit_bgzf)
+      hipHostFree(s.h_text);
+      s.h_text = nullptr;
+      s.cap_h_text = 0;
+      const uint64_t want = c->p.max_batch_bytes + BVCF_DEVICE_PAD;
+      if (hipHostMalloc(&s.h_text, want, hipHostMallocDefault) != hipSuccess) {
+        s.h_text = nullptr;
+        c->err = "hipHostMalloc failed (text copy of a BGZF batch)";
+        release();
+        return BVCF_E_NOMEM;
+      }
+      s.cap_h_text = want;
+    }
     HIP_TRY(c, hipMemcpyAsync(s.h_text, s.src, s.nbytes, hipMemcpyDeviceToHost, s.stream));
   }
   const bool names = c->names_on && s.d_name_lists;

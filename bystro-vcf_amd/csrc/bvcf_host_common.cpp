@@ -127,9 +127,11 @@ LineView line_view(const bvcf_result *r, uint32_t li, bvcf_line *tl, bvcf_allele
     // where their cut says (the cuts are in line order)
     const bvcf_row_cut *lo = r->row_cuts, *hi = r->row_cuts + r->n_row_cuts;
     const bvcf_row_cut *it = std::lower_bound(lo, hi, li, [](const bvcf_row_cut &q, uint32_t x) { return q.line < x; });
-    const uint32_t slot = (it != hi && it->line == li && it->slot < r->n_full_lines) ? it->slot : 0u;
+    const bool found = it != hi && it->line == li && it->slot < r->n_full_lines;
+    const uint32_t slot = found ? it->slot : 0u;
     v.L = &r->lines[slot];
     v.A0 = &r->alleles[slot];
+    if (found && r->text && it->text_off != BVCF_NO_TEXT_OFF) v.row = (const char *)r->text + it->text_off;
     return v;
   }
   if (!r->sites) {
@@ -263,7 +265,7 @@ void format_lines(const bvcf_config *c, const bvcf_result *r, const uint8_t *blo
     const LineView view = line_view(r, li, &tmp_line, &tmp_allele);
     const bvcf_line &L = *view.L;
     if (L.status != BVCF_LINE_OK) continue;
-    const char *row = row_of(r, block, li, L);
+    const char *row = view.row ? view.row : row_of(r, block, li, L);
     auto fstart = [&](int i) -> uint32_t { return i ? L.fend[i - 1] + 1 : 0; };
     for (uint32_t k = 0; k < L.n_rec; k++) {
       const uint32_t slot = k ? L.rec_first + k - 1 : li;  // (k == 0, packed form: the record is *view.A0, wherever it lies)
@@ -424,8 +426,9 @@ void format_log(const bvcf_result *r, const uint8_t *block, std::string &log) {
   bvcf_allele ta;
   for (uint32_t i : idx) {
     const uint32_t li = r->errs[i].line;
-    const bvcf_line &L = *line_view(r, li, &tl, &ta).L;
-    append_err(log, r->errs[i], L, row_of(r, block, li, L));
+    const LineView view = line_view(r, li, &tl, &ta);
+    const bvcf_line &L = *view.L;
+    append_err(log, r->errs[i], L, view.row ? view.row : row_of(r, block, li, L));
   }
 }
 

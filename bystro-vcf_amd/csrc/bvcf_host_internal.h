@@ -105,7 +105,9 @@ const char *row_of(const bvcf_result *r, const uint8_t *block, uint32_t li, cons
 // line li of a batch as full records, whichever form the batch came back in (see the definition)
 struct LineView {
   const bvcf_line *L;
-  const bvcf_allele *A0;  // its first output allele
+  const bvcf_allele *A0;      // its first output allele
+  const char *row = nullptr;  // where the line's bytes are when not at row_of(): rendered rows of a BGZF batch, whose text came
+                              // back as the lines of the cuts only (bvcf_row_cut.text_off)
 };
 LineView line_view(const bvcf_result *r, uint32_t li, bvcf_line *tmp_line, bvcf_allele *tmp_allele);
 void append_err(std::string &log, const bvcf_err &e, const bvcf_line &L, const char *row);

@@ -34,7 +34,13 @@ struct RenderArgs {
   uint32_t n_groups_cap;
   unsigned long long *group_bytes;  // [n_groups_cap + 1]: bytes of a group's rows -> exclusive prefix (k_render_scan)
   uint32_t *group_full;             // [n_groups_cap + 1]: its lines for the host -> exclusive prefix
-  unsigned long long *totals;       // [0] row bytes [1] lines for the host [2] rows rendered
+  unsigned long long *totals;       // [0] row bytes [1] lines for the host [2] rows rendered [3] bytes of the host's lines (cut_text)
+  // bvcf_submit_bgzf batches (the text is on the device only): the bytes of the lines left to the host, packed, so that
+  // the batch's whole text need not cross back; null for batches the caller submitted as text
+  const bvcf_line *lines;
+  uint8_t *cut_text;
+  unsigned long long cut_text_cap;
+  unsigned long long *group_ctext;  // [n_groups_cap + 1]
   const BatchCounters *counters;
   const uint8_t *fmt;               // "chr" | "\tSNP\t" | the constant tail
   uint32_t tail_len;
@@ -44,6 +50,7 @@ struct RenderArgs {
 struct SiteRow {
   uint32_t len;   // bytes of the row with its "\n"; 0: no row here (the line did not pass, or the host makes its rows)
   uint32_t full;  // 1: a line for the host
+  uint32_t ctext; // ... and the bytes of its text that go back with it (RenderArgs.cut_text)
   uint32_t chr, f0, f1, f2, f6, n_pos, n_id, n_info;
 };
 
@@ -52,6 +59,7 @@ __device__ __forceinline__ SiteRow site_row(const RenderArgs &ra, const bvcf_sit
   SiteRow r = {};
   if (s.status & BVCF_SITE_FULL) {
     r.full = 1;
+    if (ra.cut_text) r.ctext = ra.lines[s.full_idx].len;
     return r;
   }
   if (s.status != BVCF_LINE_OK) return r;
@@ -81,7 +89,7 @@ __device__ __forceinline__ unsigned long long wave_excl_scan_len(uint32_t len, u
 }
 
 __global__ __launch_bounds__(kWgThreads) void k_render_len(RenderArgs ra) {
-  __shared__ unsigned long long s_len[kWavesPerWg];
+  __shared__ unsigned long long s_len[kWavesPerWg], s_ct[kWavesPerWg];
   __shared__ uint32_t s_full[kWavesPerWg];
   const uint32_t n_lines = min(ra.counters->n_lines, ra.n_groups_cap * kRenderGroup);
   const uint32_t n_groups = (n_lines + kRenderGroup - 1u) / kRenderGroup;
@@ -90,25 +98,29 @@ __global__ __launch_bounds__(kWgThreads) void k_render_len(RenderArgs ra) {
     const uint32_t li = g * kRenderGroup + threadIdx.x;
     SiteRow r = {};
     if (li < n_lines) r = site_row(ra, ra.sites[li]);
-    unsigned long long w_len;
+    unsigned long long w_len, w_ct = 0;
     (void)wave_excl_scan_len(r.len, &w_len);
     const uint32_t w_full = wave_sum(r.full);
+    if (ra.cut_text && w_full) (void)wave_excl_scan_len(r.ctext, &w_ct);
     __syncthreads();
     if (lane_id() == 0) {
       s_len[wave_in_wg()] = w_len;
       s_full[wave_in_wg()] = w_full;
+      s_ct[wave_in_wg()] = w_ct;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      unsigned long long b = 0;
+      unsigned long long b = 0, ct = 0;
       uint32_t f = 0;
 #pragma unroll
       for (int w = 0; w < kWavesPerWg; w++) {
         b += s_len[w];
         f += s_full[w];
+        ct += s_ct[w];
       }
       ra.group_bytes[g] = b;
       ra.group_full[g] = f;
+      if (ra.cut_text) ra.group_ctext[g] = ct;
     }
     n_ok += r.len ? 1u : 0u;
   }
@@ -118,35 +130,40 @@ __global__ __launch_bounds__(kWgThreads) void k_render_len(RenderArgs ra) {
 
 // one workgroup of 1024: exclusive prefixes of both group arrays, in place; the totals
 __global__ __launch_bounds__(1024) void k_render_scan(RenderArgs ra) {
-  __shared__ unsigned long long s_b[1024];
+  __shared__ unsigned long long s_b[1024], s_c[1024];
   __shared__ uint32_t s_f[1024];
+  const bool ct = ra.cut_text != nullptr;
   const uint32_t n_lines = min(ra.counters->n_lines, ra.n_groups_cap * kRenderGroup);
   const uint32_t n_groups = (n_lines + kRenderGroup - 1u) / kRenderGroup;
   const uint32_t per = (n_groups + 1023u) / 1024u;
   const uint32_t lo = min(threadIdx.x * per, n_groups), hi = min(lo + per, n_groups);
-  unsigned long long b = 0;
+  unsigned long long b = 0, cc = 0;
   uint32_t f = 0;
   for (uint32_t g = lo; g < hi; g++) {
     b += ra.group_bytes[g];
     f += ra.group_full[g];
+    if (ct) cc += ra.group_ctext[g];
   }
   s_b[threadIdx.x] = b;
   s_f[threadIdx.x] = f;
+  s_c[threadIdx.x] = cc;
   __syncthreads();
   // (1 024 partial sums: a plain doubling scan in LDS)
   for (uint32_t d = 1; d < 1024u; d <<= 1) {
-    unsigned long long ab = 0;
+    unsigned long long ab = 0, ac = 0;
     uint32_t af = 0;
     if (threadIdx.x >= d) {
       ab = s_b[threadIdx.x - d];
       af = s_f[threadIdx.x - d];
+      ac = s_c[threadIdx.x - d];
     }
     __syncthreads();
     s_b[threadIdx.x] += ab;
     s_f[threadIdx.x] += af;
+    s_c[threadIdx.x] += ac;
     __syncthreads();
   }
-  unsigned long long run_b = s_b[threadIdx.x] - b;
+  unsigned long long run_b = s_b[threadIdx.x] - b, run_c = s_c[threadIdx.x] - cc;
   uint32_t run_f = s_f[threadIdx.x] - f;
   for (uint32_t g = lo; g < hi; g++) {
     const unsigned long long gb = ra.group_bytes[g];
@@ -155,10 +172,16 @@ __global__ __launch_bounds__(1024) void k_render_scan(RenderArgs ra) {
     ra.group_full[g] = run_f;
     run_b += gb;
     run_f += gf;
+    if (ct) {
+      const unsigned long long gc = ra.group_ctext[g];
+      ra.group_ctext[g] = run_c;
+      run_c += gc;
+    }
   }
   if (threadIdx.x == 1023u) {
     ra.totals[0] = s_b[1023];
     ra.totals[1] = s_f[1023];
+    ra.totals[3] = s_c[1023];
   }
 }
 
@@ -169,8 +192,10 @@ __device__ __forceinline__ void emit_bytes(uint8_t *&dst, const uint8_t *src, ui
 }
 
 __global__ __launch_bounds__(kWgThreads) void k_render_rows(RenderArgs ra) {
-  __shared__ unsigned long long s_len[kWavesPerWg];
+  __shared__ unsigned long long s_len[kWavesPerWg], s_ct[kWavesPerWg];
   __shared__ uint32_t s_full[kWavesPerWg];
+  // (the text of the host's lines goes back packed when it fits its buffer, and below 4 GiB; otherwise the whole text does)
+  const bool ct = ra.cut_text != nullptr && ra.totals[3] <= ra.cut_text_cap && ra.totals[3] < 0xFFFFFFFFull;
   // the stream is sized for a typical file: a batch whose rows outgrow it writes nothing, the host grows it and launches
   // this kernel again (bvcf_collect)
   if (ra.totals[0] > ra.rows_cap || ra.totals[1] > ra.cuts_cap) return;
@@ -189,17 +214,21 @@ __global__ __launch_bounds__(kWgThreads) void k_render_rows(RenderArgs ra) {
     uint32_t wtot_full;
     const unsigned long long ex_len = wave_excl_scan_len(r.len, &wtot_len);
     const uint32_t ex_full = wave_excl_scan(r.full, &wtot_full);
+    unsigned long long wtot_ct = 0, ex_ct = 0;
+    if (ct && wtot_full) ex_ct = wave_excl_scan_len(r.ctext, &wtot_ct);
     __syncthreads();
     if (lane_id() == 0) {
       s_len[wave_in_wg()] = wtot_len;
       s_full[wave_in_wg()] = wtot_full;
+      s_ct[wave_in_wg()] = wtot_ct;
     }
     __syncthreads();
-    unsigned long long before_len = 0;
+    unsigned long long before_len = 0, before_ct = 0;
     uint32_t before_full = 0;
     for (uint32_t w = 0; w < wave_in_wg(); w++) {
       before_len += s_len[w];
       before_full += s_full[w];
+      before_ct += s_ct[w];
     }
     const unsigned long long off = ra.group_bytes[g] + before_len + ex_len;
     if (r.full) {
@@ -208,6 +237,17 @@ __global__ __launch_bounds__(kWgThreads) void k_render_rows(RenderArgs ra) {
       c.line = li;
       c.slot = s.full_idx;
       c.off = off;
+      c.text_off = BVCF_NO_TEXT_OFF;
+      c.reserved = 0;
+      if (ct) {
+        const unsigned long long to = ra.group_ctext[g] + before_ct + ex_ct;
+        if (to + r.ctext <= ra.cut_text_cap) {
+          c.text_off = (uint32_t)to;
+          const uint8_t *src = ra.text + ra.lines[s.full_idx].off;
+          uint8_t *p = ra.cut_text + to;
+          emit_bytes(p, src, r.ctext);
+        }
+      }
       if (ci < ra.cuts_cap) ra.cuts[ci] = c;
     } else if (r.len && off + r.len <= ra.rows_cap) {  // (the bound holds by the check above; never write past the stream)
       const uint8_t *row = ra.text + s.off;

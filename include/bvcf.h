@@ -212,11 +212,16 @@ typedef struct {
   uint32_t len[3];
 } bvcf_names;
 
-/* one line whose rows the host makes, and where they go in bvcf_result.rows; 16 bytes */
+/* one line whose rows the host makes, and where they go in bvcf_result.rows; 24 bytes */
+#define BVCF_NO_TEXT_OFF 0xFFFFFFFFu
 typedef struct bvcf_row_cut {
-  uint32_t line;   /* line number in the batch */
-  uint32_t slot;   /* its records: lines[slot], alleles[slot] */
-  uint64_t off;    /* byte offset in rows[] in front of which its rows belong */
+  uint32_t line;     /* line number in the batch */
+  uint32_t slot;     /* its records: lines[slot], alleles[slot] */
+  uint64_t off;      /* byte offset in rows[] in front of which its rows belong */
+  uint32_t text_off; /* bvcf_submit_bgzf batches: the line's bytes start at bvcf_result.text[text_off] -- only the lines of
+                        the cuts come back, not the batch's whole text -- or BVCF_NO_TEXT_OFF: at text[lines[slot].off] (the
+                        whole text came back), as in the block of a batch submitted as text */
+  uint32_t reserved;
 } bvcf_row_cut;
 
 /* a collected batch.  All pointers are library-owned pinned host memory of the slot the batch ran in.  Collects fill

@@ -288,3 +288,28 @@ def test_cli_bgzf_edge_files(bv, golden_1kg):
     assert p.returncode == 0
     rows = p.stdout.split(b"\n")
     assert rows[0] == hdr_line and sorted(rows[1:-1]) == want_sorted
+
+
+def test_cli_bgzf_sites_only_rendered_rows_take_only_the_cut_lines_text_back(bv):
+    """sites-only BGZF input with the rows rendered on the device (the default): the text stays on the device and only the
+    lines left to the host -- here every tenth line, an insertion -- come back, packed (bvcf_row_cut.text_off); a file
+    made of nothing but such lines outgrows that buffer and falls back to the whole text.  Rows and log against the
+    oracle, for both forms and with the host's rows (BVCF_RENDER_SITES=0)."""
+    import oracle_lib as orc
+    hdr = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    for every, n in ((10, 120_000), (1, 250_000)):
+        rows = []
+        for i in range(n):
+            alt = "ATT" if i % every == 0 else "G"
+            if i % 997 == 5:
+                alt = "<DEL>"  # (a message in the log: its line is read from the cut's text too)
+            rows.append("7\t%d\trs%d\tA\t%s\t50\tPASS\tAC=%d;AN=5008" % (100 + 3 * i, i, alt, i % 5000))
+        vcf = (hdr + "\n".join(rows) + "\n").encode()
+        rc_o, out_o, log_o, _ = orc.run(vcf, {"keepInfo": True})
+        assert rc_o == 0
+        data = bgzf.bgzf_compress(vcf, level=1)
+        for render in ("1", "0"):
+            p = _cli(["--keepInfo", "--batchMB", "16"], data, {"BVCF_RENDER_SITES": render})
+            assert p.returncode == 0, p.stderr[-300:]
+            assert p.stdout == (bv.string_header({"keepInfo": True}) + "\n").encode() + out_o, (every, render)
+            assert p.stderr.decode() == log_o, (every, render)
