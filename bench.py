@@ -96,7 +96,7 @@ def reduce_over_ranks(elapsed, n_variants, device, world):
     import torch.distributed as dist
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     n_var = torch.tensor([float(n_variants)], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(n_var, op=dist.ReduceOp.SUM)
     return float(t_el.item()), float(n_var.item())
@@ -854,7 +854,7 @@ def rank_census(my_rate, device, world):
     one = torch.ones(1, dtype=torch.float64, device=device)
     rates = torch.zeros(world, dtype=torch.float64, device=device)
     rates[int(os.environ.get("RANK", "0")) if world > 1 else 0] = my_rate
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(one, op=dist.ReduceOp.SUM)
         dist.all_reduce(rates, op=dist.ReduceOp.SUM)
     return int(one.item()), [float(v) for v in rates.tolist()]
@@ -921,7 +921,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     host_group = None
-    if world > 1:
+    # (BVCF_BENCH_FORCE_MULTI=1, with the launcher's environment for ONE rank: the N > 1 code -- RCCL group, gloo group,
+    # reductions, rank 0's all-devices leg, the host-side wait -- on a one-GPU box; tests/test_gpu_bench_legs.py)
+    multi = world > 1 or os.environ.get("BVCF_BENCH_FORCE_MULTI") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         # a host-side group for the wait at the very end (rank 0 runs the CLI over every device then: the other ranks
@@ -972,7 +975,7 @@ def main():
     ptrs = [t.data_ptr() for t in blocks]
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     # ---- warm-up, then exactly K timed steps between barrier + synchronize on both sides; a step = every block once
@@ -1000,7 +1003,7 @@ def main():
         a_chain, alone, _ = ctx.bench_device(ptrs, sizes, max(args.blocks, 8), slots=1)
         alone_ms = sum(alone) / len(alone)
         alone_chain_ms = sum(a_chain) / len(a_chain)
-        if world == 1 and args.slots != LIBRARY_DEFAULT_SLOTS:
+        if not multi and args.slots != LIBRARY_DEFAULT_SLOTS:
             # the same timed region with the library's default number of blocks in flight (bvcf_params.n_slots = 0)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -1077,18 +1080,18 @@ def main():
         if default_slots_rate:
             line["value_at_library_default_slots"] = default_slots_rate
             line["config"]["library_default_slots"] = LIBRARY_DEFAULT_SLOTS
-        if world > 1:
+        if multi:
             line["ranks_seen"] = ranks_seen
             line["per_rank_variants_per_s"] = per_rank
-        if world == 1 and streaming and args.profile == "c3" and not args.golden and not args.no_real_data:
+        if not multi and streaming and args.profile == "c3" and not args.golden and not args.no_real_data:
             try:
                 line["real_data"] = real_data_leg(bv, bg, cfg, local_rank, args, kernel, achieved)
             except Exception as exc:
                 line["real_data"] = {"error": repr(exc)[:300]}
-        want_host_legs = world == 1 and not args.golden and not (args.no_e2e and args.no_cpu_baseline)
+        want_host_legs = not multi and not args.golden and not (args.no_e2e and args.no_cpu_baseline)
         if want_host_legs:
             host_legs(line, args, cfg, bg, bv, blocks, sizes, rank, local_rank, ctx.close)
-    if world > 1:
+    if multi:
         # every rank lets go of its device (the CLI of rank 0 is about to use all of them), then waits on the host
         if rank == 0 and args.all_devices_rows > 0 and not args.no_e2e and not args.golden:
             all_devices_leg(line, args, cfg, bg, bv, blocks, sizes, world, ctx.close)
@@ -1099,7 +1102,7 @@ def main():
     if rank == 0:
         emit(line)
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
