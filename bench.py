@@ -15,7 +15,7 @@ per step, so the 20 steps of the driver's run visit 49.8 M rows -- eight times t
 about 0.1 s).  A block is what one bvcf_submit takes (< 4 GiB: offsets are 32-bit); the blocks are generated on the
 device before timing and visited in order, 25 GB between two visits of the same byte (the Infinity Cache holds
 256 MiB), so every launch streams its text from HBM.  Blocks are dealt to `--slots` result slots (default 3 =
-bvcf_params.n_slots 3; the library's own default is 2, 1-2 % slower on configs[2] and 5 % on configs[3]), each with its
+the library's own default since round 5: bvcf_params.n_slots 0; two are even on configs[2] and 5 % slower on configs[3]), each with its
 own HIP stream, exactly as bvcf_submit deals them: the short latency-bound kernels that end one block's chain overlap
 the following blocks' scans.  Records are independent: rank r owns its own rows (weak
 scaling), no collective in the data path; the per-rank variant counts are summed over RCCL at the end.
@@ -675,7 +675,7 @@ def all_devices_leg(line, args, cfg, bg, bv, blocks, sizes, world, release_devic
                 os.unlink(q)
 
 
-LIBRARY_DEFAULT_SLOTS = 2  # bvcf_params.n_slots == 0 (include/bvcf.h)
+LIBRARY_DEFAULT_SLOTS = 3  # bvcf_params.n_slots == 0 (include/bvcf.h; 2 until round 5)
 LINE_LIMIT = 3072  # bytes: the driver keeps 8 KB of stdout; the verdict asks for <= 3 KB
 
 
@@ -890,7 +890,7 @@ def main():
     ap.add_argument("--path", type=int, default=0, help="0 choose, 1 census path, 2 streaming path")
     ap.add_argument("--slots", type=int, default=3,
                     help="blocks in flight per GPU: block i runs on slot i %% slots, each slot on its own HIP stream, as "
-                         "bvcf_submit deals them (bvcf_params.n_slots; the library's default is 2); 1 = strictly one block after "
+                         "bvcf_submit deals them (bvcf_params.n_slots; the library's default); 1 = strictly one block after "
                          "the other")
     ap.add_argument("--golden", action="store_true",
                     help="experiment: real 1000-Genomes lines (tests/golden/1kg_chr1_20klines.vcf.gz, 19 747 rows "

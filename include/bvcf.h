@@ -111,7 +111,8 @@ typedef struct {
   uint32_t max_lines;         /* 0 = derived from max_batch_bytes and n_header_fields */
   uint32_t max_alleles;       /* slots of alleles[] (>= max_lines); 0 = 2 * max_lines + 1024 */
   uint64_t cmap_bytes;        /* class-map arena, one map per (line, ALT index); 0 = 1.5 maps per line */
-  uint32_t n_slots;           /* batches in flight (0 = 2; 3 measured best when the input does not wait for a link) */
+  uint32_t n_slots;           /* batches in flight (0 = 3: the short kernels that end two batches' chains then run beside the
+                                 third's scan -- +5 % with 20 % multiallelic lines, +7 % on sites-only input, even elsewhere) */
   uint32_t path;              /* 0 = choose (streaming for 256 .. BVCF_WIDE_SAMPLES header fields, census otherwise);
                                  1 = census path (separate newline census, every line listed; from
                                  BVCF_WIDE_SAMPLES samples up the genotype scan of one line is split over waves);
