@@ -40,7 +40,7 @@ struct Slot {
   // leave the fast lanes), not for every line -- pinning costs 0.25 ms per megabyte at ctx set-up; bvcf_collect grows them
   uint64_t hcap_recs = 0, hcap_errs = 0;  // h_lines: hcap_recs; h_alleles: 2 * hcap_recs (first records, then the further ones)
   uint8_t *d_rows = nullptr, *h_rows = nullptr;
-  uint64_t cap_rows = 0, rows_precopied = 0;  // (precopied: bytes of the stream that went to the host behind the kernels)
+  uint64_t cap_rows = 0;
   bvcf_row_cut *d_row_cuts = nullptr, *h_row_cuts = nullptr;
   uint32_t cap_row_cuts = 0, cap_render_groups = 0;
   uint64_t cap_host_cuts = 0;
@@ -136,7 +136,6 @@ struct bvcf_ctx {
   uint32_t tile_bytes = 0, tile_quota = 0;
   // bvcf_params.render_sites (packed ctxs): rows made on the device; the format comes with bvcf_set_row_format
   bool render = false, row_fmt_set = false;
-  double row_ratio = 0;  // row bytes per byte of text in the last batch: how much of the next stream is copied ahead
   uint8_t *d_row_fmt = nullptr;  // "chr" | "\tSNP\t" | the constant tail
   uint32_t row_tail_len = 0, row_keep_pos = 0, row_keep_id = 0, row_keep_info = 0;
   uint32_t n_samples = 0;
@@ -779,6 +778,7 @@ RenderArgs make_render_args(bvcf_ctx *c, Slot &s, const KernelArgs &a) {
   ra.cuts = s.d_row_cuts;
   ra.cuts_cap = s.cap_row_cuts;
   ra.n_groups_cap = s.cap_render_groups - 2u;
+  ra.max_lines = a.max_lines;
   ra.group_bytes = s.d_rgroup_bytes;
   ra.group_full = s.d_rgroup_full;
   ra.totals = s.d_rtotals;
@@ -843,7 +843,6 @@ int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
     // behind the kernels, so that it crosses beside the next batches' uploads.  The slot's host buffer may still be read by
     // the caller then -- results stay valid until the n_slots-th following COLLECT, a submit comes earlier -- and with a
     // second buffer to make it legal the run was no faster: a sites-only run waits for the uploads, 40 GB/s.)
-    s.rows_precopied = 0;
   }
   if (names)
     HIP_TRY(c, hipMemcpyAsync(s.h_name_total, s.d_name_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream));
@@ -1606,12 +1605,8 @@ int bvcf_collect(bvcf_ctx *c, bvcf_result *r) {
       KernelArgs a = make_args(c, s, s.src, s.nbytes);
       hipLaunchKernelGGL(k_render_rows, dim3((uint32_t)c->n_cu * 8u), dim3(kWgThreads), 0, s.stream, make_render_args(c, s, a));
       HIP_TRY(c, hipGetLastError());
-      s.rows_precopied = 0;
     }
-    if (row_bytes > s.rows_precopied)
-      HIP_TRY(c, hipMemcpyAsync(s.h_rows + s.rows_precopied, s.d_rows + s.rows_precopied, row_bytes - s.rows_precopied,
-                                hipMemcpyDeviceToHost, s.stream));
-    if (s.nbytes) c->row_ratio = (double)row_bytes / (double)s.nbytes;
+    if (row_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_rows, s.d_rows, row_bytes, hipMemcpyDeviceToHost, s.stream));
     if (n_row_cuts)
       HIP_TRY(c, hipMemcpyAsync(s.h_row_cuts, s.d_row_cuts, n_row_cuts * sizeof(bvcf_row_cut), hipMemcpyDeviceToHost, s.stream));
   } else if (c->packed && ctr.n_lines)

@@ -32,6 +32,7 @@ struct RenderArgs {
   bvcf_row_cut *cuts;
   uint32_t cuts_cap;
   uint32_t n_groups_cap;
+  uint32_t max_lines;               // site records there are room for (a batch with more lines is refused by bvcf_collect)
   unsigned long long *group_bytes;  // [n_groups_cap + 1]: bytes of a group's rows -> exclusive prefix (k_render_scan)
   uint32_t *group_full;             // [n_groups_cap + 1]: its lines for the host -> exclusive prefix
   unsigned long long *totals;       // [0] row bytes [1] lines for the host [2] rows rendered [3] bytes of the host's lines (cut_text)
@@ -59,7 +60,7 @@ __device__ __forceinline__ SiteRow site_row(const RenderArgs &ra, const bvcf_sit
   SiteRow r = {};
   if (s.status & BVCF_SITE_FULL) {
     r.full = 1;
-    if (ra.cut_text) r.ctext = ra.lines[s.full_idx].len;
+    if (ra.cut_text && s.full_idx < ra.max_lines) r.ctext = ra.lines[s.full_idx].len;  // (a batch that overflowed its records is refused anyway)
     return r;
   }
   if (s.status != BVCF_LINE_OK) return r;
@@ -91,7 +92,7 @@ __device__ __forceinline__ unsigned long long wave_excl_scan_len(uint32_t len, u
 __global__ __launch_bounds__(kWgThreads) void k_render_len(RenderArgs ra) {
   __shared__ unsigned long long s_len[kWavesPerWg], s_ct[kWavesPerWg];
   __shared__ uint32_t s_full[kWavesPerWg];
-  const uint32_t n_lines = min(ra.counters->n_lines, ra.n_groups_cap * kRenderGroup);
+  const uint32_t n_lines = min(ra.counters->n_lines, min(ra.max_lines, ra.n_groups_cap * kRenderGroup));
   const uint32_t n_groups = (n_lines + kRenderGroup - 1u) / kRenderGroup;
   uint32_t n_ok = 0;
   for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(1024) void k_render_scan(RenderArgs ra) {
   __shared__ unsigned long long s_b[1024], s_c[1024];
   __shared__ uint32_t s_f[1024];
   const bool ct = ra.cut_text != nullptr;
-  const uint32_t n_lines = min(ra.counters->n_lines, ra.n_groups_cap * kRenderGroup);
+  const uint32_t n_lines = min(ra.counters->n_lines, min(ra.max_lines, ra.n_groups_cap * kRenderGroup));
   const uint32_t n_groups = (n_lines + kRenderGroup - 1u) / kRenderGroup;
   const uint32_t per = (n_groups + 1023u) / 1024u;
   const uint32_t lo = min(threadIdx.x * per, n_groups), hi = min(lo + per, n_groups);
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kWgThreads) void k_render_rows(RenderArgs ra) {
   // the stream is sized for a typical file: a batch whose rows outgrow it writes nothing, the host grows it and launches
   // this kernel again (bvcf_collect)
   if (ra.totals[0] > ra.rows_cap || ra.totals[1] > ra.cuts_cap) return;
-  const uint32_t n_lines = min(ra.counters->n_lines, ra.n_groups_cap * kRenderGroup);
+  const uint32_t n_lines = min(ra.counters->n_lines, min(ra.max_lines, ra.n_groups_cap * kRenderGroup));
   const uint32_t n_groups = (n_lines + kRenderGroup - 1u) / kRenderGroup;
   for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const uint32_t li = g * kRenderGroup + threadIdx.x;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kWgThreads) void k_render_rows(RenderArgs ra) {
       c.reserved = 0;
       if (ct) {
         const unsigned long long to = ra.group_ctext[g] + before_ct + ex_ct;
-        if (to + r.ctext <= ra.cut_text_cap) {
+        if (to + r.ctext <= ra.cut_text_cap && s.full_idx < ra.max_lines) {
           c.text_off = (uint32_t)to;
           const uint8_t *src = ra.text + ra.lines[s.full_idx].off;
           uint8_t *p = ra.cut_text + to;
