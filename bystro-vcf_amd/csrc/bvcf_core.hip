@@ -1282,15 +1282,21 @@ int bvcf_set_row_format(bvcf_ctx *c, const char *empty_field, int keep_pos, int 
   // (now, while the caller is still setting up, not inside its first submits; the slots side by side: pinning is what
   // takes the time, and the runtime pins from several threads at once)
   std::vector<int> rcs(c->slots.size(), BVCF_OK);
+  std::vector<std::string> errs(c->slots.size());  // (HIP_TRY's message of a thread goes to its own string: g_err_sink)
   std::vector<std::thread> th;
   for (size_t k = 0; k < c->slots.size(); k++)
-    th.emplace_back([c, k, &rcs]() {
+    th.emplace_back([c, k, &rcs, &errs]() {
+      g_err_sink = &errs[k];
       hipSetDevice(c->device);
       rcs[k] = ensure_render_buffers(c, c->slots[k]);
+      g_err_sink = nullptr;
     });
   for (auto &t : th) t.join();
-  for (int rc : rcs)
-    if (rc) return rc;
+  for (size_t k = 0; k < rcs.size(); k++)
+    if (rcs[k]) {
+      c->err = errs[k];
+      return rcs[k];
+    }
   return BVCF_OK;
 }
 
