@@ -133,9 +133,23 @@ __device__ inline bool inf_build(const uint8_t *lens, uint32_t n, uint16_t *tabl
   return true;
 }
 
-// length / distance bases (RFC 1951 3.2.5)
+// length / distance bases and extra bits (RFC 1951 3.2.5), closed forms.  (Round 5 tried tables in constant memory -- the
+// symbol is wave-uniform, so a lookup is ONE scalar load instead of 8-12 scalar instructions and two branches --:
+// k_inflate_w4 1 600 -> 1 710 us per 3 840 blocks, the load's latency costs more than the instructions it saves;
+// -DBVCF_INF_TABLES builds that form, profiles/r05_k_inflate_attempts.txt)
+__constant__ uint16_t kInfLenTab[32] = {  // base | extra << 12, codes 257..285
+    3,           4,           5,           6,           7,           8,           9,           10,
+    11 | 1 << 12, 13 | 1 << 12, 15 | 1 << 12, 17 | 1 << 12, 19 | 2 << 12, 23 | 2 << 12, 27 | 2 << 12, 31 | 2 << 12,
+    35 | 3 << 12, 43 | 3 << 12, 51 | 3 << 12, 59 | 3 << 12, 67 | 4 << 12, 83 | 4 << 12, 99 | 4 << 12, 115 | 4 << 12,
+    131 | 5 << 12, 163 | 5 << 12, 195 | 5 << 12, 227 | 5 << 12, 258,         0,           0,           0};
+__constant__ uint32_t kInfDistTab[32] = {  // base | extra << 16, codes 0..29
+    1,               2,               3,               4,               5 | 1 << 16,     7 | 1 << 16,     9 | 2 << 16,     13 | 2 << 16,
+    17 | 3 << 16,    25 | 3 << 16,    33 | 4 << 16,    49 | 4 << 16,    65 | 5 << 16,    97 | 5 << 16,    129 | 6 << 16,   193 | 6 << 16,
+    257 | 7 << 16,   385 | 7 << 16,   513 | 8 << 16,   769 | 8 << 16,   1025 | 9 << 16,  1537 | 9 << 16,  2049 | 10 << 16, 3073 | 10 << 16,
+    4097 | 11 << 16, 6145 | 11 << 16, 8193 | 12 << 16, 12289 | 12 << 16, 16385 | 13 << 16, 24577 | 13 << 16, 0,               0};
 __device__ __forceinline__ uint32_t inf_len_base(uint32_t i, uint32_t *extra) {
   // codes 257..285 -> i = 0..28
+#ifndef BVCF_INF_TABLES
   if (i < 8) {
     *extra = 0;
     return 3 + i;
@@ -147,8 +161,14 @@ __device__ __forceinline__ uint32_t inf_len_base(uint32_t i, uint32_t *extra) {
   const uint32_t e = (i - 4) >> 2;
   *extra = e;
   return 3 + ((4 + (i & 3)) << e);
+#else
+  const uint32_t e = kInfLenTab[i & 31u];
+  *extra = e >> 12;
+  return e & 0xFFFu;
+#endif
 }
 __device__ __forceinline__ uint32_t inf_dist_base(uint32_t i, uint32_t *extra) {
+#ifndef BVCF_INF_TABLES
   if (i < 4) {
     *extra = 0;
     return 1 + i;
@@ -156,6 +176,11 @@ __device__ __forceinline__ uint32_t inf_dist_base(uint32_t i, uint32_t *extra) {
   const uint32_t e = (i - 2) >> 1;
   *extra = e;
   return 1 + ((2 + (i & 1)) << e);
+#else
+  const uint32_t e = kInfDistTab[i & 31u];
+  *extra = e >> 16;
+  return e & 0xFFFFu;
+#endif
 }
 
 // one wave per BGZF block; status[k] = kInf*
@@ -202,6 +227,32 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     };
+#ifdef BVCF_INF_REFILL64
+    // (experiment, round 5) at least 56 bits after every refill -- whole bytes up to bit 63, as libdeflate does --, so that a
+    // length + distance pair (15 + 5 + 15 + 13 bits) needs ONE refill test, at the symbol's start.  The bits of `w` that
+    // land above position nb + 8 k are the stream's next bits: or-ing them in again at the next refill changes nothing.
+    auto refill = [&]() {
+      if (nb >= 48u) return;
+      if (in_pos > d.in_len + 16u) {  // reading far past the payload: a truncated or corrupt stream
+        err = kInfInputOverrun;
+        return;
+      }
+      if (in_pos + 12u > in_fetched) fetch();  // (unread bytes stay below half the ring)
+      const uint32_t a = in_pos & (kInfInRing - 1u);
+      const uint32_t w0 = *reinterpret_cast<const uint32_t *>(&S.in[a & ~3u]);
+      const uint32_t w1 = *reinterpret_cast<const uint32_t *>(&S.in[(a + 4u) & (kInfInRing - 1u) & ~3u]);
+      const uint32_t w2 = *reinterpret_cast<const uint32_t *>(&S.in[(a + 8u) & (kInfInRing - 1u) & ~3u]);
+      const uint32_t lo = bcast0(__builtin_amdgcn_alignbyte(w1, w0, a & 3u));
+      const uint32_t hi = bcast0(__builtin_amdgcn_alignbyte(w2, w1, a & 3u));
+      const unsigned long long w = (unsigned long long)lo | ((unsigned long long)hi << 32);
+      const uint32_t k = (63u - nb) >> 3;  // whole bytes that fit
+      bb |= w << nb;
+      nb += 8u * k;
+      in_pos += k;
+    };
+    auto refill_mid = [&]() {};  // (the symbol's start left enough)
+#else
+    auto refill_mid = [&]() {};
     // keep >= 32 bits in the buffer (a symbol needs at most 15 + 13 extra)
     auto refill = [&]() {
       while (nb <= 32u) {
@@ -222,6 +273,7 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
         in_pos += 4u;
       }
     };
+#endif
     auto take = [&](uint32_t n) -> uint32_t {
       const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
       bb >>= n;
@@ -428,7 +480,11 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
         uint32_t extra;
         uint32_t len = inf_len_base(sym - 257u, &extra);
         len += take(extra);
+#ifdef BVCF_INF_REFILL64
+        refill_mid();
+#else
         refill();
+#endif
         e = bcast0(S.dist[(uint32_t)bb & ((1u << kInfDistBits) - 1u)]);
         uint32_t dsym;
         if (e) {
