@@ -898,6 +898,7 @@ def main():
     ap.add_argument("--cpu-dry", action="store_true",
                     help="no GPU: the launch / shard / reduce plumbing over gloo with the CPU oracle per rank (a test of this "
                          "file's N > 1 path, not a measurement)")
+    ap.add_argument("--over", default="", help="experiment: row-model knobs of the profile changed, e.g. p_multi=0,p_indel=0")
     ap.add_argument("--all-devices-rows", type=int, default=6_200_000,
                     help="N > 1: rows of rank 0's `bystro-vcf --devices 0,..,N-1` leg after the timed region; 0 = skip")
     args = ap.parse_args()
@@ -935,7 +936,8 @@ def main():
     import benchgen as bg
     import bystro_vcf_amd as bv
 
-    cfg = bg.make_cfg(args.profile, align16=int(args.align16), **({"n_samples": args.samples} if args.samples else {}))
+    over = {k: int(v) for k, v in (kv.split("=") for kv in args.over.split(",") if kv)}
+    cfg = bg.make_cfg(args.profile, align16=int(args.align16), **({"n_samples": args.samples} if args.samples else {}), **over)
     ns = cfg.n_samples
     # ---- synthetic blocks, generated on this rank's GPU; rank r owns rows [r*B*R, (r+1)*B*R)
     blocks, sizes = [], []
@@ -1045,7 +1047,7 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": WORKLOADS[args.profile],
+                "workload": WORKLOADS[args.profile] + (" with " + args.over if args.over else ""),
                 "rows_per_step_per_gpu": args.rows * args.blocks, "rows_per_block": args.rows,
                 "resident_blocks_per_gpu": args.blocks, "rows_in_timed_region": int(total_variants),
                 "bytes_per_row": mean_bytes / args.rows, "bytes_per_step_per_gpu": sum(sizes), "n_samples": ns,

@@ -39,6 +39,7 @@ struct BatchCounters {
   uint32_t pad[2];       // [0]: internal error flag; [1]: wide ctxs, the longest sample region
   uint32_t n_finish;     // streaming path: entries of finish_items (what k_finish still has to settle)
   uint32_t n_full;       // sites-only input, packed form (KernelArgs.sites): lines whose full records were written (lines[0 .. n_full))
+  uint32_t n_real;       // streaming path: entries of real_tasks (the task slots that hold a scan, for k_gt)
   uint32_t n_other_shape;  // streaming path: listed lines that were not of the shape the kernel is made for -- k_stream: not the
                            // 4-byte grid (left to k_gt); k_stream_gen: of the 4-byte grid.  The host picks the next batch's kernel by it.
 };
@@ -114,7 +115,8 @@ struct KernelArgs {
   uint32_t *line_cmap;   // [max_lines] class map of ALT #1
   uint16_t *head_bits;   // [n_tiles * tile_quota][16] TAB mask per 16 bytes of a line's 256-byte head window (k_stream)
   uint32_t *line_bits;   // [max_lines][8] the same, in input order (k_order)
-  uint32_t *finish_items;// [max_lines + max_alleles] streaming path: the lines k_finish settles (verdict + record counts)
+  uint32_t *finish_items;// [max_lines] streaming path: the lines k_finish settles (verdict + record counts)
+  uint32_t *real_tasks;  // [max_tasks] streaming path: the task slots past n_lines that hold a scan (or kNoTask), see k_head
   // k_sites1: the FILTER gate of the common lines as dwords (see bvcf_sites1.hip.h; 0 = no such table, 1 = keys, 2 = no test)
   uint32_t s1_fmode;
   uint32_t s1_fkey[4], s1_flen[4];

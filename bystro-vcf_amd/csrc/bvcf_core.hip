@@ -27,6 +27,7 @@ struct Slot {
   hipStream_t stream = nullptr;
   bool used_gen = false;  // the batch in flight went through k_stream_gen
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_ctr = nullptr;
+  hipEvent_t ev_in = nullptr, ev_scan = nullptr;  // scan-stream hand-over (launch_chain)
   // device
   uint8_t *d_in = nullptr;
   uint32_t *d_census = nullptr, *d_group = nullptr, *d_line_off = nullptr;
@@ -111,6 +112,8 @@ struct bvcf_ctx {
   int device = 0;
   int n_cu = 0;
   int gt_grid = 0, stream_grid = 0;
+  hipStream_t scan_stream = nullptr;  // see launch_chain
+  uint32_t stream_lds_pad = 0;  // dynamic LDS asked for with k_stream (it uses none): caps the k_stream workgroups of ALL batches per CU
   bool fused = false;
   // streaming path: which kernel walks the next batch -- k_stream (made for the 4-byte sample grid; other lines are
   // left to k_gt) or k_stream_gen (any fields, one pass).  Adaptive: a batch whose lines were mostly of the other
@@ -258,6 +261,8 @@ void free_slot(Slot &s) {
   hipHostFree(s.h_dosage);
   if (s.ev_k0) hipEventDestroy(s.ev_k0);
   if (s.ev_k1) hipEventDestroy(s.ev_k1);
+  if (s.ev_in) hipEventDestroy(s.ev_in);
+  if (s.ev_scan) hipEventDestroy(s.ev_scan);
   if (s.ev_ctr) hipEventDestroy(s.ev_ctr);
   if (s.stream) hipStreamDestroy(s.stream);
   s = Slot{};
@@ -405,6 +410,8 @@ int alloc_slot(bvcf_ctx *c, Slot &s) {
   HIP_TRY(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
   HIP_TRY(c, hipEventCreate(&s.ev_k0));
   HIP_TRY(c, hipEventCreate(&s.ev_k1));
+  HIP_TRY(c, hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+  HIP_TRY(c, hipEventCreateWithFlags(&s.ev_scan, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreate(&s.ev_ctr));
   const uint64_t in_cap = c->p.max_batch_bytes + BVCF_DEVICE_PAD;
   HIP_TRY(c, hipMalloc(&s.d_in, in_cap));
@@ -476,6 +483,7 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.head_bits = s.d_head_bits;
   a.line_bits = s.d_line_bits;
   a.finish_items = s.d_finish_items;
+  a.real_tasks = s.d_finish_items ? s.d_finish_items + c->max_lines : nullptr;  // (one allocation: [max_lines] + [max_alleles])
   a.s1_fmode = c->s1_fmode;
   for (int i = 0; i < 4; i++) {
     a.s1_fkey[i] = c->s1_fkey[i];
@@ -499,25 +507,46 @@ void adapt_stream_kernel(bvcf_ctx *c, bool was_gen, const BatchCounters &ctr) {
   if ((uint64_t)ctr.n_other_shape * 2u > ctr.n_lines) c->gen_mode = !was_gen;
 }
 
-void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t ev_gt0, hipEvent_t ev_gt1) {
+void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t ev_gt0, hipEvent_t ev_gt1, Slot *slot = nullptr) {
   if (a.fused) {
     const uint32_t n_groups = (a.n_tiles + kScanGroup - 1) / kScanGroup;
-    hipMemsetAsync(a.counters, 0, sizeof(BatchCounters), st);
-    if (ev_gt0) hipEventRecord(ev_gt0, st);
+    // The one-pass kernels of ALL batches go through one stream of the ctx, one after the other at full rate; what follows a
+    // batch's pass runs on the slot's stream beside the next batches' passes.
+    const bool split = c->scan_stream && slot && slot->ev_in && slot->ev_scan;
+    hipStream_t ss = split ? c->scan_stream : st;
+    if (split) {
+      hipEventRecord(slot->ev_in, st);  // the text is in, and the slot's last batch is through
+      hipStreamWaitEvent(ss, slot->ev_in, 0);
+    }
+    hipMemsetAsync(a.counters, 0, sizeof(BatchCounters), ss);
+    if (ev_gt0) hipEventRecord(ev_gt0, ss);
     if (a.gen_stream)
-      hipLaunchKernelGGL(k_stream_gen, dim3(c->gen_grid), dim3(kWgThreads), gen_lds_bytes(a.n_samples), st, a);
+      hipLaunchKernelGGL(k_stream_gen, dim3(c->gen_grid), dim3(kWgThreads), gen_lds_bytes(a.n_samples), ss, a);
     else
-      hipLaunchKernelGGL(k_stream, dim3(c->stream_grid), dim3(kWgThreads), 0, st, a);
-    if (ev_gt1) hipEventRecord(ev_gt1, st);
+      hipLaunchKernelGGL(k_stream, dim3(c->stream_grid), dim3(kWgThreads), c->stream_lds_pad, ss, a);
+    if (ev_gt1) hipEventRecord(ev_gt1, ss);
+    if (split) {
+      hipEventRecord(slot->ev_scan, ss);
+      hipStreamWaitEvent(st, slot->ev_scan, 0);
+    }
     hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, a.n_tiles);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
     hipLaunchKernelGGL(k_order, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
-    if (c->p.n_slots > 1)
-      hipLaunchKernelGGL(k_head_lean, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
+#ifdef BVCF_EXPERIMENTS
+    // experiment (results are then wrong): which follower costs what with blocks in flight -- 1: no k_head, 2: no k_gt, 4: no k_finish
+    static const int skip = getenv("BVCF_EXP_SKIP") ? atoi(getenv("BVCF_EXP_SKIP")) : 0;
+    static const int head_wgs = getenv("BVCF_EXP_HEAD_WGS") ? atoi(getenv("BVCF_EXP_HEAD_WGS")) : 4;
+    static const int gt_div = getenv("BVCF_EXP_GT_DIV") ? atoi(getenv("BVCF_EXP_GT_DIV")) : 1;
+#else
+    constexpr int skip = 0, head_wgs = 4, gt_div = 1;
+#endif
+    if (skip & 1) {
+    } else if (c->p.n_slots > 1)
+      hipLaunchKernelGGL(k_head_lean, dim3(c->n_cu * head_wgs), dim3(kWgThreads), 0, st, a);
     else
-      hipLaunchKernelGGL(k_head, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
-    hipLaunchKernelGGL(k_gt, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
-    hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
+      hipLaunchKernelGGL(k_head, dim3(c->n_cu * head_wgs), dim3(kWgThreads), 0, st, a);
+    if (!(skip & 2)) hipLaunchKernelGGL(k_gt, dim3(c->gt_grid / gt_div), dim3(kWgThreads), 0, st, a);
+    if (!(skip & 4)) hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
     if (a.dosage) hipLaunchKernelGGL(k_dosage, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     return;
   }
@@ -827,7 +856,7 @@ int launch_batch(bvcf_ctx *c, Slot &s, const uint8_t *src, size_t nbytes) {
   s.s2_parity ^= 1u;
   KernelArgs a = make_args(c, s, src, nbytes);
   s.used_gen = a.gen_stream != 0;
-  launch_chain(c, a, s.stream, nullptr, nullptr);
+  launch_chain(c, a, s.stream, nullptr, nullptr, &s);
   const bool names = c->names_on && s.d_name_lists;
   if (names) launch_names(c, a, make_name_args(c, s), s.stream);
   HIP_TRY(c, hipGetLastError());
@@ -985,6 +1014,7 @@ void bvcf_destroy(bvcf_ctx *c) {
   if (!c) return;
   hipSetDevice(c->device);
   for (auto &s : c->slots) free_slot(s);
+  if (c->scan_stream) hipStreamDestroy(c->scan_stream);
   hipFree(c->d_filters);
   hipFree(c->d_row_fmt);
   hipFree(c->d_name_off);
@@ -1089,6 +1119,14 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   }
 #endif
   c->stream_grid = c->n_cu * per_cu;
+  if (c->p.n_slots > 1 && getenv("BVCF_SCAN_STREAM") && atoi(getenv("BVCF_SCAN_STREAM")) == 1 &&
+      hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking) != hipSuccess) {
+    c->err = "hipStreamCreate failed";
+    return fail(BVCF_E_HIP);
+  }
+#ifdef BVCF_EXPERIMENTS
+  if (const char *e = getenv("BVCF_EXP_STREAM_LDS")) c->stream_lds_pad = (uint32_t)atoi(e);
+#endif
   per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream_gen, kWgThreads, gen_lds_bytes(c->n_samples)) != hipSuccess || per_cu < 1)
     per_cu = 2;
@@ -2018,7 +2056,7 @@ int bvcf_bench_device_slots(bvcf_ctx *c, const void *const *dblocks, const size_
     si.s2_parity ^= 1u;
     KernelArgs a = make_args(c, si, (const uint8_t *)dblocks[i % n_blocks], nbytes[i % n_blocks]);
     HIP_TRY(c, hipEventRecord(ev[4 * i], si.stream));
-    launch_chain(c, a, si.stream, ev[4 * i + 1], ev[4 * i + 2]);
+    launch_chain(c, a, si.stream, ev[4 * i + 1], ev[4 * i + 2], &si);
     HIP_TRY(c, hipEventRecord(ev[4 * i + 3], si.stream));
   }
   HIP_TRY(c, hipGetLastError());
@@ -2055,6 +2093,14 @@ int bvcf_bench_device_slots(bvcf_ctx *c, const void *const *dblocks, const size_
 
 }  // extern "C"
 
+#ifdef BVCF_EXPERIMENTS
+// tasks k_gt ran since the last call, by kind (see g_gt_kinds)
+extern "C" int bvcf_debug_gt_kinds(unsigned int out[4]) {
+  const unsigned int z[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bvcf_dev::g_gt_kinds), sizeof(z), 0, hipMemcpyDeviceToHost) != hipSuccess) return BVCF_E_HIP;
+  return hipMemcpyToSymbol(HIP_SYMBOL(bvcf_dev::g_gt_kinds), z, sizeof(z), 0, hipMemcpyHostToDevice) == hipSuccess ? BVCF_OK : BVCF_E_HIP;
+}
+#endif
 #ifdef BVCF_EXP_TIMES
 extern "C" int bvcf_debug_head_times(unsigned long long *out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bvcf_dev::g_head_t), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);

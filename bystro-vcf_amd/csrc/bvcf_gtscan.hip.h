@@ -372,7 +372,8 @@ __device__ __forceinline__ uint32_t highest_allele(const Alleles4 &g, uint32_t t
 //   area: +0 n, +16 the entries' map byte indices (4 B each), +272 their four field words (16 B each)
 constexpr uint32_t kRawEnc = 7u << 1;  // low bits of the line's class-map offset: "raw list in the next slots"
 constexpr uint32_t kRawAreaBytes = 16u + 4u * (kRawMax + 1u) + 16u * kRawMax;
-constexpr uint32_t kRawTask = 1u;      // GtTask.pad[0]: s_begin is the raw area's offset in the class-map arena
+constexpr uint32_t kRawTask = 1u;      // GtTask.pad[0], low byte: s_begin is the raw area's offset in the class-map arena
+constexpr uint32_t kTaskRecShift = 8;  // GtTask.pad[0] >> 8: allele records k_gt fills in (pad[1], pad[2]: where; put_task)
 __device__ __forceinline__ void raw_save(uint8_t *area, uint32_t n, const u32x4 &e, uint32_t idx) {
   const uint32_t lane = (uint32_t)lane_id();
   if (lane == 0) __builtin_nontemporal_store(n, reinterpret_cast<uint32_t *>(area));
@@ -682,6 +683,12 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
 
 // ------------------------------------------------------------------ k_gt: one wave per task
 
+#ifdef BVCF_EXPERIMENTS
+__device__ unsigned int g_gt_kinds[4];  // tasks k_gt ran: raw list, regular text, general text, summed windows (bvcf_debug_gt_kinds)
+#define GT_KIND(k) if (lane == 0) atomicAdd(&g_gt_kinds[k], 1u)
+#else
+#define GT_KIND(k)
+#endif
 __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerWg][kStageBytes];
   uint8_t *stage = s_stage[wave_in_wg()];
@@ -690,28 +697,35 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
   const uint32_t n_tasks = min(n_lines + a.counters->n_tasks, a.max_tasks);
   const uint32_t stride = gridDim.x * kWavesPerWg;
   const uint32_t ns = a.n_samples;
-  // streaming path: ALT #1 of every regular line is already scanned; only the slots past n_lines
-  // (further ALT indices, and lines k_stream merely delimited) hold tasks
-  // The wave's tasks are first + k * stride.  It fetches 64 of them at a time, one per lane (k = k0 + lane), and walks
-  // only those with something to scan: on the streaming path most slots are placeholders -- further alleles k_head
-  // settled from class lists, allele 0 -- and taking them one load at a time, each a memory latency for nothing, was
-  // most of this kernel's time on configs[3].  The next 64 are in flight meanwhile.
-  const uint32_t first = (a.fused ? n_lines : 0u) + wave_in_grid();
+  // Streaming path: ALT #1 of every regular line is already scanned; of the slots past n_lines -- further ALT indices, and
+  // lines k_stream merely delimited -- k_head listed the ones that hold a scan (real_tasks), and wave w takes entries
+  // w, w + stride, ..: the same number of scans per wave, give or take one.  (Striding over the task slots themselves -- three
+  // quarters of configs[3]'s are placeholders of alleles k_head settled from class lists -- left the unluckiest wave 13 scans
+  // where the mean is 5.)  Census path: every slot from 0 on.
+  // A wave fetches 64 of its entries at a time, one per lane (k = k0 + lane), and walks those with something to scan; the next
+  // 64 are in flight meanwhile.
+  const bool listed = a.fused != 0;
+  const uint32_t n_items = listed ? min(a.counters->n_real, a.max_tasks) : n_tasks;
+  const uint32_t first = wave_in_grid();
   static_assert(sizeof(GtTask) == 32, "fetched as two 16-byte words: line, allele, s_begin, cend | cmap_off, pad[3]");
-  auto fetch = [&](uint32_t k0, u32x4 &lo, u32x4 &hi) {
-    const unsigned long long tl = (unsigned long long)first + (unsigned long long)(k0 + (uint32_t)lane) * stride;
+  auto fetch = [&](uint32_t k0, u32x4 &lo, u32x4 &hi, uint32_t &ti) {
+    const unsigned long long it = (unsigned long long)first + (unsigned long long)(k0 + (uint32_t)lane) * stride;
     lo = hi = u32x4{0u, 0u, 0u, 0u};
-    if (tl < n_tasks) {
-      const u32x4 *p = reinterpret_cast<const u32x4 *>(&a.tasks[tl]);
+    ti = 0xFFFFFFFFu;
+    if (it < n_items) ti = listed ? a.real_tasks[it] : (uint32_t)it;
+    if (ti < n_tasks && (!listed || ti >= n_lines)) {
+      const u32x4 *p = reinterpret_cast<const u32x4 *>(&a.tasks[ti]);
       lo = p[0];
       hi = p[1];
     }
   };
   u32x4 nlo, nhi;
-  fetch(0u, nlo, nhi);
-  for (uint32_t k0 = 0; (unsigned long long)first + (unsigned long long)k0 * stride < n_tasks; k0 += kWave) {
+  uint32_t nti;
+  fetch(0u, nlo, nhi, nti);
+  for (uint32_t k0 = 0; (unsigned long long)first + (unsigned long long)k0 * stride < n_items; k0 += kWave) {
    const u32x4 lo = nlo, hi = nhi;
-   fetch(k0 + kWave, nlo, nhi);
+   const uint32_t ti_l = nti;
+   fetch(k0 + kWave, nlo, nhi, nti);
    unsigned long long todo = __ballot(lo.y != 0u);  // (allele 0: rejected before getAlleles, or settled: nothing to scan)
    while (todo) {
     const int src = __ffsll((long long)todo) - 1;
@@ -723,14 +737,15 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
     t.cend = lane_value(lo.w, src);
     t.cmap_off = lane_value(hi.x, src);
     t.pad[0] = lane_value(hi.y, src);
-    t.pad[1] = t.pad[2] = 0;
-    const uint32_t ti = first + (k0 + (uint32_t)src) * stride;
+    t.pad[1] = lane_value(hi.z, src);
+    t.pad[2] = lane_value(hi.w, src);
+    const uint32_t ti = lane_value(ti_l, src);
     uint8_t *cm = t.cmap_off != BVCF_NO_CMAP ? a.cmap + t.cmap_off : nullptr;
     GtStats st = {0, 0, 0, 0, 0};
     uint32_t n_fields;
     // regular region: 4 bytes per sample, every dword of a lane is one "x|y<TAB>" field
     bool regular = false;
-    if (t.pad[0] == kRawTask) {
+    if ((t.pad[0] & 0xFFu) == kRawTask) {
       // a further allele of a line k_stream scanned: its carriers are among the entries saved with the line (raw_save)
       const uint8_t *area = a.cmap + t.s_begin;
       // (all three loads at once -- the area is there for kRawMax entries whatever the count says -- and the count applied
@@ -764,6 +779,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
       }
       n_fields = ns;
       regular = true;
+      GT_KIND(0);
     } else if (a.wide && t.cend + 1u - t.s_begin == 4u * ns && a.results[ti].pad == 0) {
       // k_gt_wide scanned the region window by window and every window was regular: add up
       const GtResult part = a.results[ti];
@@ -778,6 +794,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
                gt_scan_fast(a, t.s_begin, ns, t.allele, cm, stage, false, &st)) {
       n_fields = ns;
       regular = true;
+      GT_KIND(1);
     } else if (a.wide && a.results[ti].pad == 2u) {
       // k_gt_wide_general summed the windows of this line
       const GtResult part = a.results[ti];
@@ -791,6 +808,7 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
       uint32_t tabs;
       gt_scan_general(a, t.s_begin, t.cend, ns, t.allele, cm, &st, &tabs);
       n_fields = tabs + 1u;
+      GT_KIND(2);
     }
     if (lane == 0) {
       GtResult r;
@@ -803,6 +821,19 @@ __global__ __launch_bounds__(kWgThreads) void k_gt(KernelArgs a) {
       r.regular = regular ? 1u : 0u;
       r.pad = 0;
       a.results[ti] = r;
+    }
+    // streaming path, a further ALT index of a settled line: the counts go straight into its records (k_finish only sees
+    // lines whose ALT #1 was scanned here)
+    for (uint32_t j = (uint32_t)lane; j < (t.pad[0] >> kTaskRecShift); j += kWave) {
+      const uint32_t slot = j == 0u ? t.pad[1] : t.pad[2] + j - 1u;
+      if (slot < a.max_alleles) {
+        bvcf_allele *rec = &a.alleles[slot];
+        rec->ac = st.ac;
+        rec->an = st.an;
+        rec->n_het = st.n_het;
+        rec->n_hom = st.n_hom;
+        rec->n_miss = st.n_miss;
+      }
     }
    }
   }

@@ -97,10 +97,19 @@ __device__ inline void write_allele(const KernelArgs &a, uint32_t idx, uint32_t 
 
 constexpr uint32_t kNoTask = 0xFFFFFFFFu;
 
+// What the low bits of a line's class-map offset (k_stream: finish_list / finish_dense) say about its further ALT indices.
+// Listed: ALT #1 is a class list with the lists of ALT #2..#kmax behind it in the slot, or a dense map whose samples carry
+// no further allele (kmax = 1); nobody carries a higher index.  Not listed: no map, a map with nothing known, or kRawEnc.
+__device__ __forceinline__ bool further_listed(uint32_t cm) { return cm != BVCF_NO_CMAP && (cm & 15u) != 0u && (cm & 15u) != kRawEnc; }
+__device__ __forceinline__ uint32_t further_kmax(uint32_t cm) { return (cm & 1u) ? ((cm >> 1) & 7u) + 1u : 1u; }
+
 // Write genotype-scan task `ti` (allele == 0 marks a slot without a scan).  Task i < n_lines is
 // "line i, ALT #1"; tasks past n_lines are the further ALT indices of multiallelic lines.
+// n_rec / rec0 / rec1 (streaming path): the allele records that take their counts from this scan -- record 0 at alleles[rec0],
+// record j >= 1 at alleles[rec1 + j - 1] -- which k_gt then fills in itself (0: none, or left to k_finish)
 __device__ inline void put_task(const KernelArgs &a, uint32_t ti, uint32_t line, uint32_t allele, uint32_t s_begin,
-                                uint32_t cend, uint32_t cmap_off, uint32_t kind = 0u) {
+                                uint32_t cend, uint32_t cmap_off, uint32_t kind = 0u, uint32_t n_rec = 0u, uint32_t rec0 = 0u,
+                                uint32_t rec1 = 0u) {
   if (ti < a.max_tasks) {
     GtTask t;
     t.line = line;
@@ -108,8 +117,9 @@ __device__ inline void put_task(const KernelArgs &a, uint32_t ti, uint32_t line,
     t.s_begin = s_begin;
     t.cend = cend;
     t.cmap_off = cmap_off;
-    t.pad[0] = kind;  // (kRawTask: s_begin is the offset of the line's raw list in the class-map arena)
-    t.pad[1] = t.pad[2] = 0;
+    t.pad[0] = kind | (n_rec << kTaskRecShift);  // (kRawTask: s_begin is the offset of the line's raw list in the class-map arena)
+    t.pad[1] = rec0;
+    t.pad[2] = rec1;
     a.tasks[ti] = t;
     // (wide lines: the longest sample region bounds the windows per task of the split scans)
     if (a.wide && allele != 0 && cend >= s_begin) atomicMax(&a.counters->pad[1], cend - s_begin);
@@ -147,8 +157,8 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
   __shared__ uint32_t s_tab[kLinesPerStep * kTabRow];
   __shared__ uint32_t s_ls[kLinesPerStep], s_len[kLinesPerStep], s_found[kLinesPerStep], s_staged[kLinesPerStep],
       s_extra[kLinesPerStep];
-  __shared__ uint32_t s_wave[kWavesPerWg][3];
-  __shared__ uint32_t s_base[4];
+  __shared__ uint32_t s_wave[kWavesPerWg][4];
+  __shared__ uint32_t s_base[5];
   __shared__ FilterTable s_ft;  // FILTER sets
   {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(a.filters);
@@ -391,28 +401,56 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     const uint32_t want_rec = bound > 1 ? bound - 1 : 0u;
     // streaming path: a line whose ALT #1 scan k_stream left to k_gt takes one more task slot, so
     // that k_gt only has to visit the slots past n_lines there
-    const bool deferred = eval && a.fused && ns > 0 && line < a.max_tasks && a.results[line].n_fields == kDeferred;
+    uint32_t res_fields = 0, res_miss = 0;
+    if (eval && a.fused && ns > 0 && line < a.max_tasks) {
+      res_fields = a.results[line].n_fields;
+      res_miss = a.results[line].n_miss;
+    }
+    const bool deferred = eval && a.fused && ns > 0 && line < a.max_tasks && res_fields == kDeferred;
     const uint32_t want_task = ((eval && ns > 0 && mode == 2) ? n_commas : 0u) + (deferred ? 1u : 0u);
-    // streaming path: a line with an extra task slot (ALT #1 left to k_gt, or further ALT indices) goes on k_finish's
-    // work list; everything else is complete when this kernel ends
-    const unsigned long long fin_mask = __ballot(a.fused && want_task > 0);
-    uint32_t wt_rec, wt_task;
+    // streaming path: which of these slots will hold a scan -- three quarters of configs[3]'s are settled from class lists
+    // below -- so that k_gt walks a dense list of them, the same number per wave (real_tasks; striding over the slots themselves
+    // the unluckiest of 4 096 waves had 13 scans where the mean is 5, and that wave was the kernel's time).  ALT #1 of a deferred
+    // line and all its further ALT indices; the further ALT indices of a line whose ALT #1 is a dense map (raw list or text);
+    // of a line kept as class lists those past the last list when somebody is missing.
+    uint32_t lcm = BVCF_NO_CMAP, want_real = 0;
+    if (a.fused && want_task > 0) {
+      if (deferred) {
+        want_real = want_task;
+      } else {
+        if (maps) lcm = a.line_cmap[line];
+        if (further_listed(lcm)) {
+          const uint32_t kmax = further_kmax(lcm);
+          if (res_miss != 0u && n_commas + 1u > kmax) want_real = n_commas + 1u - kmax;
+        } else {
+          want_real = n_commas;
+        }
+      }
+    }
+    // streaming path: a line whose ALT #1 is left to k_gt goes on k_finish's work list (the scan also settles its field
+    // count); everything else is complete when this kernel -- and, for further ALT indices with a scan, k_gt -- ends
+    // (a further ALT index of a line k_stream scanned: k_gt writes the counts into the records itself, see put_task)
+    const unsigned long long fin_mask = __ballot(a.fused && deferred);
+    uint32_t wt_rec, wt_task, wt_real;
     uint32_t extra_base = wave_excl_scan(want_rec, &wt_rec);
     uint32_t task_base = wave_excl_scan(want_task, &wt_task);
+    uint32_t real_base = wave_excl_scan(want_real, &wt_real);
     uint32_t fin_at = __builtin_amdgcn_mbcnt_hi((uint32_t)(fin_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fin_mask, 0u));
     if (lane == 0) {
       s_wave[w][0] = wt_rec;
       s_wave[w][1] = wt_task;
       s_wave[w][2] = (uint32_t)__popcll(fin_mask);
+      s_wave[w][3] = wt_real;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 4) {
       uint32_t sum = 0;
       for (int k = 0; k < kWavesPerWg; k++) sum += s_wave[k][threadIdx.x];
       uint32_t got = 0;
       if (sum)
-        got = atomicAdd(threadIdx.x == 0 ? &a.counters->n_alleles : (threadIdx.x == 1 ? &a.counters->n_tasks : &a.counters->n_finish), sum);
-      s_base[threadIdx.x == 2 ? 3 : threadIdx.x] = got;
+        got = atomicAdd(threadIdx.x == 0 ? &a.counters->n_alleles : (threadIdx.x == 1 ? &a.counters->n_tasks :
+                        (threadIdx.x == 2 ? &a.counters->n_finish : &a.counters->n_real)), sum);
+      s_base[threadIdx.x == 2 ? 3 : (threadIdx.x == 3 ? 4 : threadIdx.x)] = got;
       // streaming path: the class maps of the extra tasks come from the same cursor k_stream used
       if (threadIdx.x == 1) s_base[2] = (sum && a.fused && maps) ? atomicAdd(&a.counters->cmap_maps, sum) : 0u;
     }
@@ -422,8 +460,10 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
       extra_base += s_wave[k][0];
       task_rank += s_wave[k][1];
       fin_at += s_wave[k][2];
+      real_base += s_wave[k][3];
     }
-    if (a.fused && want_task > 0 && s_base[3] + fin_at < a.max_lines + a.max_alleles) a.finish_items[s_base[3] + fin_at] = line;
+    real_base += s_base[4];
+    if (a.fused && deferred && s_base[3] + fin_at < a.max_lines + a.max_alleles) a.finish_items[s_base[3] + fin_at] = line;
     extra_base += n_lines + s_base[0];
     task_base = n_lines + s_base[1] + task_rank;
     const uint32_t map_base = a.fused ? s_base[2] + task_rank : task_base;
@@ -461,6 +501,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
           task0 = task_base;
           cm0 = cmap_of(a, map_base, maps);
           put_task(a, task0, line, 1, s_begin, cend, cm0);
+          if (real_base < a.max_tasks) a.real_tasks[real_base] = task0;
           tasks_used = 1;
         } else if (maps) {
           cm0 = a.line_cmap[line];
@@ -469,8 +510,8 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
       first_task = task0;
     }
     // Streaming path: the counts of ALT #1 of a line k_stream scanned are final (results[line]), as are those of the
-    // further ALT indices resolved from class lists below: such records are complete here.  A line with records that
-    // still depend on k_gt is on k_finish's work list (above).
+    // further ALT indices resolved from class lists below: such records are complete here; those of further ALT indices
+    // with a scan are completed by k_gt.  A line whose ALT #1 depends on k_gt is on k_finish's work list (above).
     const bool final0 = eval && a.fused && ns > 0 && !deferred && line < a.max_tasks;
     {
       const uint32_t n_tok = has_tok ? (mode == 1 ? 1u : n_commas + 1u) : 0u;
@@ -497,6 +538,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         const uint32_t o_pair0 = from_owner(pair0), o_flags = from_owner(lflags), o_commas = from_owner(n_commas);
         const uint32_t o_extra = from_owner(extra_base), o_task = from_owner(task_base), o_map = from_owner(map_base);
         const uint32_t o_task0 = from_owner(task0), o_cm0 = from_owner(cm0);
+        const uint32_t o_real = from_owner(real_base), o_miss = from_owner(res_miss);
         const uint32_t o_emitted = from_owner(emitted), o_used = from_owner(tasks_used), o_dropped = from_owner(dropped ? 1u : 0u);
         const uint32_t k = q0 + (uint32_t)lane - o_pair0;  // ALT index of this lane's token
         const uint32_t o_mode = o_flags & 3u;
@@ -559,6 +601,16 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         const uint32_t emitted_before = o_emitted + seg_excl(n_me);
         const uint32_t used_before = o_used + seg_excl(tk_me);
         uint32_t stype_me = 0;
+        // this token's place in k_gt's list (see want_real): written whether or not the token ends up with a scan
+        uint32_t real_at = kNoTask, real_task = kNoTask;
+        if (pl && a.fused && ns > 0 && k > 0 && o_mode == 2u) {
+          if (o_deferred)
+            real_at = o_real + k;
+          else if (!further_listed(o_cm0))
+            real_at = o_real + k - 1u;
+          else if (o_miss != 0u && k >= further_kmax(o_cm0))
+            real_at = o_real + k - further_kmax(o_cm0);
+        }
 
         if (live) {
           if (e.err) log_err(a, o_line, (e.err == BVCF_ERR_POS) ? 0u : k + 1u, e.err, k);
@@ -575,12 +627,11 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
               // (the reference rescans it once per allele, main.go:549-556).  The counts come from the list.
               bool resolved = false;
               const bool raw = a.fused && !o_deferred && o_cm0 != BVCF_NO_CMAP && (o_cm0 & 15u) == kRawEnc;
-              if (a.fused && !o_deferred && o_cm0 != BVCF_NO_CMAP && (o_cm0 & 15u) && !raw && task < a.max_tasks) {
+              if (a.fused && !o_deferred && further_listed(o_cm0) && task < a.max_tasks) {
                 // bit 0: ALT #1 is a class list and the lists of ALT #2..#kmax follow it in the slot (kmax - 1 in bits 1-3).
                 // Otherwise ALT #1 is a dense map and bits 1-3 = 1: no sample carries a further allele (finish_list,
                 // finish_dense; kRawEnc: some do, and k_gt settles them from the entries saved behind the slot)
-                const bool in_slot = (o_cm0 & 1u) != 0;
-                const uint32_t kmax = in_slot ? ((o_cm0 >> 1) & 7u) + 1u : 1u;
+                const uint32_t kmax = further_kmax(o_cm0);
                 r.ac = 0;
                 r.an = g0.an;
                 r.n_het = r.n_hom = 0;
@@ -600,7 +651,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
                   }
                   r.ac = r.n_het + 2u * r.n_hom;
                   resolved = true;
-                } else if (g0.n_miss == 0) {
+                } else if (o_miss == 0u) {
                   cm_off = BVCF_NO_CMAP;  // nobody carries it and nobody is missing: ac == 0, the row is dropped (main.go:558-560)
                   resolved = true;
                 }
@@ -610,15 +661,21 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
                   gr = &r;
                 }
               }
+              // the records of this token (below): filled in by k_gt when the line itself is settled (a deferred line is on
+              // k_finish's list: the scan of its ALT #1 may still reject it)
+              const uint32_t t_rec = (a.fused && !o_deferred && o_fits) ? e.n : 0u;
+              const uint32_t rec0 = emitted_before == 0u ? o_line : o_extra + emitted_before - 1u, rec1 = o_extra + emitted_before;
               if (raw) {
                 // k_gt classifies the line's saved entries for this allele instead of reading the line again
                 resolved = true;
                 cm_off = cmap_of(a, o_map + used_before, maps);
-                put_task(a, task, o_line, k + 1, (o_cm0 & ~15u) + a.cmap_stride, o_cend, cm_off, kRawTask);
+                put_task(a, task, o_line, k + 1, (o_cm0 & ~15u) + a.cmap_stride, o_cend, cm_off, kRawTask, t_rec, rec0, rec1);
+                real_task = task;
               }
               if (!resolved) {
                 cm_off = cmap_of(a, o_map + used_before, maps);
-                put_task(a, task, o_line, k + 1, o_sbegin, o_cend, cm_off);
+                put_task(a, task, o_line, k + 1, o_sbegin, o_cend, cm_off, 0u, t_rec, rec0, rec1);
+                real_task = task;
               }
             }
             if (ns == 0) task = kNoTask;
@@ -651,6 +708,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
             }
           }
         }
+        if (real_at < a.max_tasks) a.real_tasks[real_at] = real_task;
         // ---- back to the lines: the sums up to and including the last of their tokens in this round
         const uint32_t seg_end = min(pair0 + n_tok, q0 + (uint32_t)kWave) - q0 - 1u;  // (meaningful where `mine`)
         const uint32_t from = (mine ? seg_end : (uint32_t)lane) * 4u;

@@ -250,9 +250,7 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
       nb += 8u * k;
       in_pos += k;
     };
-    auto refill_mid = [&]() {};  // (the symbol's start left enough)
 #else
-    auto refill_mid = [&]() {};
     // keep >= 32 bits in the buffer (a symbol needs at most 15 + 13 extra)
     auto refill = [&]() {
       while (nb <= 32u) {
@@ -480,9 +478,7 @@ __device__ __forceinline__ void k_inflate_body(const uint8_t *comp, const BgzfDe
         uint32_t extra;
         uint32_t len = inf_len_base(sym - 257u, &extra);
         len += take(extra);
-#ifdef BVCF_INF_REFILL64
-        refill_mid();
-#else
+#ifndef BVCF_INF_REFILL64
         refill();
 #endif
         e = bcast0(S.dist[(uint32_t)bb & ((1u << kInfDistBits) - 1u)]);

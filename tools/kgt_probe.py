@@ -24,6 +24,11 @@ ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=int(os.env
              cmap_bytes=min((n_alt + nbytes // (4 * ns + 8) + 16 * 8192) * stride + 4096, 0xFFFFFF00))
 chain, scan, counts = ctx.bench_device([t.data_ptr()], [nbytes], 12, slots=1)
 print(over, "chain ms", sum(chain) / len(chain), "counts", list(counts)[:8])
+if hasattr(bv.lib, "bvcf_debug_gt_kinds"):  # an experiments build: k_gt's tasks by kind, per block
+    import ctypes as C
+    kinds = (C.c_uint * 4)()
+    bv.lib.bvcf_debug_gt_kinds(kinds)
+    print("k_gt tasks per block: raw list %.0f, regular text %.0f, general text %.0f" % tuple(k / 12 for k in list(kinds)[:3]))
 ctx.close()
 if os.environ.get("KGT_HEAD_PHASES"):  # needs a -DBVCF_EXP_TIMES build (BVCF_LIB=...): k_head's time per phase
     import ctypes as C
