@@ -14,6 +14,7 @@ constexpr int kWave = 64;
 constexpr int kWavesPerWg = 4;
 constexpr int kWgThreads = kWave * kWavesPerWg;
 constexpr uint32_t kChunk = 1024;      // bytes per wave-iteration (16 B x 64 lanes)
+constexpr uint32_t kMaxProducerWaves = 32768;  // upper bound of KernelArgs.prod_waves (8 workgroups of 4 waves on 1024 CUs)
 constexpr uint32_t kScanGroup = 1024;  // census entries per level-1 scan group
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -87,6 +88,8 @@ struct KernelArgs {
   const FilterTable *filters;
   uint32_t *census;      // [n_chunks] newline count per chunk -> exclusive prefix within group
   uint32_t *group_base;  // [n_groups]
+  uint32_t *run_lines;   // [prod_waves] streaming path: lines listed by each wave of k_stream / k_stream_gen (its run of tiles)
+  uint32_t prod_waves;   // waves of the one-pass kernel's grid
   uint32_t *s2_groups;       // k_census_tiles / k_sites2: line ends per group of kS2GroupTiles tiles, this batch's half ...
   uint32_t *s2_groups_next;  // ... and the half of the slot's next batch, zeroed meanwhile
   uint32_t *line_off;    // [max_lines + 1]

@@ -31,6 +31,7 @@ struct Slot {
   // device
   uint8_t *d_in = nullptr;
   uint32_t *d_census = nullptr, *d_group = nullptr, *d_line_off = nullptr;
+  uint32_t group_words = 0;
   uint32_t *d_s2_groups = nullptr;  // k_census_tiles: two sets of group totals, used by the slot's batches in turn
   uint32_t s2_parity = 0;           // ... which one the batch being launched adds to (make_args)
   bvcf_line *d_lines = nullptr;
@@ -422,7 +423,9 @@ int alloc_slot(bvcf_ctx *c, Slot &s) {
     c->s2_groups_cap = s2_n_groups(nt) + 2u;
   }
   HIP_TRY(c, hipMalloc(&s.d_census, s.cap_census * sizeof(uint32_t)));
-  HIP_TRY(c, hipMalloc(&s.d_group, (s.cap_census / kScanGroup + 2) * sizeof(uint32_t)));
+  // (group totals of the census scan, then -- from a 16-byte boundary -- the lines per producer wave of the streaming path)
+  s.group_words = ((uint32_t)(s.cap_census / kScanGroup) + 2u + 3u) & ~3u;
+  HIP_TRY(c, hipMalloc(&s.d_group, ((size_t)s.group_words + kMaxProducerWaves) * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&s.d_s2_groups, 2ull * c->s2_groups_cap * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(s.d_s2_groups, 0, 2ull * c->s2_groups_cap * sizeof(uint32_t)));
   s.s2_parity = 0;
@@ -455,6 +458,7 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.filters = c->d_filters;
   a.census = s.d_census;
   a.group_base = s.d_group;
+  a.run_lines = s.d_group + s.group_words;
   a.s2_groups = s.d_s2_groups + (s.s2_parity & 1u) * c->s2_groups_cap;
   a.s2_groups_next = s.d_s2_groups + ((s.s2_parity & 1u) ^ 1u) * c->s2_groups_cap;
   a.line_off = s.d_line_off;
@@ -470,6 +474,7 @@ KernelArgs make_args(bvcf_ctx *c, Slot &s, const uint8_t *d_src, size_t nbytes) 
   a.counters = s.d_counters;
   a.fused = c->fused ? 1u : 0u;
   a.gen_stream = c->gen_mode ? 1u : 0u;
+  a.prod_waves = (uint32_t)(c->gen_mode ? c->gen_grid : c->stream_grid) * kWavesPerWg;
   a.wide = c->wide ? 1u : 0u;
   a.win_bytes = c->win_bytes;
   a.win_tabs = s.d_win_tabs;
@@ -509,7 +514,6 @@ void adapt_stream_kernel(bvcf_ctx *c, bool was_gen, const BatchCounters &ctr) {
 
 void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t ev_gt0, hipEvent_t ev_gt1, Slot *slot = nullptr) {
   if (a.fused) {
-    const uint32_t n_groups = (a.n_tiles + kScanGroup - 1) / kScanGroup;
     // The one-pass kernels of ALL batches go through one stream of the ctx, one after the other at full rate; what follows a
     // batch's pass runs on the slot's stream beside the next batches' passes.
     const bool split = c->scan_stream && slot && slot->ev_in && slot->ev_scan;
@@ -529,8 +533,6 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
       hipEventRecord(slot->ev_scan, ss);
       hipStreamWaitEvent(st, slot->ev_scan, 0);
     }
-    hipLaunchKernelGGL(k_scan_groups, dim3(n_groups ? n_groups : 1), dim3(kWgThreads), 0, st, a, a.n_tiles);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, a, n_groups);
     hipLaunchKernelGGL(k_order, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
 #ifdef BVCF_EXPERIMENTS
     // experiment (results are then wrong): which follower costs what with blocks in flight -- 1: no k_head, 2: no k_gt, 4: no k_finish

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   uint32_t cm_next = 0, cm_end = 0;  // this wave's private block of class-map slots
   uint32_t seen = 0;                 // terminated lines this wave walked over
   uint32_t n_other = 0;              // listed lines that were not of the regular shape (left to k_gt)
+  uint32_t n_listed = 0;             // lines listed in the tiles this wave has closed
 
   // A wave owns a contiguous run of tiles and walks it front to back, so only the first tile needs
   // a search for its first line start (those bytes are the previous wave's last line).  Entries
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
     // (a deferred line gets its class map with its k_gt task, not here)
     while (ls >= (tile + 1) * T) {  // ls moved into a later tile of the run
       if (lane == 0) a.census[tile] = n_local;
+      n_listed += n_local;
       tile++;
       n_local = 0;
     }
@@ -457,8 +459,10 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
   }
   for (; tile < tile_hi; tile++) {  // the rest of the run has no line starts
     if (lane == 0) a.census[tile] = n_local;
+    n_listed += n_local;
     n_local = 0;
   }
+  if (lane == 0) a.run_lines[wave] = n_listed;  // (every wave of the grid, with or without tiles: k_order adds them up)
   if (lane == 0 && seen) atomicAdd(&a.counters->lines_seen, seen);
   if (lane == 0 && n_other) atomicAdd(&a.counters->n_other_shape, n_other);
 #ifdef BVCF_EXP_TIMES
@@ -473,42 +477,102 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
 #include "bvcf_streamgen.hip.h"
 namespace bvcf_dev {
 
-// tile-local entries -> input order (the exclusive scan of the tile counts is in census/group_base)
+// tile-local entries -> input order, and the batch's line count.  One kernel (round 5; k_scan_groups + k_scan_top + a k_order
+// that read their result before): with blocks in flight every kernel boundary of a chain is a wait for wave slots the other
+// blocks' k_stream holds.  Workgroup b owns the tiles of a few consecutive waves of the one-pass kernel (their runs are
+// contiguous); the lines before them are the sum of those waves' totals (run_lines: a few thousand words), and an exclusive
+// scan of its own tiles' counts in LDS gives every entry its place.
 __global__ __launch_bounds__(kWgThreads) void k_order(KernelArgs a) {
-  const uint32_t total = a.n_tiles * a.tile_quota;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const uint32_t tile = i / a.tile_quota, k = i % a.tile_quota;
-    const uint32_t first = a.census[tile] + a.group_base[tile / kScanGroup];
-    const uint32_t next = (tile + 1 < a.n_tiles)
-                              ? a.census[tile + 1] + a.group_base[(tile + 1) / kScanGroup]
-                              : a.counters->n_lines;
-    if (k >= next - first) continue;
-    const uint32_t g = first + k;
-    if (g >= a.max_lines) continue;
-    const StreamEntry en = a.entries[i];
-    a.line_off[g] = en.ls;
-    a.line_len[g] = en.len & ~kNotRegular;  // (bit 31: line_bits[g] is valid)
-    a.line_cmap[g] = en.cmap_off;
-    if (en.len & kHasHeadBits) {
-      const u32x4 *src = reinterpret_cast<const u32x4 *>(a.head_bits + (size_t)i * 16u);
-      u32x4 *dst = reinterpret_cast<u32x4 *>(a.line_bits + (size_t)g * 8u);
-      dst[0] = src[0];
-      dst[1] = src[1];
-    }
-    if (g < a.max_tasks) {
-      GtResult r;
-      r.ac = en.ac;
-      r.an = en.an;
-      r.n_het = en.n_het;
-      r.n_hom = en.n_hom;
-      r.n_miss = en.n_miss;
-      r.n_fields = en.n_miss == kDeferred ? kDeferred : a.n_header - 9u;
-      // (k_stream only lists counts of lines its regular scan accepted; k_stream_gen marks lines with haploid / odd fields)
-      r.regular = (en.n_miss == kDeferred || (en.len & kNotRegular)) ? 0u : 1u;
-      r.pad = 0;
-      a.results[g] = r;
-    }
+  __shared__ uint32_t s_part[2][kWavesPerWg];
+  __shared__ uint32_t s_first[kWgThreads + 1];
+  const int lane = lane_id();
+  const uint32_t w = threadIdx.x >> 6;
+  if (a.n_tiles == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counters->n_lines = 0;
+    return;
   }
+  // the producer's split of the tiles over its waves (k_stream, k_stream_gen: the first n_tiles % n_waves runs are one longer)
+  const uint32_t pw = a.prod_waves;
+  const uint32_t q_tiles = a.n_tiles / pw, r_tiles = a.n_tiles % pw;
+  auto run_first = [&](uint32_t wv) -> uint32_t { return wv * q_tiles + min(wv, r_tiles); };
+  const uint32_t per_wg = (pw + gridDim.x - 1u) / gridDim.x;
+  const uint32_t w_lo = min(blockIdx.x * per_wg, pw), w_hi = min(w_lo + per_wg, pw);
+  const uint32_t t_lo = run_first(w_lo), t_hi = run_first(w_hi);
+  // ---- lines before this range
+  uint32_t sum = 0;
+  {
+    const uint32_t n4 = w_lo / 4u;
+    const u32x4 *c4 = reinterpret_cast<const u32x4 *>(a.run_lines);
+    for (uint32_t i = threadIdx.x; i < n4; i += kWgThreads) {
+      const u32x4 v = c4[i];
+      sum += v.x + v.y + v.z + v.w;
+    }
+    if (threadIdx.x < (w_lo & 3u)) sum += a.run_lines[n4 * 4u + threadIdx.x];
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) s_part[0][w] = sum;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t i = 0; i < kWavesPerWg; i++) base += s_part[0][i];
+  if (w_hi == pw && w_lo < pw && t_lo >= t_hi && threadIdx.x == 0) {  // (a last range without tiles still owes the count)
+    uint32_t rest = 0;
+    for (uint32_t i = w_lo; i < w_hi; i++) rest += a.run_lines[i];
+    a.counters->n_lines = base + rest;
+  }
+  if (t_lo >= t_hi) return;
+  // ---- the range, kWgThreads tiles at a time
+  for (uint32_t c0 = t_lo; c0 < t_hi; c0 += kWgThreads) {
+    const uint32_t n_here = min(t_hi - c0, (uint32_t)kWgThreads);
+    const uint32_t cnt = threadIdx.x < n_here ? min(a.census[c0 + threadIdx.x], a.tile_quota) : 0u;
+    uint32_t wtot;
+    const uint32_t pre = wave_excl_scan(cnt, &wtot);
+    __syncthreads();  // (s_part[1], s_first: the round before is through)
+    if (lane == 0) s_part[1][w] = wtot;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (uint32_t i = 0; i < kWavesPerWg; i++) {
+      if (i < w) wbase += s_part[1][i];
+      total += s_part[1][i];
+    }
+    s_first[threadIdx.x] = wbase + pre;
+    if (threadIdx.x == 0) s_first[kWgThreads] = total;
+    __syncthreads();
+    const uint32_t pairs = n_here * a.tile_quota;
+    for (uint32_t i = threadIdx.x; i < pairs; i += kWgThreads) {
+      const uint32_t tl = i / a.tile_quota, k = i % a.tile_quota;
+      const uint32_t first = s_first[tl];
+      const uint32_t next = tl + 1u < kWgThreads ? s_first[tl + 1u] : s_first[kWgThreads];
+      if (k >= next - first) continue;
+      const uint32_t g = base + first + k;
+      if (g >= a.max_lines) continue;
+      const size_t ei = (size_t)(c0 + tl) * a.tile_quota + k;
+      const StreamEntry en = a.entries[ei];
+      a.line_off[g] = en.ls;
+      a.line_len[g] = en.len & ~kNotRegular;  // (bit 31: line_bits[g] is valid)
+      a.line_cmap[g] = en.cmap_off;
+      if (en.len & kHasHeadBits) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.head_bits + ei * 16u);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(a.line_bits + (size_t)g * 8u);
+        dst[0] = src[0];
+        dst[1] = src[1];
+      }
+      if (g < a.max_tasks) {
+        GtResult r;
+        r.ac = en.ac;
+        r.an = en.an;
+        r.n_het = en.n_het;
+        r.n_hom = en.n_hom;
+        r.n_miss = en.n_miss;
+        r.n_fields = en.n_miss == kDeferred ? kDeferred : a.n_header - 9u;
+        // (k_stream only lists counts of lines its regular scan accepted; k_stream_gen marks lines with haploid / odd fields)
+        r.regular = (en.n_miss == kDeferred || (en.len & kNotRegular)) ? 0u : 1u;
+        r.pad = 0;
+        a.results[g] = r;
+      }
+    }
+    base += s_first[kWgThreads];  // (every thread reads it before the next round's first barrier)
+  }
+  if (t_hi == a.n_tiles && threadIdx.x == 0) a.counters->n_lines = base;
 }
 
 

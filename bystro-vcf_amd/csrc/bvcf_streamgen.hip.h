@@ -681,7 +681,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream_gen(KernelArgs a) {
   const uint32_t tile_hi = tile_lo + q_tiles + (wave < r_tiles ? 1u : 0u);
   const uint32_t r0 = tile_lo * T;
   const uint32_t r1 = (uint32_t)min((unsigned long long)tile_hi * T, (unsigned long long)nb);
-  uint32_t tile = tile_lo, n_local = 0;
+  uint32_t tile = tile_lo, n_local = 0, n_listed = 0;
   uint32_t p = kNone;
   if (tile_lo < tile_hi) {
     p = 0;
@@ -706,6 +706,7 @@ __global__ __launch_bounds__(kWgThreads) void k_stream_gen(KernelArgs a) {
   auto commit = [&](uint32_t ls, uint32_t cend, const GtStats &st, bool deferred, uint32_t cm_off, bool irregular = false) {
     while (ls >= (tile + 1) * T) {
       if (lane == 0) a.census[tile] = n_local;
+      n_listed += n_local;
       tile++;
       n_local = 0;
     }
@@ -732,8 +733,10 @@ __global__ __launch_bounds__(kWgThreads) void k_stream_gen(KernelArgs a) {
   if (p != kNone && p < r1) stream_general_run(a, p, r1, n_chunks, stage, list, ring, seen, n_regular, commit, map_slot);
   for (; tile < tile_hi; tile++) {
     if (lane == 0) a.census[tile] = n_local;
+    n_listed += n_local;
     n_local = 0;
   }
+  if (lane == 0) a.run_lines[wave] = n_listed;  // (every wave of the grid: k_order adds them up)
   if (lane == 0 && seen) atomicAdd(&a.counters->lines_seen, seen);
   if (lane == 0 && n_regular) atomicAdd(&a.counters->n_other_shape, n_regular);
 #ifdef BVCF_EXP_TIMES
