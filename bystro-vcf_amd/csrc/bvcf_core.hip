@@ -2095,7 +2095,7 @@ int bvcf_bench_device_slots(bvcf_ctx *c, const void *const *dblocks, const size_
 
 }  // extern "C"
 
-#ifdef BVCF_EXPERIMENTS
+#ifdef BVCF_EXP_GT_KINDS
 // tasks k_gt ran since the last call, by kind (see g_gt_kinds)
 extern "C" int bvcf_debug_gt_kinds(unsigned int out[4]) {
   const unsigned int z[4] = {0, 0, 0, 0};

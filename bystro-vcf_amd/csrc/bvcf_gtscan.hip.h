@@ -683,7 +683,7 @@ __device__ inline void gt_scan_general(const KernelArgs &a, uint32_t s_begin, ui
 
 // ------------------------------------------------------------------ k_gt: one wave per task
 
-#ifdef BVCF_EXPERIMENTS
+#ifdef BVCF_EXP_GT_KINDS  // (one atomic per task on one address: the kernel's time is not to be read in such a build)
 __device__ unsigned int g_gt_kinds[4];  // tasks k_gt ran: raw list, regular text, general text, summed windows (bvcf_debug_gt_kinds)
 #define GT_KIND(k) if (lane == 0) atomicAdd(&g_gt_kinds[k], 1u)
 #else
