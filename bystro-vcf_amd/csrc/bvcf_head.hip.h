@@ -183,7 +183,19 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     // lane gl of a group fetches the offsets of the group's round-gl line, so the 16 rounds' offsets
     // are in flight together; the first window of round r + 1 is requested before round r is parsed
     uint32_t my_ls = 0, my_len = 0;
-    {
+    uint32_t my_line_ls = 0, my_line_len = 0;  // (streaming chains: of line line0 + threadIdx.x)
+    if (!kAllWindows) {
+      const uint32_t l = line0 + threadIdx.x;
+      if (l < n_lines) {
+        my_line_ls = a.line_off[l];
+        if (a.fused) {
+          my_line_len = a.line_len[l];  // (bit 31 rides along: the line's head TAB bitmap is in line_bits)
+        } else {
+          const uint32_t le = a.line_off[l + 1];
+          my_line_len = le - my_line_ls >= a.eol_chars ? le - my_line_ls - a.eol_chars : 0u;  // chomp, main.go:535
+        }
+      }
+    } else {
       const uint32_t l = line0 + (uint32_t)gl * kGroupsPerWg + g;
       if (l < n_lines) {
         my_ls = a.line_off[l];
@@ -195,10 +207,10 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         }
       }
     }
-    // kAllWindows (census path): the first 256 B window of all 16 rounds is requested up front, unconditionally
+    // kAllWindows (k_head: a ctx of one slot): the first 256 B window of all 16 rounds is requested up front, unconditionally
     // (lines past the end read offset 0), so the rounds are paced by the parse, not by one memory latency each;
-    // costs 64 registers.  Otherwise (streaming path) one window ahead: at 142 registers a wave of this kernel
-    // fits on a SIMD beside two waves of the next batch's k_stream instead of waiting for them to finish.
+    // costs 64 registers.  Otherwise (k_head_lean: chains that run beside another batch's k_stream, where a wave of 225
+    // registers would wait for a whole SIMD's worth): see the staging below.
     constexpr uint32_t kRounds = kLinesPerStep / kGroupsPerWg;
     u32x4 v_win[kAllWindows ? kRounds : 1u];
     uint32_t r_ls[kAllWindows ? kRounds : 1u], r_len[kAllWindows ? kRounds : 1u];
@@ -209,8 +221,6 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         r_len[r] = __shfl(my_len, r, kGroup);
         v_win[r] = *reinterpret_cast<const u32x4_u *>(a.buf + min(r_ls[r] + 16u * gl, a.cap - 16u));
       }
-    } else {
-      v_win[0] = load16(a.buf, __shfl(my_ls, 0, kGroup) + 16u * gl, a.cap);
     }
     auto tokenise = [&](uint32_t r, uint32_t ls, uint32_t len_flag, const u32x4 &v_first) {
       const uint32_t ll = r * kGroupsPerWg + g;
@@ -280,15 +290,67 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         s_extra[ll] = extra;
       }
     };
+    // this thread's line in phase S: its TAB bitmap and ALT #1's counts are asked for here, beside the head bytes, not one
+    // memory latency each later on
+    u32x4 pre_b0 = {0u, 0u, 0u, 0u}, pre_b1 = {0u, 0u, 0u, 0u};
+    GtResult pre_res = GtResult{};
+    bool pre_res_ok = false;
     if (kAllWindows) {
 #pragma unroll
       for (uint32_t r = 0; r < kRounds; r++) tokenise(r, r_ls[kAllWindows ? r : 0], r_len[kAllWindows ? r : 0], v_win[kAllWindows ? r : 0]);
     } else {
+      // Lines whose TABs k_stream found -- all but the first of a wave's run, on the streaming path -- need only their first
+      // kHeadStage bytes staged: kHeadStage / 16 lanes per line, every round's load in flight at once.  (Before: the 16-lane
+      // rounds below for every line, one window ahead: sixteen memory latencies per step for 64 of each 256 bytes loaded.)
+      constexpr uint32_t kLanesPerHead = kHeadStage / 16u, kLinesPerRound = kWgThreads / kLanesPerHead;
+      constexpr uint32_t kHeadRounds = kLinesPerStep / kLinesPerRound;
+      static_assert(kHeadStage % 16u == 0 && kWgThreads % kLanesPerHead == 0 && kLinesPerStep % kLinesPerRound == 0, "head staging");
+      s_ls[threadIdx.x] = my_line_ls;
+      s_len[threadIdx.x] = my_line_len;
+      s_found[threadIdx.x] = 0;
+      s_staged[threadIdx.x] = min(my_line_len & ~kHasHeadBits, kHeadStage);
+      s_extra[threadIdx.x] = 0;
+      __syncthreads();
+      u32x4 hv[kHeadRounds];
+      const uint32_t hq = threadIdx.x % kLanesPerHead;
+#pragma unroll
+      for (uint32_t r = 0; r < kHeadRounds; r++) {
+        const uint32_t ll = r * kLinesPerRound + threadIdx.x / kLanesPerHead;
+        hv[r] = u32x4{0u, 0u, 0u, 0u};
+        if (line0 + ll < n_lines && (s_len[ll] & kHasHeadBits)) hv[r] = load16(a.buf, s_ls[ll] + 16u * hq, a.cap);
+      }
+      {
+        const uint32_t line = line0 + threadIdx.x;
+        if (line < n_lines && (my_line_len & kHasHeadBits)) {
+          const u32x4 *bits = reinterpret_cast<const u32x4 *>(a.line_bits + (size_t)line * 8u);
+          pre_b0 = bits[0];
+          pre_b1 = bits[1];
+        }
+        if (line < n_lines && a.fused && ns > 0 && line < a.max_tasks) {
+          pre_res = a.results[line];
+          pre_res_ok = true;
+        }
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < kHeadRounds; r++) {
+        const uint32_t ll = r * kLinesPerRound + threadIdx.x / kLanesPerHead;
+        if (line0 + ll < n_lines && (s_len[ll] & kHasHeadBits)) {
+          uint32_t *row = &s_head[ll * kHeadRow + 4u * hq];
+          row[0] = hv[r].x;
+          row[1] = hv[r].y;
+          row[2] = hv[r].z;
+          row[3] = hv[r].w;
+        }
+      }
+      // the others: tokenised from the text, 16 lanes a line
 #pragma nounroll
       for (uint32_t r = 0; r < kRounds; r++) {
-        const u32x4 v_first = v_win[0];
-        if (r + 1 < kRounds) v_win[0] = load16(a.buf, __shfl(my_ls, r + 1, kGroup) + 16u * gl, a.cap);
-        tokenise(r, __shfl(my_ls, r, kGroup), __shfl(my_len, r, kGroup), v_first);
+        const uint32_t ll = r * kGroupsPerWg + g;
+        const uint32_t lf = s_len[ll];
+        if (line0 + ll < n_lines && !(lf & kHasHeadBits)) {
+          const uint32_t ls_r = s_ls[ll];
+          tokenise(r, ls_r, lf, load16(a.buf, ls_r + 16u * gl, a.cap));
+        }
       }
     }
     __syncthreads();
@@ -305,8 +367,12 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     uint32_t *tab = &s_tab[ll * kTabRow];
     if (len_flag & kHasHeadBits) {
       // the nine TABs from k_stream's bitmap of the head window (256 bits from the dword at or before ls)
-      const u32x4 *bits = reinterpret_cast<const u32x4 *>(a.line_bits + (size_t)line * 8u);
-      const u32x4 b0 = bits[0], b1 = bits[1];
+      u32x4 b0 = pre_b0, b1 = pre_b1;
+      if (kAllWindows) {
+        const u32x4 *bits = reinterpret_cast<const u32x4 *>(a.line_bits + (size_t)line * 8u);
+        b0 = bits[0];
+        b1 = bits[1];
+      }
       const uint32_t w[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       const uint32_t base = ls & ~3u;
       uint32_t k = 0;
@@ -403,8 +469,13 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     // that k_gt only has to visit the slots past n_lines there
     uint32_t res_fields = 0, res_miss = 0;
     if (eval && a.fused && ns > 0 && line < a.max_tasks) {
-      res_fields = a.results[line].n_fields;
-      res_miss = a.results[line].n_miss;
+      if (!kAllWindows && pre_res_ok) {
+        res_fields = pre_res.n_fields;
+        res_miss = pre_res.n_miss;
+      } else {
+        res_fields = a.results[line].n_fields;
+        res_miss = a.results[line].n_miss;
+      }
     }
     const bool deferred = eval && a.fused && ns > 0 && line < a.max_tasks && res_fields == kDeferred;
     const uint32_t want_task = ((eval && ns > 0 && mode == 2) ? n_commas : 0u) + (deferred ? 1u : 0u);
@@ -539,6 +610,17 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         const uint32_t o_extra = from_owner(extra_base), o_task = from_owner(task_base), o_map = from_owner(map_base);
         const uint32_t o_task0 = from_owner(task0), o_cm0 = from_owner(cm0);
         const uint32_t o_real = from_owner(real_base), o_miss = from_owner(res_miss);
+        // (streaming chains: ALT #1's counts of the owner's line were loaded with its head, see phase T)
+        GtResult o_res = GtResult{};
+        if (!kAllWindows) {
+          o_res.ac = from_owner(pre_res.ac);
+          o_res.an = from_owner(pre_res.an);
+          o_res.n_het = from_owner(pre_res.n_het);
+          o_res.n_hom = from_owner(pre_res.n_hom);
+          o_res.n_miss = from_owner(pre_res.n_miss);
+          o_res.n_fields = from_owner(pre_res.n_fields);
+          o_res.regular = 1;
+        }
         const uint32_t o_emitted = from_owner(emitted), o_used = from_owner(tasks_used), o_dropped = from_owner(dropped ? 1u : 0u);
         const uint32_t k = q0 + (uint32_t)lane - o_pair0;  // ALT index of this lane's token
         const uint32_t o_mode = o_flags & 3u;
@@ -617,7 +699,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
           if (e.n) {
             uint32_t task = o_task0, cm_off = o_cm0;
             GtResult g0 = GtResult{};
-            if (o_final0 && ns > 0) g0 = a.results[o_line];
+            if (o_final0 && ns > 0) g0 = kAllWindows ? a.results[o_line] : o_res;
             const GtResult *gr = (k == 0 && o_final0) ? &g0 : nullptr;
             GtResult r = GtResult{};
             if (ns > 0 && k > 0) {
@@ -775,7 +857,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
 }
 
 __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) { k_head_body<true>(a); }
-// the same at 142 registers, for chains that overlap with another batch's k_stream (see kAllWindows)
+// for chains that overlap with another batch's k_stream (see kAllWindows): 149 registers, three waves per SIMD
 __global__ __launch_bounds__(kWgThreads) void k_head_lean(KernelArgs a) { k_head_body<false>(a); }
 
 // ------------------------------------------------------------------ k_finish
