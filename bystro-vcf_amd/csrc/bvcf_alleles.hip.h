@@ -49,12 +49,15 @@ __device__ inline bool go_atoi(const B &buf, Span s, long long *out) {
     if (s.len == 1) return false;
   }
   unsigned long long v = 0;
-  const unsigned long long lim = neg ? 9223372036854775808ull : 9223372036854775807ull;
+  // v * 10 + d must stay within 2^63 - 1 (2^63 for a negative number): lim / 10 and lim % 10 spelled out -- a 64-bit division
+  // per digit was a hundred instructions of every wave that holds one deletion
+  const unsigned long long q = 922337203685477580ull;
+  const uint32_t r = neg ? 8u : 7u;
   #pragma nounroll
   for (; i < s.len; i++) {
     uint32_t d = (uint32_t)buf[s.off + i] - '0';
     if (d > 9u) return false;
-    if (v > (lim - d) / 10ull) return false;
+    if (v > q || (v == q && d > r)) return false;
     v = v * 10ull + d;
   }
   *out = neg ? (long long)(0ull - v) : (long long)v;
@@ -247,6 +250,203 @@ __device__ inline void eval_token(AlleleCtxT<B> &c, Span t, AlleleEval &e) {
     e.kind = BVCF_ALT_DEL;
     e.alt_len = (uint32_t)(lr + r - offset);
   }
+}
+
+// ---- the same from registers, for the shapes nearly every token has
+// eval_token / eval_single walk REF, ALT and POS byte by byte: every byte a dependent LDS read, a bounds test and a branch of
+// a divergent loop -- 15 000 clock ticks of a k_head step whose wave holds one indel, against 2 000 for SNPs alone.  When the
+// three fields lie inside the line's staged head (row: the LDS copy of the line's first kHeadRowBytes bytes, dwords), REF
+// is at most 8 bytes, ALT at most 16 with the token at most 8, and POS is 1-9 digits, the fields are read once as whole
+// words and the work is byte-parallel arithmetic on them.  Anything else: returns false, and the caller takes the walk.
+typedef const __attribute__((address_space(3))) uint32_t *lds_words_t;
+__device__ __forceinline__ lds_words_t as_lds_words(const void *p) { return (lds_words_t)p; }
+// 16 bytes of the row from byte `rel` (rel + 16 <= row bytes; the row has one more dword behind them)
+__device__ __forceinline__ u32x4 row_bytes16(lds_words_t row, uint32_t rel) {
+  const uint32_t i = rel >> 2, sh = rel & 3u;
+  const uint32_t w0 = row[i], w1 = row[i + 1u], w2 = row[i + 2u], w3 = row[i + 3u], w4 = row[i + 4u];
+  return u32x4{__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+               __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)};
+}
+// byte-parallel helpers over a word of 8 (unsigned long long) or 16 bytes (unsigned __int128)
+typedef unsigned __int128 u128_t;
+template <class W> struct WordBytes;
+template <> struct WordBytes<unsigned long long> {
+  static constexpr uint32_t kBytes = 8;
+  static __device__ __forceinline__ unsigned long long of(const u32x4 &v) { return ((unsigned long long)v.y << 32) | v.x; }
+  static __device__ __forceinline__ uint32_t clz(unsigned long long x) { return (uint32_t)__clzll((long long)x); }  // x != 0
+};
+template <> struct WordBytes<u128_t> {
+  static constexpr uint32_t kBytes = 16;
+  static __device__ __forceinline__ u128_t of(const u32x4 &v) {
+    return ((u128_t)(((unsigned long long)v.w << 32) | v.z) << 64) | (((unsigned long long)v.y << 32) | v.x);
+  }
+  static __device__ __forceinline__ uint32_t clz(u128_t x) {
+    const unsigned long long hi = (unsigned long long)(x >> 64), lo = (unsigned long long)x;
+    return hi ? (uint32_t)__clzll((long long)hi) : 64u + (uint32_t)__clzll((long long)lo);
+  }
+};
+template <class W> __device__ __forceinline__ W rep_byte(uint32_t b) {
+  const unsigned long long r = 0x0101010101010101ull * b;
+  return sizeof(W) == 8 ? (W)r : (W)(((u128_t)r << 64) | r);
+}
+template <class W> __device__ __forceinline__ W low_bytes_w(uint32_t n) { return n >= sizeof(W) ? ~(W)0 : (((W)1 << (8u * n)) - (W)1); }
+__device__ __forceinline__ unsigned long long low_bytes(uint32_t n) { return low_bytes_w<unsigned long long>(n); }
+// 0x80 in every byte of x that is zero, exact
+template <class W> __device__ __forceinline__ W zero_bytes_w(W x) {
+  const W m = rep_byte<W>(0x7Fu);
+  return ~(((x & m) + m) | x | m);
+}
+template <class W> __device__ __forceinline__ uint32_t popc_w(W x) {
+  return sizeof(W) == 8 ? (uint32_t)__popcll((unsigned long long)x)
+                        : (uint32_t)__popcll((unsigned long long)x) + (uint32_t)__popcll((unsigned long long)((u128_t)x >> (sizeof(W) == 8 ? 0 : 64)));
+}
+// strconv.Atoi for 1-9 plain digits at row byte `rel`; false: not that (the caller walks the field)
+__device__ __forceinline__ bool row_atoi9(lds_words_t row, uint32_t rel, uint32_t len, long long *out) {
+  if (len - 1u > 8u) return false;
+  const u32x4 v = row_bytes16(row, rel);
+  const unsigned long long lo = ((unsigned long long)v.y << 32) | v.x;
+  const uint32_t last = v.z & 0xFFu;  // (the ninth digit)
+  // every byte a digit: b - '0' <= 9, byte-parallel over the first eight (bytes past len masked to '0')
+  const unsigned long long keep = low_bytes(len);
+  const unsigned long long d = ((lo & keep) | (0x3030303030303030ull & ~keep)) ^ 0x3030303030303030ull;  // digits -> 0..9
+  if ((d & 0xF0F0F0F0F0F0F0F0ull) != 0ull) return false;                 // high nibble set: not '0'..'?'
+  if ((((d + 0x0606060606060606ull) & 0x1010101010101010ull)) != 0ull) return false;  // 10..15
+  if (len == 9u && (last - '0') > 9u) return false;
+  unsigned long long val = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 8u; i++)
+    if (i < len) val = val * 10ull + ((d >> (8u * i)) & 0xFull);
+  if (len == 9u) val = val * 10ull + (last - '0');
+  *out = (long long)val;
+  return true;
+}
+// the decisions of eval_token / eval_single on a token tk of nt bytes and a REF rf of nref bytes held in words of W
+template <class W>
+__device__ __forceinline__ bool eval_words(lds_words_t row, uint32_t pos_rel, AlleleCtx &c, bool single, const Span &t, W tk, W rf,
+                                           AlleleEval &e) {
+  const uint32_t nref = c.ref.len, nt = t.len;
+  constexpr uint32_t kB = WordBytes<W>::kBytes;
+  e = AlleleEval{};
+  // altIsValid, main.go:456-474
+  const W flags = rep_byte<W>(0x80u) & low_bytes_w<W>(nt);
+  const W actg = zero_bytes_w<W>(tk ^ rep_byte<W>('A')) | zero_bytes_w<W>(tk ^ rep_byte<W>('C')) |
+                 zero_bytes_w<W>(tk ^ rep_byte<W>('G')) | zero_bytes_w<W>(tk ^ rep_byte<W>('T'));
+  if (nt == 0u || (actg & flags) != flags) {
+    e.err = single ? BVCF_ERR_BAD_ALT1 : BVCF_ERR_BAD_ALT;
+    return true;
+  }
+  const uint8_t t0 = (uint8_t)tk, r0 = (uint8_t)rf;
+  if (nref == 1u) {  // main.go:743-750, 786-815
+    e.n = 1;
+    e.pos_text = true;
+    e.ref = r0;
+    if (nt == 1u) {
+      e.alt_base = t0;
+      e.kind = BVCF_ALT_BASE;
+      e.alt_len = 1;
+      return true;
+    }
+    if (t0 != r0) {
+      e = AlleleEval{};
+      e.err = BVCF_ERR_INS1;
+      return true;
+    }
+    e.kind = BVCF_ALT_INS;
+    e.alt_off = t.off + 1u;
+    e.alt_len = nt - 1u;
+    return true;
+  }
+  if (single && t0 != r0) {  // main.go:751 (before the Atoi there)
+    e.err = BVCF_ERR_DEL1_1;
+    return true;
+  }
+  long long ip;
+  if (!row_atoi9(row, pos_rel, c.pos.len, &ip)) return false;  // (odd POS fields: the walk knows every case)
+  c.int_pos = ip;  // (intPos, main.go:822: the records of an equal-length block count from it)
+  if (nt == 1u) {  // main.go:752-764, 832-847
+    if (t0 != r0) {
+      e.err = BVCF_ERR_DEL1;
+      return true;
+    }
+    e.n = 1;
+    e.pos = ip + 1;
+    e.ref = (uint8_t)(rf >> 8);
+    e.kind = BVCF_ALT_DEL;
+    e.alt_len = nref - 1u;
+    return true;
+  }
+  const W x = tk ^ rf;
+  if (nt == nref) {  // main.go:855-873: one record per differing base
+    const W same = zero_bytes_w<W>(x) & (rep_byte<W>(0x80u) & low_bytes_w<W>(nref));
+    e.n = nref - popc_w<W>(same);
+    e.mnp = true;
+    return true;
+  }
+  // common suffix: both ends moved to the word's last byte (a byte before the shorter one's start is zero there, a letter in the other)
+  const W xs = (tk << (8u * (kB - nt))) ^ (rf << (8u * (kB - nref)));
+  const uint32_t suffix = xs ? WordBytes<W>::clz(xs) >> 3 : kB;
+  if (nt > nref) {  // main.go:899-958
+    const uint32_t m = min(suffix, nref - 1u);  // (lr + r > 1)
+    const uint32_t offset = nref - m;
+    if (x & low_bytes_w<W>(offset)) {
+      e.err = BVCF_ERR_MIXED;
+      return true;
+    }
+    e.n = 1;
+    e.pos = ip + (long long)offset - 1;
+    e.ref = (uint8_t)(rf >> (8u * (offset - 1u)));
+    e.kind = BVCF_ALT_INS;
+    e.alt_off = t.off + offset;
+    e.alt_len = nt - m - offset;
+    return true;
+  }
+  {  // main.go:971-998
+    const uint32_t m = min(suffix, nt - 1u);  // (lt + r > 1)
+    const uint32_t offset = nt - m;
+    if (x & low_bytes_w<W>(offset)) {
+      e.err = BVCF_ERR_MIXED;
+      return true;
+    }
+    e.n = 1;
+    e.pos = ip + (long long)offset;
+    e.ref = (uint8_t)(rf >> (8u * offset));
+    e.kind = BVCF_ALT_DEL;
+    e.alt_len = nref - m - offset;
+    return true;
+  }
+}
+// One ALT token (k-th of strings.Split(alt, ","); `single`: the single-byte ALT path, eval_single) from the staged row.
+// ls: the line's start, staged: bytes of it in the row.  *t: the token's span (set whenever true is returned).
+template <uint32_t kRowBytes>
+__device__ inline bool eval_token_row(lds_words_t row, uint32_t staged, uint32_t ls, AlleleCtx &c, uint32_t k, bool single,
+                                      Span *t, AlleleEval &e) {
+  const uint32_t nref = c.ref.len, nalt = c.alt.len;
+  const uint32_t ref_rel = c.ref.off - ls, alt_rel = c.alt.off - ls, pos_rel = c.pos.off - ls;
+  if (nref - 1u > 15u || nalt - 1u > 15u) return false;
+  if (ref_rel + 16u > kRowBytes || alt_rel + 16u > kRowBytes || pos_rel + 16u > kRowBytes) return false;  // (the reads stay in the row)
+  if (ref_rel + nref > staged || alt_rel + nalt > staged || pos_rel + c.pos.len > staged) return false;
+  const u32x4 av = row_bytes16(row, alt_rel);
+  const u32x4 rv = row_bytes16(row, ref_rel);
+  // ---- the token
+  uint32_t start = 0, end = nalt;
+  if (!single) {
+    uint32_t cm = eq_mask16(av, ',') & ((1u << nalt) - 1u);
+    if (k > (uint32_t)__popc(cm)) return false;
+    uint32_t m = cm;
+    for (uint32_t i = 0; i + 1u < k; i++) m &= m - 1u;
+    if (k > 0u) {
+      start = (uint32_t)__ffs(m);  // (one past the k-th comma)
+      m &= m - 1u;
+    }
+    end = m ? (uint32_t)__ffs(m) - 1u : nalt;
+  }
+  t->off = c.alt.off + start;
+  t->len = end - start;
+  const u128_t a16 = WordBytes<u128_t>::of(av) >> (8u * start);
+  if (nref <= 8u && t->len <= 8u)
+    return eval_words<unsigned long long>(row, pos_rel, c, single, *t, (unsigned long long)a16 & low_bytes(t->len),
+                                          WordBytes<unsigned long long>::of(rv) & low_bytes(nref), e);
+  return eval_words<u128_t>(row, pos_rel, c, single, *t, a16 & low_bytes_w<u128_t>(t->len), WordBytes<u128_t>::of(rv) & low_bytes_w<u128_t>(nref), e);
 }
 
 // next token of the ALT field starting at *cursor (relative to alt.off); false when exhausted

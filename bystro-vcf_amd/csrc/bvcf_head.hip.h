@@ -148,6 +148,15 @@ __device__ unsigned long long g_head_t[6][8192];
 #else
 #define HSTAMP(k)
 #endif
+// -DBVCF_EXP_TIMES=3: the stamps split PART 2 instead (0: everything before it, 1: the owners' values over ds_bpermute, 2: the token,
+// 3: sums over the line's lanes, 4: lists / tasks / records, 5: back to the lines and the line record)
+#if defined(BVCF_EXP_TIMES) && BVCF_EXP_TIMES + 0 == 3
+#define HSTAMP_A(k)
+#define HSTAMP_B(k) HSTAMP(k)
+#else
+#define HSTAMP_A(k) HSTAMP(k)
+#define HSTAMP_B(k)
+#endif
 template <bool kAllWindows>
 __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
 #ifdef BVCF_EXP_TIMES
@@ -177,7 +186,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
 
   for (uint32_t line0 = blockIdx.x * kLinesPerStep; line0 < n_lines; line0 += stride) {
     __syncthreads();  // LDS of the previous step is free (also covers the s_ft copy)
-    HSTAMP(0);
+    HSTAMP_A(0);
 
     // ================= phase T: 16 lanes per line =================
     // lane gl of a group fetches the offsets of the group's round-gl line, so the 16 rounds' offsets
@@ -355,7 +364,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     }
     __syncthreads();
 
-    HSTAMP(1);
+    HSTAMP_A(1);
     // ================= phase S: one lane per line =================
     const uint32_t ll = threadIdx.x;
     const uint32_t line = line0 + ll;
@@ -460,7 +469,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
       bound = mode == 1 ? 1u : (mode == 2 ? b2 : 0u);
     }
 
-    HSTAMP(2);
+    HSTAMP_A(2);
     // ---- slot reservation, once per workgroup step: record slot `line` and task slot `line` are
     // the line's own; only further records / ALT indices draw from the batch counters.  Biallelic
     // lines — all of a 1KG-shaped file — never touch an atomic.
@@ -514,16 +523,19 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
       s_wave[w][3] = wt_real;
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < 5) {
+      // one thread per counter, so that the five atomics are one round trip: records, tasks, k_finish's list, k_gt's list, and
+      // -- streaming path -- the class maps of the extra tasks, which come from the cursor k_stream used (as many as tasks)
+      const uint32_t col = threadIdx.x == 4 ? 1u : threadIdx.x;
       uint32_t sum = 0;
-      for (int k = 0; k < kWavesPerWg; k++) sum += s_wave[k][threadIdx.x];
+      for (int k = 0; k < kWavesPerWg; k++) sum += s_wave[k][col];
+      if (threadIdx.x == 4 && !(a.fused && maps)) sum = 0;
+      uint32_t *ctr = threadIdx.x == 0 ? &a.counters->n_alleles : (threadIdx.x == 1 ? &a.counters->n_tasks :
+                      (threadIdx.x == 2 ? &a.counters->n_finish : (threadIdx.x == 3 ? &a.counters->n_real : &a.counters->cmap_maps)));
       uint32_t got = 0;
-      if (sum)
-        got = atomicAdd(threadIdx.x == 0 ? &a.counters->n_alleles : (threadIdx.x == 1 ? &a.counters->n_tasks :
-                        (threadIdx.x == 2 ? &a.counters->n_finish : &a.counters->n_real)), sum);
-      s_base[threadIdx.x == 2 ? 3 : (threadIdx.x == 3 ? 4 : threadIdx.x)] = got;
-      // streaming path: the class maps of the extra tasks come from the same cursor k_stream used
-      if (threadIdx.x == 1) s_base[2] = (sum && a.fused && maps) ? atomicAdd(&a.counters->cmap_maps, sum) : 0u;
+      if (sum) got = atomicAdd(ctr, sum);
+      // s_base: 0 records, 1 tasks, 2 class maps, 3 k_finish's list, 4 k_gt's list
+      s_base[threadIdx.x == 2 ? 3 : (threadIdx.x == 3 ? 4 : (threadIdx.x == 4 ? 2 : threadIdx.x))] = got;
     }
     __syncthreads();
     uint32_t task_rank = task_base;  // this line's first extra task, counted inside the workgroup
@@ -539,7 +551,8 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
     task_base = n_lines + s_base[1] + task_rank;
     const uint32_t map_base = a.fused ? s_base[2] + task_rank : task_base;
 
-    HSTAMP(3);
+    HSTAMP_A(3);
+    HSTAMP_B(0);
     // ---- part 2: the ALT tokens -> records and scan tasks, ONE LANE PER (line, ALT token) PAIR.
     // The reference walks a line's ALT tokens one after the other (main.go:774-999).  With one lane per line a wave that
     // holds a single multiallelic line ran the token loop three times with one lane working -- k_head's time followed the
@@ -622,6 +635,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
           o_res.regular = 1;
         }
         const uint32_t o_emitted = from_owner(emitted), o_used = from_owner(tasks_used), o_dropped = from_owner(dropped ? 1u : 0u);
+        HSTAMP_B(1);
         const uint32_t k = q0 + (uint32_t)lane - o_pair0;  // ALT index of this lane's token
         const uint32_t o_mode = o_flags & 3u;
         const bool o_deferred = (o_flags & 4u) != 0, o_fits = (o_flags & 8u) != 0, o_final0 = (o_flags & 16u) != 0;
@@ -648,7 +662,8 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         // ---- this lane's token
         AlleleEval e = AlleleEval{};
         Span t = c.alt;
-        if (pl) {
+        // (REF, ALT and POS as whole words from the staged head when they are short and lie inside it: eval_token_row)
+        if (pl && !eval_token_row<kHeadStage>(as_lds_words(&s_head[oll * kHeadRow]), c.buf.n, o_ls, c, k, o_mode == 1, &t, e)) {
           if (o_mode == 1) {
             eval_single(c, e);
           } else {
@@ -667,6 +682,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
             eval_token(c, t, e);
           }
         }
+        HSTAMP_B(2);
         // ---- what the tokens before it in the line did (exclusive sums over the line's lanes of this round, plus what
         // the line carries from the round before)
         const uint32_t seg_lane = o_pair0 > q0 ? o_pair0 - q0 : 0u;
@@ -683,6 +699,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         const uint32_t emitted_before = o_emitted + seg_excl(n_me);
         const uint32_t used_before = o_used + seg_excl(tk_me);
         uint32_t stype_me = 0;
+        HSTAMP_B(3);
         // this token's place in k_gt's list (see want_real): written whether or not the token ends up with a scan
         uint32_t real_at = kNoTask, real_task = kNoTask;
         if (pl && a.fused && ns > 0 && k > 0 && o_mode == 2u) {
@@ -791,6 +808,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
           }
         }
         if (real_at < a.max_tasks) a.real_tasks[real_at] = real_task;
+        HSTAMP_B(4);
         // ---- back to the lines: the sums up to and including the last of their tokens in this round
         const uint32_t seg_end = min(pair0 + n_tok, q0 + (uint32_t)kWave) - q0 - 1u;  // (meaningful where `mine`)
         const uint32_t from = (mine ? seg_end : (uint32_t)lane) * 4u;
@@ -827,7 +845,7 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
       if (ns == 0 || final0) n_fields = a.n_header;  // (k_stream only lists the lines its regular scan accepted: ns sample fields)
     }
 
-    HSTAMP(4);
+    HSTAMP_A(4);
     // ---- line record
     if (active) {
       bvcf_line L;
@@ -848,7 +866,8 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
       if (ns > 0 && !task_written && !a.fused) put_task(a, line, line, 0, cend, cend, BVCF_NO_CMAP);
       if (!primary_written && line < a.max_alleles) a.alleles[line].gt_task = kNoTask;
     }
-    HSTAMP(5);
+    HSTAMP_A(5);
+    HSTAMP_B(5);
   }
 #ifdef BVCF_EXP_TIMES
   if (threadIdx.x == 0 && blockIdx.x < 8192)
@@ -857,8 +876,9 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
 }
 
 __global__ __launch_bounds__(kWgThreads) void k_head(KernelArgs a) { k_head_body<true>(a); }
-// for chains that overlap with another batch's k_stream (see kAllWindows): 149 registers, three waves per SIMD
-__global__ __launch_bounds__(kWgThreads) void k_head_lean(KernelArgs a) { k_head_body<false>(a); }
+// for chains that overlap with another batch's k_stream (see kAllWindows)
+// (three waves per SIMD: 168 registers; without the bound the compiler takes 175 and a workgroup less fits a CU)
+__global__ __launch_bounds__(kWgThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_head_lean(KernelArgs a) { k_head_body<false>(a); }
 
 // ------------------------------------------------------------------ k_finish
 

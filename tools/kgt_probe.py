@@ -33,7 +33,8 @@ ctx.close()
 if os.environ.get("KGT_HEAD_PHASES"):  # needs a -DBVCF_EXP_TIMES build (BVCF_LIB=...): k_head's time per phase
     import ctypes as C
     import numpy as np
-    ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=1, max_lines=rows + 16, max_alleles=n_alt,
+    # (KGT_SLOTS=2: k_head_lean, the kernel of chains with blocks in flight; the blocks still run one at a time)
+    ctx = bv.Ctx(bg.n_header_fields(cfg), max_batch_bytes=nbytes, n_slots=int(os.environ.get("KGT_SLOTS", "1")), max_lines=rows + 16, max_alleles=n_alt,
                  cmap_bytes=min((n_alt + nbytes // (4 * ns + 8) + 16 * 8192) * stride + 4096, 0xFFFFFF00))
     ctx.bench_device([t.data_ptr()], [nbytes], 2, slots=1)
     hbuf = (C.c_ulonglong * (6 * 8192))()
@@ -42,6 +43,9 @@ if os.environ.get("KGT_HEAD_PHASES"):  # needs a -DBVCF_EXP_TIMES build (BVCF_LI
     hp = np.frombuffer(hbuf, dtype=np.uint64).reshape(6, 8192).astype(np.float64)
     busy = hp[1] > 0
     names = ["loop top / barrier", "phase T: tokenise", "part 1: gate, ALT shape", "slot reservation", "part 2: alleles, records, tasks", "line record"]
+    if os.environ["KGT_HEAD_PHASES"] == "3":  # a -DBVCF_EXP_TIMES=3 build: part 2 split
+        names = ["everything before part 2", "part 2: owners' values (ds_bpermute)", "part 2: the token", "part 2: sums over the line's lanes",
+                 "part 2: lists, tasks, records", "back to the lines, line record"]
     print("k_head phases (shader clock ticks per workgroup, mean / p95 over %d workgroups):" % busy.sum())
     for k in range(6):
         print("  %-34s %9.0f %9.0f" % (names[k], hp[k, busy].mean(), np.percentile(hp[k, busy], 95)))
