@@ -251,3 +251,59 @@ def test_dense_lines_agree_between_paths(bv, bvcf_path):
                 n_cmp += 1
                 n_dense_further += int(y["alt_idx"]) > 0 and not int(y["flags"]) & 2
     assert n_cmp > 250 and n_dense_further > 10
+
+
+def test_ref_alt_lengths_around_the_word_sizes(bv):
+    """k_head reads REF / ALT / POS as 8- or 16-byte words from the line's staged head (eval_token_row) and falls back to the
+    byte walk (eval_token, main.go:774-999) past them: lengths around 8 and 16, fields that straddle the staged 64 bytes
+    (long ID), shared suffixes and prefixes of every length, mismatches in the padding (MIXED), POS of 9 and 10 digits"""
+    rng = random.Random(77)
+    ns = 5
+    bases = "ACGT"
+
+    def rb(n):
+        return "".join(rng.choice(bases) for _ in range(n))
+
+    rows = []
+    pos = 1000
+    lens = [1, 2, 3, 7, 8, 9, 10, 15, 16, 17, 20]
+    for li in range(900):
+        pos += rng.randint(1, 40)
+        lr = rng.choice(lens)
+        ref = rb(lr)
+        alts = []
+        for _ in range(rng.choice([1, 1, 1, 2, 3])):
+            shape = rng.randint(0, 7)
+            lt = rng.choice(lens)
+            if shape == 0:      # unrelated token of some length
+                tok = rb(lt)
+            elif shape == 1:    # insertion after a shared prefix, sharing a suffix of some length
+                p = rng.randint(1, lr)
+                tok = ref[:p] + rb(rng.randint(1, 9)) + ref[p:]
+            elif shape == 2:    # deletion, sharing prefix and suffix
+                if lr < 2:
+                    tok = ref + rb(2)
+                else:
+                    p = rng.randint(1, lr - 1)
+                    q = rng.randint(p, lr)
+                    tok = ref[:p] + ref[q:]
+            elif shape == 3:    # equal length: a few differing bases (or none)
+                tok = "".join(c if rng.random() < 0.7 else rng.choice(bases) for c in ref)
+            elif shape == 4:    # shares only a suffix (the prefix test fails: MIXED) or only the first base
+                s = rng.randint(0, lr)
+                tok = rb(rng.randint(1, 6)) + ref[lr - s:]
+            elif shape == 5:    # single base
+                tok = rng.choice([ref[0], rng.choice(bases)])
+            elif shape == 6:    # junk
+                tok = rng.choice(["N", "", "<DEL>", "a", ref[:1] + "N" + ref[1:], "*"])
+            else:               # the whole REF repeated / truncated
+                tok = (ref * 3)[: rng.choice(lens)]
+            alts.append(tok)
+        ident = rng.choice(["rs%d" % li, ".", "rs" + "9" * rng.randint(20, 45)])   # (a long ID pushes REF / ALT past byte 48 / 64)
+        pos_s = rng.choice([str(pos), str(pos), str(10 ** 8 + pos), str(10 ** 9 + pos), "0%d" % pos, str(2 ** 31 + pos)])
+        gts = [rng.choice(["0|0", "0|1", "1|1", "1|2", "2|0", ".|.", "0|3"]) for _ in range(ns)]
+        rows.append("\t".join([rng.choice(["1", "chr7"]), pos_s, ident, ref, ",".join(alts), "50", "PASS", "NS=%d" % ns, "GT"] + gts))
+    vcf = (vcfgen.header(ns) + "\n".join(rows) + "\n").encode()
+    out = both(bv, vcf, {"allow": ""})
+    assert out.count(b"\n") > 600 and out.count(b"DEL") > 50 and out.count(b"INS") > 50
+    both(bv, vcf, {"allow": "", "keepId": True, "keepInfo": True, "keepPos": True}, max_batch_bytes=1 << 16)
