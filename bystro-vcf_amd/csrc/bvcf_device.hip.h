@@ -25,9 +25,12 @@
 //   k_stream       one wave walks a 64 KiB tile: finds the lines that start in it, tokenises their
 //                  fixed columns and scans ALT #1 straight away (the scan's loads ARE the newline
 //                  search: a regular line ends where 4*ns bytes of "x|y<TAB>" end)
-//   k_scan_*       exclusive scan of the per-tile line counts
-//   k_order        tile-local line entries -> input-ordered line_off / line_len / results
-// after which k_head, k_gt (further ALT indices only) and k_finish run as above.
+//   (k_stream_gen  the same for sample fields of any shape -- GT:DP:GQ ... --, bvcf_streamgen.hip.h; chosen per batch)
+//   k_order        tile-local line entries -> input-ordered line_off / line_len / results and the batch's line count
+//                  (a workgroup adds up the one-pass kernel's per-wave line totals and scans its own tiles' counts itself)
+// after which k_head (k_head_lean when blocks are in flight), k_gt -- only the task slots k_head listed as holding a scan:
+// deferred lines and further ALT indices of dense lines; it fills their allele records itself -- and k_finish (lines whose
+// ALT #1 was deferred) run.
 //
 //   (bvcf_params.want_name_lists, after k_finish: k_name_len / k_name_scan / k_name_write render the het / hom / missing
 //    sample-name lists of every output allele as text -- main.go:612-656 -- see bvcf_names.hip.h)
