@@ -351,14 +351,21 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
           row[3] = hv[r].w;
         }
       }
-      // the others: tokenised from the text, 16 lanes a line
+      // the others (every line of a k_stream_gen batch, the first line of a k_stream wave's run; the census path): tokenised from
+      // the text, 16 lanes a line, the first window of the next round's line requested before this round's is parsed
+      auto wants = [&](uint32_t r) -> bool {
+        const uint32_t ll = r * kGroupsPerWg + g;
+        return r < kRounds && line0 + ll < n_lines && !(s_len[ll] & kHasHeadBits);
+      };
+      u32x4 v_next = {0u, 0u, 0u, 0u};
+      if (wants(0)) v_next = load16(a.buf, s_ls[g] + 16u * gl, a.cap);
 #pragma nounroll
       for (uint32_t r = 0; r < kRounds; r++) {
-        const uint32_t ll = r * kGroupsPerWg + g;
-        const uint32_t lf = s_len[ll];
-        if (line0 + ll < n_lines && !(lf & kHasHeadBits)) {
-          const uint32_t ls_r = s_ls[ll];
-          tokenise(r, ls_r, lf, load16(a.buf, ls_r + 16u * gl, a.cap));
+        const u32x4 v_first = v_next;
+        if (wants(r + 1u)) v_next = load16(a.buf, s_ls[(r + 1u) * kGroupsPerWg + g] + 16u * gl, a.cap);
+        if (wants(r)) {
+          const uint32_t ll = r * kGroupsPerWg + g;
+          tokenise(r, s_ls[ll], s_len[ll], v_first);
         }
       }
     }
@@ -663,7 +670,9 @@ __device__ __forceinline__ void k_head_body(const KernelArgs &a) {
         AlleleEval e = AlleleEval{};
         Span t = c.alt;
         // (REF, ALT and POS as whole words from the staged head when they are short and lie inside it: eval_token_row)
-        if (pl && !eval_token_row<kHeadStage>(as_lds_words(&s_head[oll * kHeadRow]), c.buf.n, o_ls, c, k, o_mode == 1, &t, e)) {
+        // (a SNP -- one REF byte, one ALT byte -- is two byte reads in eval_single: cheaper than fetching the words)
+        const bool snp = o_mode == 1 && c.ref.len == 1u;
+        if (pl && (snp || !eval_token_row<kHeadStage>(as_lds_words(&s_head[oll * kHeadRow]), c.buf.n, o_ls, c, k, o_mode == 1, &t, e))) {
           if (o_mode == 1) {
             eval_single(c, e);
           } else {
