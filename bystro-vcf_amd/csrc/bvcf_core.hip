@@ -120,6 +120,7 @@ struct bvcf_ctx {
   // left to k_gt) or k_stream_gen (any fields, one pass).  Adaptive: a batch whose lines were mostly of the other
   // kernel's shape switches (the results are the same either way); BVCF_GEN_STREAM=0 / 1 pins it.
   bool gen_mode = false;
+  uint32_t last_real = 0xFFFFFFFFu, last_finish = 0xFFFFFFFFu;  // the last collected batch's counters->n_real / n_finish (unknown: full grids)
   bool shape_seen = false;  // gen_mode has had its first hint (peek_line_shape) or a batch's counters
   int gen_policy = -1;  // -1 adaptive, 0 never, 1 always
   uint32_t gen_grid = 0;
@@ -507,6 +508,9 @@ void launch_names(bvcf_ctx *c, const KernelArgs &a, const NameArgs &na, hipStrea
 
 // a batch's counters are in: should the next one go through the other streaming kernel?
 void adapt_stream_kernel(bvcf_ctx *c, bool was_gen, const BatchCounters &ctr) {
+  // how many scans the last batch left to k_gt, and lines to k_finish: the grids of the next batch's (launch_chain)
+  c->last_real = ctr.n_real;
+  c->last_finish = ctr.n_finish;
   if (c->gen_policy >= 0 || !c->fused || ctr.n_lines < 16) return;
   c->shape_seen = true;
   if ((uint64_t)ctr.n_other_shape * 2u > ctr.n_lines) c->gen_mode = !was_gen;
@@ -547,8 +551,17 @@ void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t e
       hipLaunchKernelGGL(k_head_lean, dim3(c->n_cu * head_wgs), dim3(kWgThreads), 0, st, a);
     else
       hipLaunchKernelGGL(k_head, dim3(c->n_cu * head_wgs), dim3(kWgThreads), 0, st, a);
-    if (!(skip & 2)) hipLaunchKernelGGL(k_gt, dim3(c->gt_grid / gt_div), dim3(kWgThreads), 0, st, a);
-    if (!(skip & 4)) hipLaunchKernelGGL(k_finish, dim3(c->n_cu * 4), dim3(kWgThreads), 0, st, a);
+    // k_gt and k_finish walk lists (real_tasks, finish_items) with grid strides: any grid is right.  A file of biallelic lines
+    // leaves both empty, and a thousand workgroups that start to find that out hold wave slots the next blocks' scans would
+    // use; the grids follow what the last collected batch needed (a wave of k_gt per two scans, a thread of k_finish per line).
+    const uint32_t gt_full = (uint32_t)c->gt_grid / (uint32_t)gt_div;
+    const uint32_t gt_wgs = c->last_real == 0xFFFFFFFFu ? gt_full
+                            : std::min<uint32_t>(gt_full, std::max<uint32_t>((uint32_t)c->n_cu / 4u, c->last_real / (2u * kWavesPerWg) + 1u));
+    const uint32_t fin_full = (uint32_t)c->n_cu * 4u;
+    const uint32_t fin_wgs = c->last_finish == 0xFFFFFFFFu ? fin_full
+                             : std::min<uint32_t>(fin_full, std::max<uint32_t>((uint32_t)c->n_cu / 4u, c->last_finish / kWgThreads + 1u));
+    if (!(skip & 2)) hipLaunchKernelGGL(k_gt, dim3(gt_wgs), dim3(kWgThreads), 0, st, a);
+    if (!(skip & 4)) hipLaunchKernelGGL(k_finish, dim3(fin_wgs), dim3(kWgThreads), 0, st, a);
     if (a.dosage) hipLaunchKernelGGL(k_dosage, dim3(c->gt_grid), dim3(kWgThreads), 0, st, a);
     return;
   }
