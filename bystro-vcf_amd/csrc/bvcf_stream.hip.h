@@ -398,7 +398,11 @@ __global__ __launch_bounds__(kWgThreads) void k_stream(KernelArgs a) {
           peA = peB;
           hv_ok = hvc_ok;
           mtA = mtB;
+#ifdef BVCF_EXP_NO_HEAD_BITS  // (probe: what do the 32 bytes of TAB bitmap per line cost this kernel? k_head tokenises such lines itself)
+          bitsA = false;
+#else
           bitsA = true;
+#endif
           STAMP(4);
         }
       };
