@@ -518,8 +518,8 @@ void adapt_stream_kernel(bvcf_ctx *c, bool was_gen, const BatchCounters &ctr) {
 
 void launch_chain(bvcf_ctx *c, const KernelArgs &a, hipStream_t st, hipEvent_t ev_gt0, hipEvent_t ev_gt1, Slot *slot = nullptr) {
   if (a.fused) {
-    // The one-pass kernels of ALL batches go through one stream of the ctx, one after the other at full rate; what follows a
-    // batch's pass runs on the slot's stream beside the next batches' passes.
+    // (experiments builds, BVCF_SCAN_STREAM=1: the one-pass kernels of ALL batches through one stream of the ctx, what follows
+    // a batch's pass on the slot's stream behind events -- the chain then runs nearly serially; scan_stream is null otherwise)
     const bool split = c->scan_stream && slot && slot->ev_in && slot->ev_scan;
     hipStream_t ss = split ? c->scan_stream : st;
     if (split) {
@@ -1134,12 +1134,14 @@ int bvcf_create(bvcf_ctx **out, const bvcf_params *p) {
   }
 #endif
   c->stream_grid = c->n_cu * per_cu;
+#ifdef BVCF_EXPERIMENTS
+  // (round 5, measured and not adopted: every batch's one-pass kernel on one stream of the ctx; LDS asked for with k_stream
+  // to cap its workgroups per CU over all batches -- profiles/r05_c4_in_flight_what_the_ten_percent_are.txt)
   if (c->p.n_slots > 1 && getenv("BVCF_SCAN_STREAM") && atoi(getenv("BVCF_SCAN_STREAM")) == 1 &&
       hipStreamCreateWithFlags(&c->scan_stream, hipStreamNonBlocking) != hipSuccess) {
     c->err = "hipStreamCreate failed";
     return fail(BVCF_E_HIP);
   }
-#ifdef BVCF_EXPERIMENTS
   if (const char *e = getenv("BVCF_EXP_STREAM_LDS")) c->stream_lds_pad = (uint32_t)atoi(e);
 #endif
   per_cu = 0;
