@@ -3,9 +3,12 @@
 set -o pipefail
 O=gpurun_out/abf; mkdir -p $O
 profs=$1; shift
+libs=("$@")
 for rep in 1 2 3; do
+# (the boxes drift within a call: every round starts with another build)
+rot=("${libs[@]:$(( (rep - 1) % ${#libs[@]} ))}" "${libs[@]:0:$(( (rep - 1) % ${#libs[@]} ))}")
 for prof in $profs; do
-for lib in "$@"; do
+for lib in "${rot[@]}"; do
   name=${prof}_$(basename $(dirname $lib))_$rep
   BVCF_LIB=$PWD/$lib python3 bench.py --no-e2e --no-cpu-baseline --no-real-data --profile $prof > $O/$name.out 2> $O/$name.err || { echo "$name failed"; tail -3 $O/$name.err; continue; }
   python3 - $O/$name.out "$name" <<'PY'
